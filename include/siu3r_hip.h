@@ -1,0 +1,141 @@
+/*
+ * siu3r_hip.h -- C ABI of libsiu3r_hip.so, the MI355X (gfx950) hot path of SIU3R inference.
+ *
+ * Conventions:
+ *   - every entry point returns 0 on success, non-zero on error; siu3r_last_error() returns a
+ *     thread-local message.  The Python wrappers raise RuntimeError, mirroring the reference's
+ *     TORCH_CHECK behaviour (reference: src/models/croco/curope/curope.cpp:54-59, kernels.cu:91-94).
+ *   - all pointers are raw DEVICE pointers unless stated; no entry point allocates, synchronises
+ *     or owns memory; kernels are enqueued on `stream` (a hipStream_t passed as void*).
+ *   - dtype codes: SIU3R_BF16 = 0, SIU3R_F32 = 1.
+ *   - activations are channel-last ("NHWC" / token-major) everywhere.
+ *
+ * Each group cites the reference interface it replaces.
+ */
+#ifndef SIU3R_HIP_H
+#define SIU3R_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIU3R_BF16 0
+#define SIU3R_F32 1
+
+const char* siu3r_last_error(void);
+int siu3r_abi_version(void);
+
+/* ---- seam 1: curope.rope_2d(tokens, positions, base, fwd)
+ * reference: src/models/croco/curope/curope.cpp:49-65 (dispatch), kernels.cu:17-108 (kernel).
+ * tokens [B,N,H,D] in place (stride_d == 1), positions int64 [B,N,2] contiguous, D % 4 == 0.    */
+int siu3r_rope2d(void* tokens, int dtype, int B, int N, int H, int D, int64_t stride_b,
+                 int64_t stride_n, int64_t stride_h, const int64_t* positions, float base, float fwd,
+                 void* stream);
+
+/* ---- GEMM / implicit-GEMM convolution on MFMA (bf16 operands, fp32 accumulate).
+ * Replaces every nn.Linear / nn.Conv2d / nn.ConvTranspose2d(k==stride) on the path
+ * (reference: croco/blocks.py:58-79,94-112; heads/dpt_block.py; vit_adapter.py; video_seg_decoder.py).
+ * C[M,N] = epilogue(A[M,K] * W[N,K]^T).  W is pre-packed bf16 [N, Kpad] (Kpad % 64 == 0, zero padded);
+ * w_lo (may be NULL) holds the bf16 residual of the fp32 weight and enables the 3-pass
+ * "bf16x3" mode (A must then be fp32): C = Ahi*Whi + Ahi*Wlo + Alo*Whi, ~fp32 accuracy. */
+typedef struct {
+  const void* a;          /* activations */
+  const void* w_hi;       /* bf16 [N,Kpad] */
+  const void* w_lo;       /* bf16 [N,Kpad] or NULL */
+  void* c;                /* output */
+  const float* bias;      /* [N] (or [Cout] for out_mode 1) or NULL */
+  const void* residual;   /* added after activation, same indexing as c, or NULL */
+  int32_t m, n, k, kpad;
+  int64_t lda, ldc, ldr;  /* row strides in elements (dense A / C / residual) */
+  int32_t a_dtype, c_dtype, r_dtype;
+  int32_t act;            /* 0 none, 1 exact-erf GELU, 2 ReLU */
+  int32_t relu_in;        /* apply ReLU to A while loading */
+  /* batching: blockIdx.z selects the batch; strides in elements */
+  int32_t batch;
+  int64_t sa, sw, sc, sr;
+  /* A addressing: 0 dense rows; 1 NHWC conv gather; 2 NCHW fp32 16x16 patchify (patch-embed) */
+  int32_t a_mode;
+  int32_t ih, iw, cin, kh, kw, stride, pad, oh, ow; /* conv geometry (a_mode 1,2) */
+  /* output addressing: 0 row-major; 1 conv-transpose (kernel==stride) pixel shuffle:
+     n = (ky*up+kx)*cout + co, row m=(b,iy,ix) -> out[b, iy*up+ky, ix*up+kx, co] */
+  int32_t out_mode, up, cout;
+  /* fused epilogue extra: bilinear x2 (align_corners=True) upsample-add of a low-res NHWC map
+     (GS head: feat_up(path_1) + ReLU(conv7x7(img)), reference dpt_gs_head.py:160-162) */
+  const void* up_src;     /* [B, oh/2, ow/2, n] or NULL */
+  int32_t up_dtype;
+} siu3r_gemm_params;
+int siu3r_gemm(const siu3r_gemm_params* p, void* stream);
+
+/* ---- LayerNorm over the last dim (fp32 in, act-dtype out); reference: nn.LayerNorm call sites
+ * croco/blocks.py:127-191 (eps 1e-6), video_seg_decoder.py:945-1018 (eps 1e-5). */
+int siu3r_layernorm(const float* x, void* y, int y_dtype, const float* gamma, const float* beta,
+                    int64_t rows, int C, int64_t ldx, int64_t ldy, float eps, void* stream);
+
+/* ---- fused attention (flash style, online softmax), head_dim 64 or 32.
+ * Replaces Attention/CrossAttention (croco/blocks.py:94-112,149-169, incl. RoPE2D on q,k) and
+ * the Mask2Former decoder attentions (video_seg_decoder.py:782-912, nn.MultiheadAttention 946-983).
+ * q,k,v: element strides (batch, token, head); head_dim contiguous.  out [B,Nq,H*D] contiguous.
+ * rope_cos/sin: fp32 [max_pos, D/4] tables or NULL; qpos/kpos int64 [B,N,2] (y,x).
+ * mask: uint8 [B,Nq,Nk] (1 = blocked), shared by all heads, or NULL. split3 = bf16x3 mode (fp32 io). */
+typedef struct {
+  const void *q, *k, *v;
+  void* out;
+  int32_t dtype;          /* dtype of q,k,v,out */
+  int32_t B, H, Nq, Nk, D;
+  int64_t q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh;
+  float scale;
+  const float *rope_cos, *rope_sin;
+  int32_t rope_max_pos;
+  const int64_t *qpos, *kpos;
+  const uint8_t* mask;
+  int32_t split3;
+} siu3r_attn_params;
+int siu3r_attention(const siu3r_attn_params* p, void* stream);
+
+/* ---- element-wise / gather kernels (see DESIGN.md for the HBM roofline of each) ---------- */
+/* y = a + b (b broadcast over rows when b_rows < rows: row r uses b[r % b_rows]) */
+int siu3r_add(const float* a, const float* b, float* y, int64_t rows, int64_t b_rows, int C, void* stream);
+/* image [N,3,H,W] fp32 (NCHW) -> [N,H,W,8] channel-last, zero padded channels */
+int siu3r_pack_image_nhwc8(const float* img, void* out, int out_dtype, int N, int H, int W, void* stream);
+/* bilinear resize NHWC; align_corners as in F.interpolate; y = affine(resize(x) + addend)
+ * (heads/dpt_block.py:230-235 align=1; vit_adapter.py:429-433, video_seg_decoder.py:2173-2178 align=0) */
+int siu3r_resize_bilinear(const void* x, int x_dtype, void* y, int y_dtype, const void* addend, int add_dtype,
+                          const float* ch_scale, const float* ch_shift, int N, int IH, int IW, int OH, int OW,
+                          int C, int align_corners, void* stream);
+/* y = x*scale[c] + shift[c] (+ addend) ; eval-mode BatchNorm folded (vit_adapter.py:436-440) */
+int siu3r_affine_add(const void* x, int x_dtype, const void* addend, int add_dtype, void* y, int y_dtype,
+                     const float* ch_scale, const float* ch_shift, int64_t rows, int C, void* stream);
+/* 3x3 stride-2 pad-1 max pool, NHWC (vit_adapter.py:226) */
+int siu3r_maxpool3x3s2(const void* x, void* y, int dtype, int N, int IH, int IW, int C, void* stream);
+/* depth-wise 3x3 + bias + GELU over the 3 token scales of the adapter ConvFFN (vit_adapter.py:16-59) */
+int siu3r_dwconv3x3_gelu(const void* x, void* y, int dtype, const float* w9c, const float* bias, int B, int H,
+                         int W, int C, void* stream);
+/* multi-scale deformable attention sampling core (vit_adapter/blocks.py:217-267):
+ * value [B,S,heads,d]; offs_aw fp32 [B,Q,heads*L*P*3] = per row [offsets (h,L,P,2) | logits (h,L,P)];
+ * ref fp32 [Q,L,2]; shapes int32 [L,2] (h,w) host pointer; out [B,Q,heads*d]. */
+int siu3r_msdeform_sample(const void* value, int v_dtype, const float* offs_aw, const float* ref,
+                          const int32_t* shapes_host, void* out, int out_dtype, int B, int S, int Q, int heads,
+                          int d, int L, int P, void* stream);
+/* GroupNorm(32) on NHWC (video_seg_decoder.py:2002-2050): two kernels, stats then apply
+ * y = relu?(gn(x)) + addend? ; stats is a [N,groups,2] fp32 workspace */
+int siu3r_groupnorm(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta,
+                    float* stats_ws, const void* addend, int add_dtype, int relu, int N, int HW, int C,
+                    int groups, float eps, void* stream);
+/* pts3d = xyz/|xyz| * expm1(|xyz|)  (heads/postprocess.py:45-61), in place on [n,3] fp32 */
+int siu3r_pts3d_exp(float* xyz, int64_t n, void* stream);
+/* UnifiedGaussianAdapter.forward (gaussian_adapter.py:81-110): raw [n,83] -> fields (all fp32) */
+int siu3r_gaussian_adapter(const void* raw, int raw_dtype, float* opacities, float* scales, float* rotations,
+                           float* harmonics, float* covariances, int64_t n, void* stream);
+/* Mask2Former attention mask (video_seg_decoder.py:1461-1478 + 1306-1308): mask logits
+ * [B,T,IH,IW,Q] (channel-last) -> uint8 [B,Q,T*OH*OW], 1 = blocked; rows fully blocked are cleared. */
+int siu3r_m2f_attn_mask(const float* mask_logits, uint8_t* out, int32_t* row_counts_ws, int B, int T, int IH,
+                        int IW, int OH, int OW, int Q, void* stream);
+
+/* fp32 [rows, k] (row stride ldx) -> bf16 hi plane [rows,kpad] (+ optional lo = bf16(x - hi)), zero padded:
+ * weight / operand pre-packing for siu3r_gemm. */
+int siu3r_split_bf16(const float* x, void* hi, void* lo, int64_t rows, int k, int kpad, int64_t ldx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

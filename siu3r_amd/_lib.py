@@ -1,0 +1,99 @@
+"""ctypes binding of libsiu3r_hip.so (the C ABI declared in include/siu3r_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a symbol is absent the
+import raises, and every op raises RuntimeError when handed a non-GPU tensor.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsiu3r_hip.so")
+
+BF16, F32 = 0, 1
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("c", C.c_void_p),
+        ("bias", C.c_void_p), ("residual", C.c_void_p),
+        ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("kpad", C.c_int32),
+        ("lda", C.c_int64), ("ldc", C.c_int64), ("ldr", C.c_int64),
+        ("a_dtype", C.c_int32), ("c_dtype", C.c_int32), ("r_dtype", C.c_int32),
+        ("act", C.c_int32), ("relu_in", C.c_int32),
+        ("batch", C.c_int32),
+        ("sa", C.c_int64), ("sw", C.c_int64), ("sc", C.c_int64), ("sr", C.c_int64),
+        ("a_mode", C.c_int32),
+        ("ih", C.c_int32), ("iw", C.c_int32), ("cin", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+        ("stride", C.c_int32), ("pad", C.c_int32), ("oh", C.c_int32), ("ow", C.c_int32),
+        ("out_mode", C.c_int32), ("up", C.c_int32), ("cout", C.c_int32),
+        ("up_src", C.c_void_p), ("up_dtype", C.c_int32),
+    ]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p),
+        ("dtype", C.c_int32),
+        ("B", C.c_int32), ("H", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("D", C.c_int32),
+        ("q_sb", C.c_int64), ("q_sn", C.c_int64), ("q_sh", C.c_int64),
+        ("k_sb", C.c_int64), ("k_sn", C.c_int64), ("k_sh", C.c_int64),
+        ("v_sb", C.c_int64), ("v_sn", C.c_int64), ("v_sh", C.c_int64),
+        ("scale", C.c_float),
+        ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("rope_max_pos", C.c_int32),
+        ("qpos", C.c_void_p), ("kpos", C.c_void_p), ("mask", C.c_void_p),
+        ("split3", C.c_int32),
+    ]
+
+
+# name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/siu3r_hip.h.
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SIGNATURES = {
+    "siu3r_last_error": [],
+    "siu3r_abi_version": [],
+    "siu3r_rope2d": [_P, _I, _I, _I, _I, _I, _L, _L, _L, _P, _F, _F, _P],
+    "siu3r_gemm": [C.POINTER(GemmParams), _P],
+    "siu3r_layernorm": [_P, _P, _I, _P, _P, _L, _I, _L, _L, _F, _P],
+    "siu3r_attention": [C.POINTER(AttnParams), _P],
+    "siu3r_add": [_P, _P, _P, _L, _L, _I, _P],
+    "siu3r_pack_image_nhwc8": [_P, _P, _I, _I, _I, _I, _P],
+    "siu3r_resize_bilinear": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "siu3r_affine_add": [_P, _I, _P, _I, _P, _I, _P, _P, _L, _I, _P],
+    "siu3r_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "siu3r_dwconv3x3_gelu": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "siu3r_msdeform_sample": [_P, _I, _P, _P, C.POINTER(C.c_int32), _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "siu3r_groupnorm": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "siu3r_pts3d_exp": [_P, _L, _P],
+    "siu3r_gaussian_adapter": [_P, _I, _P, _P, _P, _P, _P, _L, _P],
+    "siu3r_m2f_attn_mask": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "siu3r_split_bf16": [_P, _P, _P, _L, _I, _I, _L, _P],
+}
+_RESTYPES = {"siu3r_last_error": C.c_char_p}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; raise loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m siu3r_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the SIU3R hot path."
+        )
+    l = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(l, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().siu3r_last_error()
+        raise RuntimeError((msg.decode() if msg else f"{what} failed") + f" [rc={rc}]")

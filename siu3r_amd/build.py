@@ -1,0 +1,66 @@
+"""Build libsiu3r_hip.so (HIP kernels + C ABI) for gfx950, in-tree.
+
+`python -m siu3r_amd.build` or `siu3r_amd.build.build()`.  hipcc cross-compiles without a GPU.
+The .so lands next to this file so that it travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libsiu3r_hip.so")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest(path):
+    h = hashlib.sha1()
+    for f in [path, os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "siu3r_hip.h")]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src):
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    stamp = obj + ".sha1"
+    dg = _digest(path)
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dg:
+        return obj
+    cmd = ["hipcc", *FLAGS, "-c", path, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+    with open(stamp, "w") as fh:
+        fh.write(dg)
+    return obj
+
+
+def build(force: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(_compile, _sources()))
+    newest = max(os.path.getmtime(o) for o in objs)
+    if force or not os.path.exists(OUT) or os.path.getmtime(OUT) < newest:
+        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,335 @@
+// Fused (flash-style) attention for gfx950: S = (Q K^T) * scale -> online softmax -> O = P V,
+// with RoPE2D applied to Q and K on load (reference croco/blocks.py:94-112,149-169 + curope kernels.cu:17-82)
+// and an optional boolean key mask (Mask2Former masked cross-attention, video_seg_decoder.py:946-983).
+//
+// Work split: one workgroup (4 waves) per (batch, head, 128-query tile); each wave owns 32 queries.
+// K/V are streamed in 64-key tiles through double-buffered LDS (register-staged, one barrier per tile).
+// The score tile is computed TRANSPOSED (S^T = K Q^T, v_mfma_f32_32x32x16_bf16) so that every lane owns one
+// query column: row max / row sum are in-lane reductions plus one cross-half exchange, and the softmax
+// rescale factor is a per-lane scalar.  The P^T accumulator layout is fed straight back as the MFMA B operand
+// of O^T = V^T P^T using a "virtual k" ordering (key(h,j) = 16*sb + (j&3) + 8*(j>>2) + 4*h); V^T is built in
+// LDS with that same ordering in mind, so no cross-lane shuffle is needed between the two GEMMs.
+// SPLIT = bf16x3 mode: Q,K,P,V are split hi+lo and every product uses three MFMAs (~fp32 accuracy).
+#include "common.h"
+
+namespace {
+
+constexpr int KT = 64;           // keys per tile
+constexpr int VT_STRIDE = 136;   // bytes per V^T row: 64 keys * 2 B + 8 B pad (conflict-free ds_read_b64)
+constexpr float NEG_BIG = -1.0e30f;
+
+template <int D>
+__device__ __forceinline__ int k_off(int row, int chunk) {
+  if (D == 64) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+  return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
+
+template <int D, int IN_F32, int SPLIT>
+__global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
+  constexpr int PL = SPLIT ? 2 : 1;
+  constexpr int K_BYTES = KT * D * 2;
+  constexpr int V_BYTES = D * VT_STRIDE;
+  constexpr int STAGE = PL * (K_BYTES + V_BYTES);
+  constexpr int CH = D / 32;  // chunks (8 elements) per thread per tile: 64 keys * D/8 chunks / 256 threads
+  constexpr int KS = D / 16;  // k-substeps of the score GEMM
+  constexpr int DT = D / 32;  // 32-row output tiles of O^T
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q_row = blockIdx.x * 128 + wave * 32 + l31;
+  const bool q_ok = q_row < p.Nq;
+  const int esz = IN_F32 ? 4 : 2;
+  const bool rope = p.rope_cos != nullptr;
+  const int Q4 = D / 4;
+
+  // ---------------- Q fragments (B operand: lane = query, 8 consecutive d per k-substep) ----------------
+  bf16x8 qf[KS], qfl[KS];
+  {
+    float qv[KS][8];
+    const unsigned char* qp = (const unsigned char*)p.q + ((int64_t)b * p.q_sb + (int64_t)q_row * p.q_sn + (int64_t)h * p.q_sh) * esz;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (q_ok) {
+        f32x8 v = load8_as_f32(qp, IN_F32 ? SIU3R_F32 : SIU3R_BF16, ks * 16 + 8 * lh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[ks][j] = v.v[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[ks][j] = 0.f;
+      }
+    }
+    if constexpr (D == 64) if (rope && q_ok) {
+      // head vector = [u_Y v_Y u_X v_X], quarters of D; for D=64: ks 0/1 = (u_Y, v_Y), ks 2/3 = (u_X, v_X)
+#pragma unroll
+      for (int ax = 0; ax < 2; ++ax) {
+        const int pos = (int)p.qpos[((int64_t)b * p.Nq + q_row) * 2 + ax];
+        const float* cs = p.rope_cos + (int64_t)pos * Q4 + 8 * lh;
+        const float* sn = p.rope_sin + (int64_t)pos * Q4 + 8 * lh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float c = cs[j], s = sn[j];
+          const float u = qv[2 * ax][j], v = qv[2 * ax + 1][j];
+          qv[2 * ax][j] = u * c - v * s;
+          qv[2 * ax + 1][j] = v * c + u * s;
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (SPLIT) {
+        uint4 hi, lo;
+        split_bf16x8(qv[ks], hi, lo);
+        qf[ks] = as_bf16x8(hi);
+        qfl[ks] = as_bf16x8(lo);
+      } else {
+        qf[ks] = as_bf16x8(pack_bf16x8(qv[ks]));
+      }
+    }
+  }
+
+  // ---------------- K/V tile staging ----------------
+  // D=64: thread -> (key = t>>2, chunk pair (c0, c0+2), c0 in {0,1,4,5});  D=32: (key = t>>2, chunk = t&3)
+  const int ld_key = t >> 2;
+  const int ld_c0 = (D == 64) ? ((t & 1) + 4 * ((t >> 1) & 1)) : (t & 3);
+  float kreg[CH][8], vreg[CH][8];
+  bool ld_ok = false;
+
+  auto load_tile = [&](int kt) {
+    const int key = kt * KT + ld_key;
+    ld_ok = key < p.Nk;
+    if (ld_ok) {
+      const unsigned char* kp = (const unsigned char*)p.k + ((int64_t)b * p.k_sb + (int64_t)key * p.k_sn + (int64_t)h * p.k_sh) * esz;
+      const unsigned char* vp = (const unsigned char*)p.v + ((int64_t)b * p.v_sb + (int64_t)key * p.v_sn + (int64_t)h * p.v_sh) * esz;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int ch = ld_c0 + 2 * c;
+        f32x8 a = load8_as_f32(kp, IN_F32 ? SIU3R_F32 : SIU3R_BF16, ch * 8);
+        f32x8 bb = load8_as_f32(vp, IN_F32 ? SIU3R_F32 : SIU3R_BF16, ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          kreg[c][j] = a.v[j];
+          vreg[c][j] = bb.v[j];
+        }
+      }
+      if (rope && D == 64) {
+        const int ax = ld_c0 >> 2;
+        const int pos = (int)p.kpos[((int64_t)b * p.Nk + key) * 2 + ax];
+        const float* cs = p.rope_cos + (int64_t)pos * Q4 + (ld_c0 & 1) * 8;
+        const float* sn = p.rope_sin + (int64_t)pos * Q4 + (ld_c0 & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float c = cs[j], s = sn[j];
+          const float u = kreg[0][j], v = kreg[CH - 1][j];
+          kreg[0][j] = u * c - v * s;
+          kreg[CH - 1][j] = v * c + u * s;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          kreg[c][j] = 0.f;
+          vreg[c][j] = 0.f;
+        }
+    }
+  };
+
+  auto store_tile = [&](int stage) {
+    unsigned char* sK = smem + stage * STAGE;
+    unsigned char* sV = sK + K_BYTES;
+    unsigned char* sKl = sK + K_BYTES + V_BYTES;
+    unsigned char* sVl = sKl + K_BYTES;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = ld_c0 + 2 * c;
+      const int ko = k_off<D>(ld_key, ch);
+      if (SPLIT) {
+        uint4 hi, lo;
+        split_bf16x8(kreg[c], hi, lo);
+        *(uint4*)(sK + ko) = hi;
+        *(uint4*)(sKl + ko) = lo;
+      } else {
+        *(uint4*)(sK + ko) = pack_bf16x8(kreg[c]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int d = ch * 8 + j;
+        const u16 hb = f32_to_bf16_bits(vreg[c][j]);
+        *(u16*)(sV + d * VT_STRIDE + ld_key * 2) = hb;
+        if (SPLIT) *(u16*)(sVl + d * VT_STRIDE + ld_key * 2) = f32_to_bf16_bits(vreg[c][j] - bf16_bits_to_f32(hb));
+      }
+    }
+  };
+
+  // ---------------- main loop ----------------
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+  const float sl2 = p.scale * 1.4426950408889634f;
+  const int nkt = (p.Nk + KT - 1) / KT;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    const unsigned char* sK = smem + cur * STAGE;
+    const unsigned char* sV = sK + K_BYTES;
+    const unsigned char* sKl = sK + K_BYTES + V_BYTES;
+    const unsigned char* sVl = sKl + K_BYTES;
+
+    // S^T tile: rows = keys (2 blocks of 32), cols = this wave's 32 queries
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int o = k_off<D>(kb * 32 + l31, ks * 2 + lh);
+        const bf16x8 kf = as_bf16x8(*(const uint4*)(sK + o));
+        if (SPLIT) {
+          const bf16x8 kfl = as_bf16x8(*(const uint4*)(sKl + o));
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl, qf[ks], sacc[kb], 0, 0, 0);
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfl[ks], sacc[kb], 0, 0, 0);
+        }
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
+      }
+    }
+    // scale, key-validity and mask; lane holds keys key(kb,r) = kt*64 + kb*32 + (r&3) + 8*(r>>2) + 4*lh
+    float mx = NEG_BIG;
+    const uint8_t* mrow = (p.mask && q_ok) ? p.mask + ((int64_t)b * p.Nq + q_row) * p.Nk : nullptr;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        bool ok = key < p.Nk;
+        if (ok && mrow) ok = mrow[key] == 0;
+        const float s = ok ? sacc[kb][r] * sl2 : NEG_BIG;
+        sacc[kb][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = exp2f(sacc[kb][r] - m_new);
+        sacc[kb][r] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+
+    // O^T += V^T P^T : 4 k-substeps of 16 keys; B operand = P registers as they are (virtual-k order)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        float pf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = sacc[kb][8 * sb + j];
+        bf16x8 ph, plo;
+        if (SPLIT) {
+          uint4 hi, lo;
+          split_bf16x8(pf, hi, lo);
+          ph = as_bf16x8(hi);
+          plo = as_bf16x8(lo);
+        } else {
+          ph = as_bf16x8(pack_bf16x8(pf));
+        }
+        const int kbase = (kb * 32 + 16 * sb + 4 * lh) * 2;  // byte offset of the lane's first 4 keys
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int vo = (dt * 32 + l31) * VT_STRIDE + kbase;
+          const uint2 a0 = *(const uint2*)(sV + vo);
+          const uint2 a1 = *(const uint2*)(sV + vo + 16);
+          const bf16x8 vf = as_bf16x8(make_uint4(a0.x, a0.y, a1.x, a1.y));
+          if (SPLIT) {
+            const uint2 b0 = *(const uint2*)(sVl + vo);
+            const uint2 b1 = *(const uint2*)(sVl + vo + 16);
+            const bf16x8 vfl = as_bf16x8(make_uint4(b0.x, b0.y, b1.x, b1.y));
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl, ph, oacc[dt], 0, 0, 0);
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, plo, oacc[dt], 0, 0, 0);
+          }
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, ph, oacc[dt], 0, 0, 0);
+        }
+      }
+    if (kt + 1 < nkt) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue: O[q, h*D + d] = O^T[d][q] / l ----------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.f / l_tot;
+  if (q_ok) {
+    unsigned char* op = (unsigned char*)p.out + (((int64_t)b * p.Nq + q_row) * ((int64_t)p.H * D) + (int64_t)h * D) * esz;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + 8 * g + 4 * lh;
+        const float o0 = oacc[dt][4 * g] * inv, o1 = oacc[dt][4 * g + 1] * inv, o2 = oacc[dt][4 * g + 2] * inv,
+                    o3 = oacc[dt][4 * g + 3] * inv;
+        if (IN_F32) {
+          *(float4*)(op + d * 4) = make_float4(o0, o1, o2, o3);
+        } else {
+          uint2 w;
+          w.x = (uint32_t)f32_to_bf16_bits(o0) | ((uint32_t)f32_to_bf16_bits(o1) << 16);
+          w.y = (uint32_t)f32_to_bf16_bits(o2) | ((uint32_t)f32_to_bf16_bits(o3) << 16);
+          *(uint2*)(op + d * 2) = w;
+        }
+      }
+  }
+}
+
+template <int D, int IN_F32, int SPLIT>
+int launch(const siu3r_attn_params& p, hipStream_t s) {
+  dim3 grid((p.Nq + 127) / 128, p.H, p.B), block(256);
+  hipLaunchKernelGGL((attn_kernel<D, IN_F32, SPLIT>), grid, block, 0, s, p);
+  SIU3R_LAUNCH_CHECK("siu3r_attention");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int siu3r_attention(const siu3r_attn_params* pp, void* stream) {
+  const siu3r_attn_params& p = *pp;
+  SIU3R_CHECK(p.q && p.k && p.v && p.out, "siu3r_attention: null pointer");
+  SIU3R_CHECK(p.D == 64 || p.D == 32, "siu3r_attention: head_dim %d unsupported (32 or 64)", p.D);
+  SIU3R_CHECK(p.B > 0 && p.H > 0 && p.Nq > 0 && p.Nk > 0, "siu3r_attention: empty problem");
+  SIU3R_CHECK(p.dtype == SIU3R_BF16 || p.dtype == SIU3R_F32, "siu3r_attention: bad dtype %d", p.dtype);
+  SIU3R_CHECK(!(p.split3 && p.dtype != SIU3R_F32), "siu3r_attention: bf16x3 mode needs fp32 tensors");
+  SIU3R_CHECK(!(p.rope_cos && p.D != 64), "siu3r_attention: RoPE2D path is specialised for head_dim 64");
+  SIU3R_CHECK(!(p.rope_cos && !(p.rope_sin && p.qpos && p.kpos)), "siu3r_attention: rope tables/positions missing");
+  const int64_t al = p.dtype == SIU3R_F32 ? 4 : 8;  // 16-byte vector loads
+  SIU3R_CHECK(p.q_sn % al == 0 && p.q_sh % al == 0 && p.q_sb % al == 0 && p.k_sn % al == 0 && p.k_sh % al == 0 &&
+                  p.k_sb % al == 0 && p.v_sn % al == 0 && p.v_sh % al == 0 && p.v_sb % al == 0,
+              "siu3r_attention: q/k/v strides must keep 16-byte alignment");
+  hipStream_t s = (hipStream_t)stream;
+  if (p.D == 64) {
+    if (p.split3) return launch<64, 1, 1>(p, s);
+    if (p.dtype == SIU3R_F32) return launch<64, 1, 0>(p, s);
+    return launch<64, 0, 0>(p, s);
+  } else {
+    if (p.split3) return launch<32, 1, 1>(p, s);
+    if (p.dtype == SIU3R_F32) return launch<32, 1, 0>(p, s);
+    return launch<32, 0, 0>(p, s);
+  }
+}

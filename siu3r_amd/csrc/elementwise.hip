@@ -1,0 +1,705 @@
+// HBM-bound kernels of the SIU3R path: RoPE2D (seam 1), LayerNorm, GroupNorm, bilinear resize,
+// deformable-attention sampling, depth-wise conv, Gaussian adapter, ...   All channel-last, vectorised
+// 16 B per lane where the layout allows, one pass over the data per kernel.
+#include "common.h"
+
+namespace {
+
+// ---- 4-element vector access of runtime dtype --------------------------------------------------
+struct f32x4v {
+  float v[4];
+};
+__device__ __forceinline__ f32x4v load4(const void* p, int dtype, int64_t i) {
+  f32x4v r;
+  if (dtype == SIU3R_F32) {
+    float4 a = *(const float4*)((const float*)p + i);
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+  } else {
+    uint2 a = *(const uint2*)((const u16*)p + i);
+    r.v[0] = bf16_bits_to_f32((u16)(a.x & 0xffff));
+    r.v[1] = bf16_bits_to_f32((u16)(a.x >> 16));
+    r.v[2] = bf16_bits_to_f32((u16)(a.y & 0xffff));
+    r.v[3] = bf16_bits_to_f32((u16)(a.y >> 16));
+  }
+  return r;
+}
+__device__ __forceinline__ void store4(void* p, int dtype, int64_t i, const f32x4v& r) {
+  if (dtype == SIU3R_F32) {
+    *(float4*)((float*)p + i) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+  } else {
+    uint2 w;
+    w.x = (uint32_t)f32_to_bf16_bits(r.v[0]) | ((uint32_t)f32_to_bf16_bits(r.v[1]) << 16);
+    w.y = (uint32_t)f32_to_bf16_bits(r.v[2]) | ((uint32_t)f32_to_bf16_bits(r.v[3]) << 16);
+    *(uint2*)((u16*)p + i) = w;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ================================ RoPE2D (seam 1) ================================================
+// One thread per (token, rotation pair); loops over heads re-using cos/sin, like the reference
+// kernel (kernels.cu:17-82): inv_freq = fwd / powf(base, q/Q), angle = pos * inv_freq.
+template <typename T>
+__global__ void rope2d_kernel(T* tokens, const int64_t* pos, int B, int N, int H, int D, int64_t sb, int64_t sn,
+                              int64_t sh, float base, float fwd) {
+  const int Q = D / 4, half = D / 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * N * half;
+  if (idx >= total) return;
+  const int pr = (int)(idx % half);
+  const int64_t tok = idx / half;
+  const int n = (int)(tok % N), b = (int)(tok / N);
+  const int axis = pr / Q, q = pr - axis * Q;
+  const float inv_freq = fwd / powf(base, q / float(Q));
+  const float freq = pos[tok * 2 + axis] * inv_freq;
+  const float c = cosf(freq), s = sinf(freq);
+  T* tp = tokens + b * sb + n * sn + axis * 2 * Q + q;
+  for (int h = 0; h < H; ++h) {
+    T* p = tp + h * sh;
+    float u, v;
+    if (sizeof(T) == 4) {
+      u = ((float*)p)[0];
+      v = ((float*)p)[Q];
+      ((float*)p)[0] = u * c - v * s;
+      ((float*)p)[Q] = v * c + u * s;
+    } else {
+      u = bf16_bits_to_f32(((u16*)p)[0]);
+      v = bf16_bits_to_f32(((u16*)p)[Q]);
+      ((u16*)p)[0] = f32_to_bf16_bits(u * c - v * s);
+      ((u16*)p)[Q] = f32_to_bf16_bits(v * c + u * s);
+    }
+  }
+}
+
+// ================================ LayerNorm ======================================================
+// One wave per row; the row lives in registers (C <= 2048); two-pass mean / variance.
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, void* y, int y_dtype, const float* gamma,
+                                                        const float* beta, int64_t rows, int C, int64_t ldx,
+                                                        int64_t ldy, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  float4 v[8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < C) {
+      v[i] = *(const float4*)(xr + c);
+      sum += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < C) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      sq += a * a + b * b + cc * cc + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < C) {
+      const float4 g = *(const float4*)(gamma + c), bb = *(const float4*)(beta + c);
+      f32x4v o;
+      o.v[0] = (v[i].x - mean) * rstd * g.x + bb.x;
+      o.v[1] = (v[i].y - mean) * rstd * g.y + bb.y;
+      o.v[2] = (v[i].z - mean) * rstd * g.z + bb.z;
+      o.v[3] = (v[i].w - mean) * rstd * g.w + bb.w;
+      store4(y, y_dtype, row * ldy + c, o);
+    }
+  }
+}
+
+// ================================ add (row broadcast) ===========================================
+__global__ void add_kernel(const float* a, const float* b, float* y, int64_t rows, int64_t b_rows, int C4) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * C4) return;
+  const int64_t r = idx / C4;
+  const int c = (int)(idx - r * C4);
+  const float4 x = ((const float4*)a)[idx];
+  const float4 z = ((const float4*)b)[(r % b_rows) * C4 + c];
+  ((float4*)y)[idx] = make_float4(x.x + z.x, x.y + z.y, x.z + z.z, x.w + z.w);
+}
+
+// ================================ image pack NCHW(3) -> NHWC(8) =================================
+__global__ void pack_image_kernel(const float* img, void* out, int out_dtype, int N, int H, int W) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t hw = (int64_t)H * W;
+  if (idx >= (int64_t)N * hw) return;
+  const int64_t n = idx / hw, r = idx - n * hw;
+  f32x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v.v[j] = 0.f;
+  for (int c = 0; c < 3; ++c) v.v[c] = img[(n * 3 + c) * hw + r];
+  store8_from_f32(out, out_dtype, idx * 8, v);
+}
+
+// ================================ bilinear resize (NHWC) ========================================
+__device__ __forceinline__ void src_index(int o, int in, int out, int align, int& i0, int& i1, float& l1) {
+  float src;
+  if (align) {
+    const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    src = scale * o;
+  } else {
+    const float scale = (float)in / (float)out;
+    src = scale * (o + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+  }
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - i0;
+}
+
+__global__ void resize_kernel(const void* x, int x_dtype, void* y, int y_dtype, const void* addend, int add_dtype,
+                              const float* ch_scale, const float* ch_shift, int N, int IH, int IW, int OH, int OW,
+                              int C, int align) {
+  const int C4 = C >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)N * OH * OW * C4;
+  if (idx >= total) return;
+  const int c = (int)(idx % C4) * 4;
+  int64_t r = idx / C4;
+  const int ox = (int)(r % OW);
+  r /= OW;
+  const int oy = (int)(r % OH);
+  const int n = (int)(r / OH);
+  int y0, y1, x0, x1;
+  float ly, lx;
+  src_index(oy, IH, OH, align, y0, y1, ly);
+  src_index(ox, IW, OW, align, x0, x1, lx);
+  const int64_t base = (int64_t)n * IH * IW;
+  const f32x4v v00 = load4(x, x_dtype, (base + (int64_t)y0 * IW + x0) * C + c);
+  const f32x4v v01 = load4(x, x_dtype, (base + (int64_t)y0 * IW + x1) * C + c);
+  const f32x4v v10 = load4(x, x_dtype, (base + (int64_t)y1 * IW + x0) * C + c);
+  const f32x4v v11 = load4(x, x_dtype, (base + (int64_t)y1 * IW + x1) * C + c);
+  const int64_t oidx = (((int64_t)n * OH + oy) * OW + ox) * C + c;
+  f32x4v o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    o.v[j] = (1.f - ly) * ((1.f - lx) * v00.v[j] + lx * v01.v[j]) + ly * ((1.f - lx) * v10.v[j] + lx * v11.v[j]);
+  if (addend) {
+    const f32x4v a = load4(addend, add_dtype, oidx);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] += a.v[j];
+  }
+  if (ch_scale) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = o.v[j] * ch_scale[c + j] + ch_shift[c + j];
+  }
+  store4(y, y_dtype, oidx, o);
+}
+
+__global__ void affine_add_kernel(const void* x, int x_dtype, const void* addend, int add_dtype, void* y, int y_dtype,
+                                  const float* ch_scale, const float* ch_shift, int64_t rows, int C) {
+  const int C4 = C >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * C4) return;
+  const int c = (int)(idx % C4) * 4;
+  f32x4v o = load4(x, x_dtype, idx * 4);
+  if (addend) {
+    const f32x4v a = load4(addend, add_dtype, idx * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] += a.v[j];
+  }
+  if (ch_scale) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = o.v[j] * ch_scale[c + j] + ch_shift[c + j];
+  }
+  store4(y, y_dtype, idx * 4, o);
+}
+
+// ================================ max-pool 3x3 s2 p1 (NHWC) =====================================
+__global__ void maxpool_kernel(const void* x, void* y, int dtype, int N, int IH, int IW, int OH, int OW, int C) {
+  const int C4 = C >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * OH * OW * C4) return;
+  const int c = (int)(idx % C4) * 4;
+  int64_t r = idx / C4;
+  const int ox = (int)(r % OW);
+  r /= OW;
+  const int oy = (int)(r % OH);
+  const int n = (int)(r / OH);
+  f32x4v m;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) m.v[j] = -INFINITY;
+  for (int dy = 0; dy < 3; ++dy) {
+    const int iy = oy * 2 - 1 + dy;
+    if (iy < 0 || iy >= IH) continue;
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = ox * 2 - 1 + dx;
+      if (ix < 0 || ix >= IW) continue;
+      const f32x4v v = load4(x, dtype, (((int64_t)n * IH + iy) * IW + ix) * C + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m.v[j] = fmaxf(m.v[j], v.v[j]);
+    }
+  }
+  store4(y, dtype, idx * 4, m);
+}
+
+// ================================ depth-wise 3x3 + bias + GELU over 3 token scales =============
+// tokens [B, 21n, C]: [0,16n) is a (2H x 2W) map, [16n,20n) (H x W), [20n,21n) (H/2 x W/2)
+__global__ void dwconv_gelu_kernel(const void* x, void* y, int dtype, const float* w9c, const float* bias, int B,
+                                   int H, int W, int C) {
+  const int C4 = C >> 2;
+  const int n = (H * W) / 4;
+  const int ntok = 21 * n;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * ntok * C4) return;
+  const int c = (int)(idx % C4) * 4;
+  int64_t r = idx / C4;
+  const int tok = (int)(r % ntok);
+  const int b = (int)(r / ntok);
+  int start, hh, ww;
+  if (tok < 16 * n) {
+    start = 0; hh = 2 * H; ww = 2 * W;
+  } else if (tok < 20 * n) {
+    start = 16 * n; hh = H; ww = W;
+  } else {
+    start = 20 * n; hh = H / 2; ww = W / 2;
+  }
+  const int loc = tok - start;
+  const int py = loc / ww, px = loc - py * ww;
+  f32x4v acc;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc.v[j] = bias[c + j];
+  for (int dy = 0; dy < 3; ++dy) {
+    const int iy = py - 1 + dy;
+    if (iy < 0 || iy >= hh) continue;
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = px - 1 + dx;
+      if (ix < 0 || ix >= ww) continue;
+      const f32x4v v = load4(x, dtype, ((int64_t)b * ntok + start + iy * ww + ix) * C + c);
+      const float4 wv = *(const float4*)(w9c + (dy * 3 + dx) * C + c);
+      acc.v[0] += v.v[0] * wv.x;
+      acc.v[1] += v.v[1] * wv.y;
+      acc.v[2] += v.v[2] * wv.z;
+      acc.v[3] += v.v[3] * wv.w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc.v[j] = gelu_erf(acc.v[j]);
+  store4(y, dtype, idx * 4, acc);
+}
+
+// ================================ MS-deformable attention sampling ==============================
+struct MsdShapes {
+  int h[4], w[4], start[4];
+};
+__global__ void msdeform_kernel(const void* value, int v_dtype, const float* offs_aw, const float* ref, MsdShapes sh,
+                                void* out, int out_dtype, int B, int S, int Q, int heads, int d, int L, int P) {
+  const int D4 = d >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * Q * heads * D4) return;
+  const int dc = (int)(idx % D4) * 4;
+  int64_t r = idx / D4;
+  const int hd = (int)(r % heads);
+  r /= heads;
+  const int q = (int)(r % Q);
+  const int b = (int)(r / Q);
+  const int LP = L * P;
+  const float* row = offs_aw + ((int64_t)b * Q + q) * (heads * LP * 3);
+  const float* offs = row + hd * LP * 2;
+  const float* logit = row + heads * LP * 2 + hd * LP;
+  float mx = -INFINITY;
+  for (int i = 0; i < LP; ++i) mx = fmaxf(mx, logit[i]);
+  float den = 0.f;
+  for (int i = 0; i < LP; ++i) den += expf(logit[i] - mx);
+  f32x4v acc;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc.v[j] = 0.f;
+  for (int l = 0; l < L; ++l) {
+    const int hh = sh.h[l], ww = sh.w[l];
+    const float rx = ref[((int64_t)q * L + l) * 2 + 0], ry = ref[((int64_t)q * L + l) * 2 + 1];
+    for (int pt = 0; pt < P; ++pt) {
+      const int i = l * P + pt;
+      const float aw = expf(logit[i] - mx) / den;
+      const float locx = rx + offs[i * 2 + 0] / (float)ww;
+      const float locy = ry + offs[i * 2 + 1] / (float)hh;
+      // grid_sample(align_corners=False): pixel = ((2*loc-1 + 1) * size - 1) / 2
+      const float gx = 2.f * locx - 1.f, gy = 2.f * locy - 1.f;
+      const float fx = ((gx + 1.f) * ww - 1.f) * 0.5f, fy = ((gy + 1.f) * hh - 1.f) * 0.5f;
+      const float x0f = floorf(fx), y0f = floorf(fy);
+      const int x0 = (int)x0f, y0 = (int)y0f;
+      const float lx = fx - x0f, ly = fy - y0f;
+      const float wgt[4] = {(1.f - lx) * (1.f - ly), lx * (1.f - ly), (1.f - lx) * ly, lx * ly};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+        if (xx < 0 || xx >= ww || yy < 0 || yy >= hh) continue;
+        const int64_t s = sh.start[l] + (int64_t)yy * ww + xx;
+        const f32x4v v = load4(value, v_dtype, (((int64_t)b * S + s) * heads + hd) * d + dc);
+        const float wk = wgt[k] * aw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc.v[j] += v.v[j] * wk;
+      }
+    }
+  }
+  store4(out, out_dtype, (((int64_t)b * Q + q) * heads + hd) * d + dc, acc);
+}
+
+// ================================ GroupNorm (NHWC) ==============================================
+// stats: one block per (n, group); cg = C/groups channels (multiple of 4)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const void* x, int x_dtype, float* stats, int HW, int C,
+                                                       int groups, float eps) {
+  const int n = blockIdx.y, g = blockIdx.x;
+  const int cg = C / groups, cg4 = cg >> 2;
+  const int64_t total = (int64_t)HW * cg4;
+  double s = 0.0, ss = 0.0;
+  for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
+    const int64_t px = i / cg4;
+    const int c = g * cg + (int)(i - px * cg4) * 4;
+    const f32x4v v = load4(x, x_dtype, ((int64_t)n * HW + px) * C + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s += v.v[j];
+      ss += (double)v.v[j] * v.v[j];
+    }
+  }
+  __shared__ double sh_s[256], sh_ss[256];
+  sh_s[threadIdx.x] = s;
+  sh_ss[threadIdx.x] = ss;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sh_s[threadIdx.x] += sh_s[threadIdx.x + o];
+      sh_ss[threadIdx.x] += sh_ss[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double cnt = (double)HW * cg;
+    const double mean = sh_s[0] / cnt;
+    double var = sh_ss[0] / cnt - mean * mean;
+    if (var < 0) var = 0;
+    stats[((int64_t)n * groups + g) * 2 + 0] = (float)mean;
+    stats[((int64_t)n * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+__global__ void gn_apply_kernel(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma,
+                                const float* beta, const float* stats, const void* addend, int add_dtype, int relu,
+                                int N, int HW, int C, int groups) {
+  const int C4 = C >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * HW * C4) return;
+  const int c = (int)(idx % C4) * 4;
+  const int n = (int)(idx / ((int64_t)HW * C4));
+  const int g = c / (C / groups);
+  const float mean = stats[((int64_t)n * groups + g) * 2], rstd = stats[((int64_t)n * groups + g) * 2 + 1];
+  f32x4v v = load4(x, x_dtype, idx * 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float o = (v.v[j] - mean) * rstd * gamma[c + j] + beta[c + j];
+    if (relu) o = fmaxf(o, 0.f);
+    v.v[j] = o;
+  }
+  if (addend) {
+    const f32x4v a = load4(addend, add_dtype, idx * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v.v[j] += a.v[j];
+  }
+  store4(y, y_dtype, idx * 4, v);
+}
+
+// ================================ pts3d 'exp' post-process ======================================
+__global__ void pts3d_kernel(float* xyz, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = xyz[i * 3], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
+  const float d = sqrtf(x * x + y * y + z * z);
+  const float dc = fmaxf(d, 1e-8f);
+  const float e = expm1f(d);
+  xyz[i * 3] = x / dc * e;
+  xyz[i * 3 + 1] = y / dc * e;
+  xyz[i * 3 + 2] = z / dc * e;
+}
+
+// ================================ Gaussian adapter ==============================================
+// 128 Gaussians per block; raw rows (83 floats) are staged through LDS so that global traffic is
+// fully coalesced in both directions (row stride 83 words is odd -> conflict-free LDS access).
+constexpr int GA_ROWS = 128, GA_D = 83, GA_SH = 75;
+__constant__ float c_sh_mask[25];
+__global__ __launch_bounds__(128) void gaussian_adapter_kernel(const void* raw, int raw_dtype, float* opac,
+                                                               float* scales, float* rots, float* sh, float* cov,
+                                                               int64_t n) {
+  __shared__ float s[GA_ROWS * GA_D];
+  const int64_t g0 = (int64_t)blockIdx.x * GA_ROWS;
+  const int rows = (int)((n - g0) < GA_ROWS ? (n - g0) : GA_ROWS);
+  for (int i = threadIdx.x; i < rows * GA_D; i += GA_ROWS) s[i] = load_as_f32(raw, raw_dtype, g0 * GA_D + i);
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < rows) {
+    const float* r = s + t * GA_D;
+    const int64_t g = g0 + t;
+    opac[g] = 1.f / (1.f + expf(-r[0]));
+    float sc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float x = r[1 + j];
+      const float sp = x > 20.f ? x : log1pf(expf(x));
+      sc[j] = fminf(0.001f * sp, 0.3f);
+      scales[g * 3 + j] = sc[j];
+    }
+    const float qi = r[4], qj = r[5], qk = r[6], qr = r[7];
+    rots[g * 4 + 0] = qi; rots[g * 4 + 1] = qj; rots[g * 4 + 2] = qk; rots[g * 4 + 3] = qr;
+    const float nrm = sqrtf(qi * qi + qj * qj + qk * qk + qr * qr) + 1e-8f;
+    const float i_ = qi / nrm, j_ = qj / nrm, k_ = qk / nrm, r_ = qr / nrm;
+    const float two_s = 2.f / ((i_ * i_ + j_ * j_ + k_ * k_ + r_ * r_) + 1e-8f);
+    float R[9];
+    R[0] = 1.f - two_s * (j_ * j_ + k_ * k_);
+    R[1] = two_s * (i_ * j_ - k_ * r_);
+    R[2] = two_s * (i_ * k_ + j_ * r_);
+    R[3] = two_s * (i_ * j_ + k_ * r_);
+    R[4] = 1.f - two_s * (i_ * i_ + k_ * k_);
+    R[5] = two_s * (j_ * k_ - i_ * r_);
+    R[6] = two_s * (i_ * k_ - j_ * r_);
+    R[7] = two_s * (j_ * k_ + i_ * r_);
+    R[8] = 1.f - two_s * (i_ * i_ + j_ * j_);
+    // cov = (R S)(R S)^T, same association as R @ S @ S^T @ R^T up to fp32 rounding
+    float M[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) M[a * 3 + b] = R[a * 3 + b] * sc[b];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        float v = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 3; ++k2) v += (M[a * 3 + k2] * sc[k2]) * R[b * 3 + k2];
+        cov[g * 9 + a * 3 + b] = v;
+      }
+  }
+  __syncthreads();
+  // harmonics: [n, 3, 25] = raw[:, 8:83] * mask[d_sh]
+  for (int i = threadIdx.x; i < rows * GA_SH; i += GA_ROWS) {
+    const int rr = i / GA_SH, e = i - rr * GA_SH;
+    sh[g0 * GA_SH + i] = s[rr * GA_D + 8 + e] * c_sh_mask[e % 25];
+  }
+}
+
+// ================================ Mask2Former attention mask ====================================
+__global__ void m2f_mask_kernel(const float* ml, uint8_t* out, int32_t* row_counts, int B, int T, int IH, int IW,
+                                int OH, int OW, int Q) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * T * OH * OW * Q;
+  if (idx >= total) return;
+  const int q = (int)(idx % Q);
+  int64_t r = idx / Q;
+  const int ox = (int)(r % OW);
+  r /= OW;
+  const int oy = (int)(r % OH);
+  r /= OH;
+  const int t = (int)(r % T);
+  const int b = (int)(r / T);
+  int y0, y1, x0, x1;
+  float ly, lx;
+  src_index(oy, IH, OH, 0, y0, y1, ly);
+  src_index(ox, IW, OW, 0, x0, x1, lx);
+  const int64_t base = ((int64_t)b * T + t) * IH * IW;
+  const float v00 = ml[(base + (int64_t)y0 * IW + x0) * Q + q], v01 = ml[(base + (int64_t)y0 * IW + x1) * Q + q];
+  const float v10 = ml[(base + (int64_t)y1 * IW + x0) * Q + q], v11 = ml[(base + (int64_t)y1 * IW + x1) * Q + q];
+  const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+  const float sg = 1.f / (1.f + expf(-v));
+  const uint8_t blocked = sg < 0.5f ? 1 : 0;
+  const int64_t nk = (int64_t)T * OH * OW;
+  out[((int64_t)b * Q + q) * nk + ((int64_t)t * OH + oy) * OW + ox] = blocked;
+  if (blocked) atomicAdd(&row_counts[b * Q + q], 1);
+}
+__global__ void m2f_mask_fix_kernel(uint8_t* out, const int32_t* row_counts, int64_t rows, int64_t nk) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * nk) return;
+  const int64_t r = idx / nk;
+  if (row_counts[r] == nk) out[idx] = 0;
+}
+
+// ================================ fp32 -> bf16 hi (+lo) planes, K zero-padded ====================
+__global__ void split_bf16_kernel(const float* x, u16* hi, u16* lo, int64_t rows, int k, int kpad, int64_t ldx) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * kpad) return;
+  const int64_t r = idx / kpad;
+  const int c = (int)(idx - r * kpad);
+  const float v = c < k ? x[r * ldx + c] : 0.f;
+  const u16 h = f32_to_bf16_bits(v);
+  hi[idx] = h;
+  if (lo) lo[idx] = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
+}
+
+inline dim3 grid1d(int64_t total, int block = 256) { return dim3((unsigned)cdiv64(total, block)); }
+
+}  // namespace
+
+// ================================ C ABI ==========================================================
+extern "C" int siu3r_rope2d(void* tokens, int dtype, int B, int N, int H, int D, int64_t sb, int64_t sn, int64_t sh,
+                            const int64_t* positions, float base, float fwd, void* stream) {
+  SIU3R_CHECK(tokens && positions, "rope_2d: null pointer");
+  SIU3R_CHECK(D % 4 == 0, "token dim must be multiple of 4");  // kernels.cu:94
+  SIU3R_CHECK(dtype == SIU3R_F32 || dtype == SIU3R_BF16, "rope_2d: unsupported dtype %d", dtype);
+  SIU3R_CHECK(B >= 0 && N >= 0 && H >= 0, "rope_2d: negative size");
+  const int64_t total = (int64_t)B * N * (D / 2);
+  if (total == 0 || H == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == SIU3R_F32)
+    hipLaunchKernelGGL(rope2d_kernel<float>, grid1d(total), dim3(256), 0, s, (float*)tokens, positions, B, N, H, D, sb, sn, sh, base, fwd);
+  else
+    hipLaunchKernelGGL(rope2d_kernel<u16>, grid1d(total), dim3(256), 0, s, (u16*)tokens, positions, B, N, H, D, sb, sn, sh, base, fwd);
+  SIU3R_LAUNCH_CHECK("siu3r_rope2d");
+  return 0;
+}
+
+extern "C" int siu3r_layernorm(const float* x, void* y, int y_dtype, const float* gamma, const float* beta,
+                               int64_t rows, int C, int64_t ldx, int64_t ldy, float eps, void* stream) {
+  SIU3R_CHECK(x && y && gamma && beta, "layernorm: null pointer");
+  SIU3R_CHECK(C % 4 == 0 && C <= 2048 && ldx % 4 == 0 && ldy % 4 == 0, "layernorm: C=%d must be a multiple of 4 and <= 2048", C);
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, y_dtype, gamma, beta, rows, C, ldx, ldy, eps);
+  SIU3R_LAUNCH_CHECK("siu3r_layernorm");
+  return 0;
+}
+
+extern "C" int siu3r_add(const float* a, const float* b, float* y, int64_t rows, int64_t b_rows, int C, void* stream) {
+  SIU3R_CHECK(a && b && y && C % 4 == 0 && b_rows > 0, "add: bad arguments");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(add_kernel, grid1d(rows * (C / 4)), dim3(256), 0, (hipStream_t)stream, a, b, y, rows, b_rows, C / 4);
+  SIU3R_LAUNCH_CHECK("siu3r_add");
+  return 0;
+}
+
+extern "C" int siu3r_pack_image_nhwc8(const float* img, void* out, int out_dtype, int N, int H, int W, void* stream) {
+  SIU3R_CHECK(img && out, "pack_image: null pointer");
+  hipLaunchKernelGGL(pack_image_kernel, grid1d((int64_t)N * H * W), dim3(256), 0, (hipStream_t)stream, img, out, out_dtype, N, H, W);
+  SIU3R_LAUNCH_CHECK("siu3r_pack_image_nhwc8");
+  return 0;
+}
+
+extern "C" int siu3r_resize_bilinear(const void* x, int x_dtype, void* y, int y_dtype, const void* addend,
+                                     int add_dtype, const float* ch_scale, const float* ch_shift, int N, int IH,
+                                     int IW, int OH, int OW, int C, int align_corners, void* stream) {
+  SIU3R_CHECK(x && y && C % 4 == 0, "resize_bilinear: bad arguments (C=%d)", C);
+  SIU3R_CHECK((ch_scale == nullptr) == (ch_shift == nullptr), "resize_bilinear: scale/shift must come together");
+  hipLaunchKernelGGL(resize_kernel, grid1d((int64_t)N * OH * OW * (C / 4)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, addend, add_dtype, ch_scale, ch_shift, N, IH, IW, OH, OW, C, align_corners);
+  SIU3R_LAUNCH_CHECK("siu3r_resize_bilinear");
+  return 0;
+}
+
+extern "C" int siu3r_affine_add(const void* x, int x_dtype, const void* addend, int add_dtype, void* y, int y_dtype,
+                                const float* ch_scale, const float* ch_shift, int64_t rows, int C, void* stream) {
+  SIU3R_CHECK(x && y && C % 4 == 0, "affine_add: bad arguments");
+  hipLaunchKernelGGL(affine_add_kernel, grid1d(rows * (C / 4)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, addend, add_dtype, y, y_dtype, ch_scale, ch_shift, rows, C);
+  SIU3R_LAUNCH_CHECK("siu3r_affine_add");
+  return 0;
+}
+
+extern "C" int siu3r_maxpool3x3s2(const void* x, void* y, int dtype, int N, int IH, int IW, int C, void* stream) {
+  SIU3R_CHECK(x && y && C % 4 == 0, "maxpool: bad arguments");
+  const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_kernel, grid1d((int64_t)N * OH * OW * (C / 4)), dim3(256), 0, (hipStream_t)stream, x, y, dtype, N, IH, IW, OH, OW, C);
+  SIU3R_LAUNCH_CHECK("siu3r_maxpool3x3s2");
+  return 0;
+}
+
+extern "C" int siu3r_dwconv3x3_gelu(const void* x, void* y, int dtype, const float* w9c, const float* bias, int B,
+                                    int H, int W, int C, void* stream) {
+  SIU3R_CHECK(x && y && w9c && bias && C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "dwconv3x3_gelu: bad arguments");
+  const int64_t ntok = 21 * (int64_t)(H * W / 4);
+  hipLaunchKernelGGL(dwconv_gelu_kernel, grid1d((int64_t)B * ntok * (C / 4)), dim3(256), 0, (hipStream_t)stream, x, y, dtype, w9c, bias, B, H, W, C);
+  SIU3R_LAUNCH_CHECK("siu3r_dwconv3x3_gelu");
+  return 0;
+}
+
+extern "C" int siu3r_msdeform_sample(const void* value, int v_dtype, const float* offs_aw, const float* ref,
+                                     const int32_t* shapes_host, void* out, int out_dtype, int B, int S, int Q,
+                                     int heads, int d, int L, int P, void* stream) {
+  SIU3R_CHECK(value && offs_aw && ref && shapes_host && out, "msdeform_sample: null pointer");
+  SIU3R_CHECK(L >= 1 && L <= 4 && d % 4 == 0, "msdeform_sample: L=%d (1..4), d=%d (%%4)", L, d);
+  MsdShapes sh;
+  int start = 0;
+  for (int l = 0; l < L; ++l) {
+    sh.h[l] = shapes_host[2 * l];
+    sh.w[l] = shapes_host[2 * l + 1];
+    sh.start[l] = start;
+    start += sh.h[l] * sh.w[l];
+  }
+  SIU3R_CHECK(start == S, "msdeform_sample: spatial shapes sum %d != S=%d", start, S);
+  hipLaunchKernelGGL(msdeform_kernel, grid1d((int64_t)B * Q * heads * (d / 4)), dim3(256), 0, (hipStream_t)stream, value, v_dtype, offs_aw, ref, sh, out, out_dtype, B, S, Q, heads, d, L, P);
+  SIU3R_LAUNCH_CHECK("siu3r_msdeform_sample");
+  return 0;
+}
+
+extern "C" int siu3r_groupnorm(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma,
+                               const float* beta, float* stats_ws, const void* addend, int add_dtype, int relu, int N,
+                               int HW, int C, int groups, float eps, void* stream) {
+  SIU3R_CHECK(x && y && gamma && beta && stats_ws, "groupnorm: null pointer");
+  SIU3R_CHECK(C % groups == 0 && (C / groups) % 4 == 0, "groupnorm: C/groups must be a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(groups, N), dim3(256), 0, s, x, x_dtype, stats_ws, HW, C, groups, eps);
+  hipLaunchKernelGGL(gn_apply_kernel, grid1d((int64_t)N * HW * (C / 4)), dim3(256), 0, s, x, x_dtype, y, y_dtype, gamma, beta, stats_ws, addend, add_dtype, relu, N, HW, C, groups);
+  SIU3R_LAUNCH_CHECK("siu3r_groupnorm");
+  return 0;
+}
+
+extern "C" int siu3r_pts3d_exp(float* xyz, int64_t n, void* stream) {
+  SIU3R_CHECK(xyz, "pts3d_exp: null pointer");
+  hipLaunchKernelGGL(pts3d_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, xyz, n);
+  SIU3R_LAUNCH_CHECK("siu3r_pts3d_exp");
+  return 0;
+}
+
+extern "C" int siu3r_gaussian_adapter(const void* raw, int raw_dtype, float* opacities, float* scales,
+                                      float* rotations, float* harmonics, float* covariances, int64_t n,
+                                      void* stream) {
+  SIU3R_CHECK(raw && opacities && scales && rotations && harmonics && covariances, "gaussian_adapter: null pointer");
+  static bool mask_set = false;
+  if (!mask_set) {
+    float m[25];
+    m[0] = 1.f;
+    for (int deg = 1; deg <= 4; ++deg) {
+      float v = 0.1f;
+      for (int i = 0; i < deg; ++i) v *= 0.25f;  // 0.1 * 0.25**deg  (gaussian_adapter.py:70-71)
+      for (int i = deg * deg; i < (deg + 1) * (deg + 1); ++i) m[i] = v;
+    }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_sh_mask), m, sizeof(m)) != hipSuccess) {
+      siu3r_set_error("gaussian_adapter: cannot upload SH mask");
+      return 2;
+    }
+    mask_set = true;
+  }
+  hipLaunchKernelGGL(gaussian_adapter_kernel, dim3((unsigned)cdiv64(n, GA_ROWS)), dim3(GA_ROWS), 0, (hipStream_t)stream, raw, raw_dtype, opacities, scales, rotations, harmonics, covariances, n);
+  SIU3R_LAUNCH_CHECK("siu3r_gaussian_adapter");
+  return 0;
+}
+
+extern "C" int siu3r_m2f_attn_mask(const float* mask_logits, uint8_t* out, int32_t* row_counts_ws, int B, int T,
+                                   int IH, int IW, int OH, int OW, int Q, void* stream) {
+  SIU3R_CHECK(mask_logits && out && row_counts_ws, "m2f_attn_mask: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(row_counts_ws, 0, sizeof(int32_t) * B * Q, s) != hipSuccess) {
+    siu3r_set_error("m2f_attn_mask: memset failed");
+    return 2;
+  }
+  const int64_t nk = (int64_t)T * OH * OW;
+  hipLaunchKernelGGL(m2f_mask_kernel, grid1d((int64_t)B * nk * Q), dim3(256), 0, s, mask_logits, out, row_counts_ws, B, T, IH, IW, OH, OW, Q);
+  hipLaunchKernelGGL(m2f_mask_fix_kernel, grid1d((int64_t)B * Q * nk), dim3(256), 0, s, out, row_counts_ws, (int64_t)B * Q, nk);
+  SIU3R_LAUNCH_CHECK("siu3r_m2f_attn_mask");
+  return 0;
+}
+
+extern "C" int siu3r_split_bf16(const float* x, void* hi, void* lo, int64_t rows, int k, int kpad, int64_t ldx,
+                                void* stream) {
+  SIU3R_CHECK(x && hi && kpad >= k, "split_bf16: bad arguments");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(split_bf16_kernel, grid1d(rows * kpad), dim3(256), 0, (hipStream_t)stream, x, (u16*)hi, (u16*)lo, rows, k, kpad, ldx);
+  SIU3R_LAUNCH_CHECK("siu3r_split_bf16");
+  return 0;
+}

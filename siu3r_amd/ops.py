@@ -1,0 +1,427 @@
+"""Thin Python wrappers over the C ABI (include/siu3r_hip.h): torch tensors in, raw device
+pointers + the current HIP stream out.  PyTorch provides memory and streams only; every
+arithmetic operation below runs in libsiu3r_hip.so.  No CPU fallback: non-GPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, AttnParams, GemmParams, check
+
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise RuntimeError(f"unsupported dtype {t.dtype} (float32 or bfloat16 expected)")
+
+
+def torch_dtype(code: int):
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("siu3r_amd ops need GPU tensors: the HIP path has no CPU fallback")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+# weight packing
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class PackedWeight:
+    hi: torch.Tensor                 # bf16 [N, Kpad]
+    lo: Optional[torch.Tensor]       # bf16 [N, Kpad] (bf16x3 mode) or None
+    bias: Optional[torch.Tensor]     # fp32
+    n: int
+    k: int
+    kpad: int
+    meta: dict
+
+
+def split_bf16(x2d: torch.Tensor, want_lo: bool, kpad: Optional[int] = None):
+    """fp32 [rows, k] (last dim contiguous) -> bf16 hi [rows, kpad] (+ lo)."""
+    _gpu(x2d)
+    assert x2d.dtype == torch.float32 and x2d.dim() == 2 and x2d.stride(1) == 1
+    rows, k = x2d.shape
+    kpad = kpad or ((k + 63) // 64) * 64
+    hi = torch.empty((rows, kpad), dtype=torch.bfloat16, device=x2d.device)
+    lo = torch.empty_like(hi) if want_lo else None
+    check(_lib.lib().siu3r_split_bf16(_p(x2d), _p(hi), _p(lo), rows, k, kpad, x2d.stride(0), _stream()))
+    return hi, lo, kpad
+
+
+def pack_matrix(w2d: torch.Tensor, bias: Optional[torch.Tensor], split: bool, **meta) -> PackedWeight:
+    w2d = w2d.contiguous().float()
+    hi, lo, kpad = split_bf16(w2d, split)
+    b = None if bias is None else bias.detach().float().contiguous()
+    return PackedWeight(hi, lo, b, w2d.shape[0], w2d.shape[1], kpad, meta)
+
+
+def pack_linear(weight, bias, split):
+    return pack_matrix(weight, bias, split)
+
+
+def pack_conv(weight: torch.Tensor, bias, split, cin_pad: Optional[int] = None) -> PackedWeight:
+    """[Cout, Cin, KH, KW] -> [Cout, KH*KW*Cin'] in (ky, kx, c) order for the NHWC gather."""
+    co, ci, kh, kw = weight.shape
+    w = weight.permute(0, 2, 3, 1)
+    if cin_pad and cin_pad != ci:
+        w = torch.nn.functional.pad(w, (0, cin_pad - ci))  # layout plumbing (zero channels)
+        ci = cin_pad
+    return pack_matrix(w.reshape(co, kh * kw * ci), bias, split, kh=kh, kw=kw, cin=ci)
+
+
+def pack_conv_transpose(weight: torch.Tensor, bias, split) -> PackedWeight:
+    """ConvTranspose2d weight [Cin, Cout, k, k] with kernel == stride -> [(ky,kx,co), Cin]."""
+    ci, co, k, _ = weight.shape
+    w = weight.permute(2, 3, 1, 0).reshape(k * k * co, ci)
+    return pack_matrix(w, bias, split, up=k, cout=co)
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM family
+# ------------------------------------------------------------------------------------------------
+def _gemm_launch(p: GemmParams):
+    check(_lib.lib().siu3r_gemm(C.byref(p), _stream()))
+
+
+def _fill_common(p: GemmParams, a, pw: PackedWeight, out, act, residual, relu_in):
+    p.a, p.w_hi, p.w_lo, p.c = _p(a), _p(pw.hi), _p(pw.lo), _p(out)
+    p.bias = _p(pw.bias)
+    p.residual = _p(residual)
+    p.n, p.k, p.kpad = pw.n, pw.k, pw.kpad
+    p.a_dtype, p.c_dtype = _dt(a), _dt(out)
+    p.r_dtype = _dt(residual) if residual is not None else F32
+    p.act, p.relu_in = act, int(relu_in)
+    p.batch = 1
+    if pw.lo is not None and a.dtype != torch.float32:
+        raise RuntimeError("bf16x3 weights need fp32 activations")
+
+
+def linear(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=ACT_NONE,
+           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, relu_in=False):
+    """y[..., N] = act(x[..., K] @ W^T + b) (+ residual).  x may be a strided 2-D/3-D view whose last
+    dim is contiguous and whose leading dims collapse to one row stride (or [B, M, K] with a batch stride)."""
+    _gpu(x, residual, out)
+    K = x.shape[-1]
+    assert K == pw.k, (K, pw.k)
+    assert x.stride(-1) == 1
+    p = GemmParams()
+    if x.dim() == 3 and not (x.stride(0) == x.shape[1] * x.stride(1)):
+        B, M = x.shape[0], x.shape[1]
+        if out is None:
+            out = torch.empty((B, M, pw.n), dtype=out_dtype, device=x.device)
+        _fill_common(p, x, pw, out, act, residual, relu_in)
+        p.m, p.lda, p.ldc = M, x.stride(1), out.stride(1)
+        p.batch, p.sa, p.sw, p.sc = B, x.stride(0), 0, out.stride(0)
+        if residual is not None:
+            p.ldr, p.sr = residual.stride(1), residual.stride(0)
+    else:
+        lead = x.shape[:-1]
+        M = 1
+        for s in lead:
+            M *= s
+        lda = x.stride(-2) if x.dim() >= 2 else K
+        if out is None:
+            out = torch.empty((*lead, pw.n), dtype=out_dtype, device=x.device)
+        _fill_common(p, x, pw, out, act, residual, relu_in)
+        p.m, p.lda, p.ldc = M, lda, out.stride(-2) if out.dim() >= 2 else pw.n
+        if residual is not None:
+            p.ldr = residual.stride(-2) if residual.dim() >= 2 else pw.n
+    _gemm_launch(p)
+    return out
+
+
+def bmm_nt(a: torch.Tensor, b_hi: torch.Tensor, b_lo: Optional[torch.Tensor], n: int, k: int, *, out_dtype=torch.float32):
+    """out[z, M, n] = a[z, M, k] @ b[z, n, k]^T with pre-split bf16 b planes [Z, n, kpad]."""
+    _gpu(a, b_hi)
+    Z, M, K = a.shape
+    assert K == k and a.stride(2) == 1
+    out = torch.empty((Z, M, n), dtype=out_dtype, device=a.device)
+    p = GemmParams()
+    p.a, p.w_hi, p.w_lo, p.c = _p(a), _p(b_hi), _p(b_lo), _p(out)
+    p.m, p.n, p.k, p.kpad = M, n, k, b_hi.shape[-1]
+    p.lda, p.ldc = a.stride(1), n
+    p.a_dtype, p.c_dtype, p.r_dtype = _dt(a), _dt(out), F32
+    p.batch, p.sa, p.sw, p.sc = Z, a.stride(0), b_hi.stride(0), out.stride(0)
+    _gemm_launch(p)
+    return out
+
+
+def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride=1, pad=0, out_dtype=torch.float32, act=ACT_NONE,
+           residual=None, relu_in=False, up_src: Optional[torch.Tensor] = None):
+    """NHWC implicit-GEMM convolution: x [B, IH, IW, Cin] -> [B, OH, OW, Cout]."""
+    _gpu(x, residual, up_src)
+    assert x.is_contiguous()
+    B, IH, IW, Cin = x.shape
+    kh, kw = pw.meta["kh"], pw.meta["kw"]
+    assert Cin == pw.meta["cin"], (Cin, pw.meta)
+    OH = (IH + 2 * pad - kh) // stride + 1
+    OW = (IW + 2 * pad - kw) // stride + 1
+    out = torch.empty((B, OH, OW, pw.n), dtype=out_dtype, device=x.device)
+    p = GemmParams()
+    _fill_common(p, x, pw, out, act, residual, relu_in)
+    p.m, p.ldc, p.ldr = B * OH * OW, pw.n, pw.n
+    p.a_mode = 1
+    p.ih, p.iw, p.cin, p.kh, p.kw, p.stride, p.pad, p.oh, p.ow = IH, IW, Cin, kh, kw, stride, pad, OH, OW
+    if up_src is not None:
+        assert up_src.is_contiguous() and up_src.shape == (B, OH // 2, OW // 2, pw.n)
+        p.up_src, p.up_dtype = _p(up_src), _dt(up_src)
+    _gemm_launch(p)
+    return out
+
+
+def conv_transpose2d(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, residual=None):
+    """ConvTranspose2d with kernel == stride (pixel shuffle epilogue): [B,IH,IW,Cin] -> [B,IH*up,IW*up,Cout]."""
+    _gpu(x, residual)
+    assert x.is_contiguous()
+    B, IH, IW, Cin = x.shape
+    up, cout = pw.meta["up"], pw.meta["cout"]
+    out = torch.empty((B, IH * up, IW * up, cout), dtype=out_dtype, device=x.device)
+    p = GemmParams()
+    _fill_common(p, x, pw, out, ACT_NONE, residual, False)
+    p.m, p.lda = B * IH * IW, Cin
+    p.out_mode, p.up, p.cout, p.ih, p.iw = 1, up, cout, IH, IW
+    _gemm_launch(p)
+    return out
+
+
+def patch_embed(img: torch.Tensor, pw: PackedWeight, out: torch.Tensor):
+    """Conv2d(3->C, k16, s16) on an NCHW fp32 image, written token-major into out[b, :h*w, :]
+    (out is [B, Ntok(+extra), C] fp32; reference croco/patch_embed.py:19-29)."""
+    _gpu(img, out)
+    assert img.dtype == torch.float32 and img.is_contiguous()
+    B, _, H, W = img.shape
+    assert H % 16 == 0, f"Input image height ({H}) is not a multiple of patch size (16)."
+    assert W % 16 == 0, f"Input image width ({W}) is not a multiple of patch size (16)."
+    h, w = H // 16, W // 16
+    p = GemmParams()
+    _fill_common(p, img, pw, out, ACT_NONE, None, False)
+    p.a_mode, p.ih, p.iw, p.oh, p.ow = 2, H, W, h, w
+    if out.stride(0) == h * w * out.stride(1):
+        p.m, p.ldc = B * h * w, out.stride(1)
+    else:  # extra tokens per batch item: one launch per batch via blockIdx.z
+        p.m, p.ldc = h * w, out.stride(1)
+        p.batch, p.sa, p.sw, p.sc = B, 3 * H * W, 0, out.stride(0)
+    _gemm_launch(p)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# attention / norms / element-wise
+# ------------------------------------------------------------------------------------------------
+def attention(q, k, v, *, heads: int, head_dim: int, scale: float, rope=None, qpos=None, kpos=None,
+              mask: Optional[torch.Tensor] = None, split3=False):
+    """q [B,Nq,H,D] / k,v [B,Nk,H,D] strided views (D contiguous) -> out [B,Nq,H*D]."""
+    _gpu(q, k, v, mask)
+    B, Nq = q.shape[0], q.shape[1]
+    Nk = k.shape[1]
+    out = torch.empty((B, Nq, heads * head_dim), dtype=q.dtype, device=q.device)
+    p = AttnParams()
+    p.q, p.k, p.v, p.out = _p(q), _p(k), _p(v), _p(out)
+    p.dtype = _dt(q)
+    p.B, p.H, p.Nq, p.Nk, p.D = B, heads, Nq, Nk, head_dim
+    p.q_sb, p.q_sn, p.q_sh = q.stride(0), q.stride(1), q.stride(2)
+    p.k_sb, p.k_sn, p.k_sh = k.stride(0), k.stride(1), k.stride(2)
+    p.v_sb, p.v_sn, p.v_sh = v.stride(0), v.stride(1), v.stride(2)
+    p.scale = scale
+    if rope is not None:
+        cos, sin = rope
+        p.rope_cos, p.rope_sin, p.rope_max_pos = _p(cos), _p(sin), cos.shape[0]
+        assert qpos.dtype == torch.int64 and kpos.dtype == torch.int64 and qpos.is_contiguous() and kpos.is_contiguous()
+        p.qpos, p.kpos = _p(qpos), _p(kpos)
+    if mask is not None:
+        assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.shape == (B, Nq, Nk)
+        p.mask = _p(mask)
+    p.split3 = int(split3)
+    check(_lib.lib().siu3r_attention(C.byref(p), _stream()))
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma, beta, eps: float, out_dtype=torch.float32):
+    _gpu(x)
+    assert x.dtype == torch.float32 and x.stride(-1) == 1
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    x2 = x.reshape(rows, Cc) if x.is_contiguous() else x
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    if x.is_contiguous():
+        ldx = Cc
+    else:  # [B, N, C] view with a batch stride: handle per batch
+        assert x.dim() == 3
+        for b in range(x.shape[0]):
+            check(_lib.lib().siu3r_layernorm(_p(x[b]), _p(out[b]), _dt(out), _p(gamma), _p(beta), x.shape[1], Cc,
+                                             x.stride(1), Cc, eps, _stream()))
+        return out
+    check(_lib.lib().siu3r_layernorm(_p(x2), _p(out), _dt(out), _p(gamma), _p(beta), rows, Cc, ldx, Cc, eps, _stream()))
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor):
+    """fp32 a[rows, C] + b[b_rows, C] broadcast over rows (row r uses b[r % b_rows])."""
+    _gpu(a, b)
+    assert a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float32 and b.dtype == torch.float32
+    Cc = a.shape[-1]
+    y = torch.empty_like(a)
+    check(_lib.lib().siu3r_add(_p(a), _p(b), _p(y), a.numel() // Cc, b.numel() // Cc, Cc, _stream()))
+    return y
+
+
+def pack_image_nhwc8(img: torch.Tensor, out_dtype):
+    _gpu(img)
+    assert img.dtype == torch.float32 and img.is_contiguous() and img.shape[1] == 3
+    N, _, H, W = img.shape
+    out = torch.empty((N, H, W, 8), dtype=out_dtype, device=img.device)
+    check(_lib.lib().siu3r_pack_image_nhwc8(_p(img), _p(out), _dt(out), N, H, W, _stream()))
+    return out
+
+
+def resize_bilinear(x: torch.Tensor, size, align_corners: bool, *, addend=None, ch_scale=None, ch_shift=None,
+                    out_dtype=None):
+    _gpu(x, addend)
+    assert x.is_contiguous()
+    N, IH, IW, Cc = x.shape
+    OH, OW = size
+    out = torch.empty((N, OH, OW, Cc), dtype=out_dtype or x.dtype, device=x.device)
+    if addend is not None:
+        assert addend.is_contiguous() and addend.shape == out.shape
+    check(_lib.lib().siu3r_resize_bilinear(_p(x), _dt(x), _p(out), _dt(out), _p(addend),
+                                           _dt(addend) if addend is not None else F32, _p(ch_scale), _p(ch_shift),
+                                           N, IH, IW, OH, OW, Cc, int(align_corners), _stream()))
+    return out
+
+
+def affine_add(x: torch.Tensor, addend, ch_scale, ch_shift, out_dtype=None):
+    _gpu(x, addend)
+    assert x.is_contiguous() and (addend is None or (addend.is_contiguous() and addend.numel() == x.numel()))
+    Cc = x.shape[-1]
+    out = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    check(_lib.lib().siu3r_affine_add(_p(x), _dt(x), _p(addend), _dt(addend) if addend is not None else F32, _p(out),
+                                      _dt(out), _p(ch_scale), _p(ch_shift), x.numel() // Cc, Cc, _stream()))
+    return out
+
+
+def maxpool3x3s2(x: torch.Tensor):
+    _gpu(x)
+    assert x.is_contiguous()
+    N, IH, IW, Cc = x.shape
+    out = torch.empty((N, (IH - 1) // 2 + 1, (IW - 1) // 2 + 1, Cc), dtype=x.dtype, device=x.device)
+    check(_lib.lib().siu3r_maxpool3x3s2(_p(x), _p(out), _dt(x), N, IH, IW, Cc, _stream()))
+    return out
+
+
+def dwconv3x3_gelu(x: torch.Tensor, w9c: torch.Tensor, bias: torch.Tensor, H: int, W: int):
+    _gpu(x)
+    assert x.is_contiguous()
+    B, N, Cc = x.shape
+    assert N == 21 * (H * W // 4)
+    out = torch.empty_like(x)
+    check(_lib.lib().siu3r_dwconv3x3_gelu(_p(x), _p(out), _dt(x), _p(w9c), _p(bias), B, H, W, Cc, _stream()))
+    return out
+
+
+def msdeform_sample(value: torch.Tensor, offs_aw: torch.Tensor, ref: torch.Tensor, shapes: Sequence[Sequence[int]],
+                    heads: int, points: int, out_dtype):
+    """value [B,S,heads*d]; offs_aw fp32 [B,Q,heads*L*P*3]; ref fp32 [Q,L,2] -> [B,Q,heads*d]."""
+    _gpu(value, offs_aw, ref)
+    assert value.is_contiguous() and offs_aw.is_contiguous() and ref.is_contiguous() and offs_aw.dtype == torch.float32
+    B, S, Cc = value.shape
+    Q = offs_aw.shape[1]
+    L = len(shapes)
+    d = Cc // heads
+    assert offs_aw.shape[2] == heads * L * points * 3 and ref.shape == (Q, L, 2)
+    out = torch.empty((B, Q, Cc), dtype=out_dtype, device=value.device)
+    arr = (C.c_int32 * (2 * L))(*[int(v) for s in shapes for v in s])
+    check(_lib.lib().siu3r_msdeform_sample(_p(value), _dt(value), _p(offs_aw), _p(ref), arr, _p(out), _dt(out), B, S, Q,
+                                           heads, d, L, points, _stream()))
+    return out
+
+
+def groupnorm(x: torch.Tensor, gamma, beta, groups=32, eps=1e-5, *, relu=False, addend=None, out_dtype=None):
+    _gpu(x, addend)
+    assert x.is_contiguous()
+    N, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * Cc)
+    out = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    ws = torch.empty((N, groups, 2), dtype=torch.float32, device=x.device)
+    check(_lib.lib().siu3r_groupnorm(_p(x), _dt(x), _p(out), _dt(out), _p(gamma), _p(beta), _p(ws), _p(addend),
+                                     _dt(addend) if addend is not None else F32, int(relu), N, HW, Cc, groups, eps,
+                                     _stream()))
+    return out
+
+
+def pts3d_exp_(xyz: torch.Tensor):
+    _gpu(xyz)
+    assert xyz.dtype == torch.float32 and xyz.is_contiguous() and xyz.shape[-1] == 3
+    check(_lib.lib().siu3r_pts3d_exp(_p(xyz), xyz.numel() // 3, _stream()))
+    return xyz
+
+
+def gaussian_adapter(raw: torch.Tensor):
+    """raw [..., 83] -> dict of fp32 tensors (reference gaussian_adapter.py:81-110)."""
+    _gpu(raw)
+    assert raw.is_contiguous() and raw.shape[-1] == 83
+    lead = raw.shape[:-1]
+    n = raw.numel() // 83
+    dev = raw.device
+    f = lambda *s: torch.empty((*lead, *s), dtype=torch.float32, device=dev)
+    op, sc, rot, sh, cov = f(), f(3), f(4), f(3, 25), f(3, 3)
+    check(_lib.lib().siu3r_gaussian_adapter(_p(raw), _dt(raw), _p(op), _p(sc), _p(rot), _p(sh), _p(cov), n, _stream()))
+    return dict(opacities=op, scales=sc, rotations=rot, harmonics=sh, covariances=cov)
+
+
+def m2f_attn_mask(mask_logits: torch.Tensor, size):
+    """mask logits [B,T,IH,IW,Q] fp32 -> uint8 [B,Q,T*OH*OW] (1 = blocked, fully blocked rows cleared)."""
+    _gpu(mask_logits)
+    assert mask_logits.is_contiguous() and mask_logits.dtype == torch.float32
+    B, T, IH, IW, Q = mask_logits.shape
+    OH, OW = size
+    out = torch.empty((B, Q, T * OH * OW), dtype=torch.uint8, device=mask_logits.device)
+    ws = torch.empty((B * Q,), dtype=torch.int32, device=mask_logits.device)
+    check(_lib.lib().siu3r_m2f_attn_mask(_p(mask_logits), _p(out), _p(ws), B, T, IH, IW, OH, OW, Q, _stream()))
+    return out
+
+
+def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: float):
+    """Drop-in for the reference's pybind `curope.rope_2d` (curope.cpp:49-65): tokens [B,N,H,D] in place."""
+    if tokens.dim() != 4:
+        raise RuntimeError("tokens must have 4 dimensions")
+    if positions.dim() != 3:
+        raise RuntimeError("positions must have 3 dimensions")
+    if tokens.size(0) != positions.size(0):
+        raise RuntimeError("batch size differs between tokens & positions")
+    if tokens.size(1) != positions.size(1):
+        raise RuntimeError("seq_length differs between tokens & positions")
+    if positions.size(2) != 2:
+        raise RuntimeError("positions.shape[2] must be equal to 2")
+    if tokens.is_cuda != positions.is_cuda:
+        raise RuntimeError("tokens and positions are not on the same device")
+    _gpu(tokens)
+    B, N, H, D = tokens.shape
+    if not (tokens.stride(3) == 1 and tokens.stride(2) == D):
+        raise RuntimeError("tokens are not contiguous")  # kernels.cu:91
+    if not positions.is_contiguous():
+        raise RuntimeError("positions are not contiguous")
+    if positions.dtype != torch.int64:
+        raise RuntimeError("positions must be int64")
+    check(_lib.lib().siu3r_rope2d(_p(tokens), _dt(tokens), B, N, H, D, tokens.stride(0), tokens.stride(1),
+                                  tokens.stride(2), _p(positions), float(base), float(fwd), _stream()))
+    return None

@@ -1,0 +1,375 @@
+"""Per-kernel parity tests: HIP path (through the C ABI in libsiu3r_hip.so) vs the CPU oracle /
+plain fp32 torch on the same seeded inputs.  Tolerances (max |err| / max |ref|):
+  bf16 operand mode ......... 2e-2  (bf16 has 8 mantissa bits; documented deviation from 1e-3)
+  bf16x3 / fp32 kernels ...... 2e-4  (well inside the north-star's 1e-3)
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL_BF16 = 2e-2
+TOL_F32 = 2e-4
+
+
+def _ops():
+    from siu3r_amd import ops
+
+    return ops
+
+
+def rel_err(got, ref):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return ((got - ref).abs().max() / (ref.abs().max() + 1e-30)).item()
+
+
+def check(name, got, ref, tol):
+    e = rel_err(got, ref)
+    print(f"[parity] {name}: rel_err={e:.3e} tol={tol:.1e}")
+    assert math.isfinite(e) and e <= tol, f"{name}: rel_err {e:.3e} > {tol:.1e}"
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+MODES = [("bf16", torch.bfloat16, False, TOL_BF16), ("f32", torch.float32, False, TOL_BF16),
+         ("bf16x3", torch.float32, True, TOL_F32)]
+
+
+@pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
+def test_gemm_dense(mode):
+    ops = _ops()
+    name, adt, split, tol = mode
+    M, N, K = 300, 200, 264  # ragged in every dimension; K % 8 == 0 but not % 64
+    a, w, b, r = gen(M, K, seed=1), gen(N, K, seed=2, scale=0.2), gen(N, seed=3), gen(M, N, seed=4)
+    pw = ops.pack_linear(w.cuda(), b.cuda(), split)
+    ref = F.gelu(a.to(adt).float() @ w.t() + b) + r
+    out = ops.linear(a.cuda().to(adt), pw, out_dtype=torch.float32, act=ops.ACT_GELU, residual=r.cuda())
+    check(f"gemm_dense[{name}] gelu+residual f32 out", out, ref, tol)
+    out2 = ops.linear(a.cuda().to(adt), pw, out_dtype=adt, act=ops.ACT_RELU)
+    check(f"gemm_dense[{name}] relu act-dtype out", out2, F.relu(a.to(adt).float() @ w.t() + b), max(tol, 5e-3 if adt == torch.bfloat16 else 0))
+    # asymmetric A = I check (transpose detecting): out == W^T rows
+    eye = torch.eye(K)[:64]
+    out3 = ops.linear(eye.cuda().to(adt), ops.pack_linear(w.cuda(), None, split), out_dtype=torch.float32)
+    check(f"gemm_dense[{name}] A=I", out3, w.t()[:64], tol)
+
+
+@pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
+def test_gemm_batched_strided(mode):
+    """tokens[:, :-1] view (strip the intrinsics token) feeding a 1x1 conv / linear."""
+    ops = _ops()
+    name, adt, split, tol = mode
+    B, Nt, K, N = 2, 131, 128, 96
+    x = gen(B, Nt, K, seed=5)
+    w, b = gen(N, K, seed=6, scale=0.3), gen(N, seed=7)
+    pw = ops.pack_linear(w.cuda(), b.cuda(), split)
+    xg = x.cuda().to(adt)
+    out = ops.linear(xg[:, :-1], pw, out_dtype=torch.float32)
+    check(f"gemm_batched[{name}]", out, x[:, :-1].to(adt).float() @ w.t() + b, tol)
+
+
+@pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
+@pytest.mark.parametrize("cfg", [(3, 1, 1, 16, 24), (3, 2, 1, 24, 40), (1, 1, 0, 64, 16), (7, 1, 3, 3, 32)], ids=["k3s1", "k3s2", "k1", "k7c3"])
+def test_conv2d(mode, cfg):
+    ops = _ops()
+    name, adt, split, tol = mode
+    k, s, pd, cin, cout = cfg
+    B, H, W = 2, 20, 28
+    x = gen(B, cin, H, W, seed=8)
+    w, b = gen(cout, cin, k, k, seed=9, scale=0.3), gen(cout, seed=10)
+    cin_pad = 8 if cin == 3 else None
+    pw = ops.pack_conv(w.cuda(), b.cuda(), split, cin_pad=cin_pad)
+    if cin == 3:
+        xg = ops.pack_image_nhwc8(x.cuda(), adt)
+    else:
+        xg = x.permute(0, 2, 3, 1).contiguous().cuda().to(adt)
+    ref = F.conv2d(F.relu(x.to(adt).float()), w, b, stride=s, padding=pd).permute(0, 2, 3, 1)
+    out = ops.conv2d(xg, pw, stride=s, pad=pd, out_dtype=torch.float32, relu_in=True)
+    check(f"conv2d[{name}] k{k}s{s} relu_in", out, ref, tol)
+
+
+@pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
+def test_conv2d_upsample_add_epilogue(mode):
+    """GS head: feat_up(path_1) + ReLU(conv7x7(img)) fused (dpt_gs_head.py:160-162)."""
+    ops = _ops()
+    name, adt, split, tol = mode
+    B, H, W, C = 1, 16, 24, 32
+    img = gen(B, 3, H, W, seed=11).abs()
+    low = gen(B, C, H // 2, W // 2, seed=12)
+    w, b = gen(C, 3, 7, 7, seed=13, scale=0.2), gen(C, seed=14)
+    pw = ops.pack_conv(w.cuda(), b.cuda(), split, cin_pad=8)
+    ref = (F.relu(F.conv2d(img.to(adt).float(), w, b, padding=3)) + F.interpolate(low.to(adt).float(), scale_factor=2, mode="bilinear", align_corners=True)).permute(0, 2, 3, 1)
+    out = ops.conv2d(ops.pack_image_nhwc8(img.cuda(), adt), pw, stride=1, pad=3, act=ops.ACT_RELU, out_dtype=torch.float32,
+                     up_src=low.permute(0, 2, 3, 1).contiguous().cuda().to(adt))
+    check(f"conv7x7+up_add[{name}]", out, ref, tol)
+
+
+@pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
+@pytest.mark.parametrize("k", [2, 4])
+def test_conv_transpose(mode, k):
+    ops = _ops()
+    name, adt, split, tol = mode
+    B, H, W, cin, cout = 2, 6, 5, 48, 24
+    x = gen(B, cin, H, W, seed=15)
+    w, b = gen(cin, cout, k, k, seed=16, scale=0.3), gen(cout, seed=17)
+    pw = ops.pack_conv_transpose(w.cuda(), b.cuda(), split)
+    ref = F.conv_transpose2d(x.to(adt).float(), w, b, stride=k).permute(0, 2, 3, 1)
+    out = ops.conv_transpose2d(x.permute(0, 2, 3, 1).contiguous().cuda().to(adt), pw, out_dtype=torch.float32)
+    check(f"conv_transpose[{name}] k{k}", out, ref, tol)
+
+
+@pytest.mark.parametrize("split", [False, True], ids=["bf16", "bf16x3"])
+def test_patch_embed(split):
+    ops = _ops()
+    B, H, W, Cc = 2, 64, 96, 80
+    img = gen(B, 3, H, W, seed=18).abs()
+    w, b = gen(Cc, 3, 16, 16, seed=19, scale=0.1), gen(Cc, seed=20)
+    pw = ops.pack_matrix(w.reshape(Cc, -1).cuda(), b.cuda(), split)
+    n = (H // 16) * (W // 16)
+    out = torch.zeros(B, n + 1, Cc, device="cuda")
+    ops.patch_embed(img.cuda(), pw, out)
+    ref = F.conv2d(img, w, b, stride=16).flatten(2).transpose(1, 2)
+    check(f"patch_embed[{'bf16x3' if split else 'bf16'}]", out[:, :n], ref, TOL_F32 if split else TOL_BF16)
+    assert float(out[:, n].abs().max()) == 0.0  # extra token untouched
+
+
+@pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
+def test_layernorm(odt):
+    ops = _ops()
+    x = gen(37, 1024, seed=21, scale=3.0) + 0.5
+    g, b = gen(1024, seed=22) + 1.0, gen(1024, seed=23)
+    out = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-6, out_dtype=odt)
+    check(f"layernorm[{odt}]", out, F.layer_norm(x, (1024,), g, b, 1e-6), 1e-5 if odt == torch.float32 else 8e-3)
+    x3 = gen(2, 9, 768, seed=24)
+    out3 = ops.layernorm(x3.cuda()[:, :-1], g[:768].cuda().contiguous(), b[:768].cuda().contiguous(), 1e-5, out_dtype=odt)
+    check("layernorm strided", out3, F.layer_norm(x3[:, :-1], (768,), g[:768], b[:768], 1e-5), 1e-5 if odt == torch.float32 else 8e-3)
+
+
+def test_rope2d_seam():
+    """seam 1: curope.rope_2d(tokens, positions, base, fwd) in place on a [B,H,N,D]->transpose(1,2) view."""
+    from oracle import siu3r_oracle as O
+
+    ops = _ops()
+    B, H, N, D = 2, 4, 33, 64
+    tok = gen(B, H, N, D, seed=25)
+    pos = torch.stack([torch.randint(0, 33, (B, N), generator=torch.Generator().manual_seed(1)),
+                       torch.randint(0, 33, (B, N), generator=torch.Generator().manual_seed(2))], -1)
+    ref = O.rope2d(tok, pos, 100.0, 1.0)
+    t = tok.cuda()  # [B,H,N,D]
+    view = t.transpose(1, 2)  # [B,N,H,D] view accepted by the reference (kernels.cu:91) only if stride(2)==D
+    cont = view.contiguous()
+    assert ops.rope_2d(cont, pos.cuda(), 100.0, 1.0) is None
+    check("rope2d fwd", cont.transpose(1, 2), ref, 2e-6)
+    ops.rope_2d(cont, pos.cuda(), 100.0, -1.0)  # backward = inverse rotation
+    check("rope2d fwd+bwd = identity", cont.transpose(1, 2), tok, 2e-6)
+    # qkv-packed view [B,N,3,H,D][:, :, 0] has stride(2)==D and is accepted in place
+    qkv = gen(B, N, 3, H, D, seed=26).cuda()
+    ref_q = O.rope2d(qkv[:, :, 0].permute(0, 2, 1, 3).cpu(), pos)
+    ops.rope_2d(qkv[:, :, 0], pos.cuda(), 100.0, 1.0)
+    check("rope2d strided view", qkv[:, :, 0].permute(0, 2, 1, 3), ref_q, 2e-6)
+    bf = tok.transpose(1, 2).contiguous().cuda().bfloat16()
+    ops.rope_2d(bf, pos.cuda(), 100.0, 1.0)
+    check("rope2d bf16", bf.transpose(1, 2), O.rope2d(tok.bfloat16().float(), pos), 8e-3)
+    # error behaviour mirrors TORCH_CHECK -> RuntimeError (curope.cpp:54-59, kernels.cu:91-94)
+    with pytest.raises(RuntimeError):
+        ops.rope_2d(t[0], pos.cuda(), 100.0, 1.0)
+    with pytest.raises(RuntimeError):
+        ops.rope_2d(view, pos.cuda(), 100.0, 1.0)  # non-contiguous head stride
+    with pytest.raises(RuntimeError):
+        ops.rope_2d(cont, pos.cuda()[:, :5], 100.0, 1.0)
+    with pytest.raises(RuntimeError):
+        ops.rope_2d(gen(1, 2, 2, 6).cuda(), torch.zeros(1, 2, 2, dtype=torch.int64).cuda(), 100.0, 1.0)
+    e = torch.zeros(0, 4, 2, 64, device="cuda")
+    ops.rope_2d(e, torch.zeros(0, 4, 2, dtype=torch.int64, device="cuda"), 100.0, 1.0)  # empty is a no-op
+
+
+def _attn_ref(q, k, v, scale, qpos=None, kpos=None, mask=None):
+    from oracle import siu3r_oracle as O
+
+    q, k, v = (t.permute(0, 2, 1, 3) for t in (q, k, v))  # [B,H,N,D]
+    if qpos is not None:
+        q, k = O.rope2d(q, qpos), O.rope2d(k, kpos)
+    a = (q @ k.transpose(-1, -2)) * scale
+    if mask is not None:
+        a = a.masked_fill(mask[:, None].bool(), float("-inf"))
+    o = a.softmax(-1) @ v
+    return o.permute(0, 2, 1, 3).flatten(2)
+
+
+@pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
+@pytest.mark.parametrize("shape", [(2, 3, 257, 257), (1, 2, 130, 321), (1, 4, 64, 1025)], ids=["self257", "cross", "long"])
+def test_attention_rope_d64(mode, shape):
+    from oracle import siu3r_oracle as O
+
+    ops = _ops()
+    name, adt, split, tol = mode
+    B, H, Nq, Nk = shape
+    D = 64
+    qkv = gen(B, Nq, 3, H, D, seed=27)
+    if Nq == Nk:
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    else:
+        q, k, v = qkv[:, :, 0], gen(B, Nk, H, D, seed=28), gen(B, Nk, H, D, seed=29)
+    g = torch.Generator().manual_seed(3)
+    qpos = torch.randint(0, 34, (B, Nq, 2), generator=g)
+    kpos = qpos if Nq == Nk else torch.randint(0, 34, (B, Nk, 2), generator=g)
+    cos, sin = O.rope2d_table(34, D)
+    ref = _attn_ref(q.to(adt).float(), k.to(adt).float(), v.to(adt).float(), D ** -0.5, qpos, kpos)
+    dev = lambda t: t.cuda().to(adt)
+    if Nq == Nk:
+        packed = dev(qkv)
+        qg, kg, vg = packed[:, :, 0], packed[:, :, 1], packed[:, :, 2]
+    else:
+        qg, kg, vg = dev(q.contiguous()), dev(k), dev(v)
+    out = ops.attention(qg, kg, vg, heads=H, head_dim=D, scale=D ** -0.5, rope=(cos.cuda(), sin.cuda()),
+                        qpos=qpos.cuda(), kpos=kpos.cuda(), split3=split)
+    check(f"attention_rope_d64[{name}] {shape}", out, ref, tol)
+
+
+@pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
+def test_attention_masked_d32(mode):
+    ops = _ops()
+    name, adt, split, tol = mode
+    B, H, Nq, Nk, D = 2, 8, 100, 520, 32
+    q, k, v = gen(B, Nq, H, D, seed=30), gen(B, Nk, H, D, seed=31), gen(B, Nk, H, D, seed=32)
+    mask = (torch.rand(B, Nq, Nk, generator=torch.Generator().manual_seed(4)) < 0.7)
+    mask[:, :, 0] = False  # every row keeps at least one key (the reference re-opens fully blocked rows)
+    mask[0, 5, :] = True
+    mask[0, 5, 300] = False  # single surviving key far from the first tile
+    ref = _attn_ref(q.to(adt).float(), k.to(adt).float(), v.to(adt).float(), D ** -0.5, mask=mask)
+    dev = lambda t: t.cuda().to(adt)
+    out = ops.attention(dev(q), dev(k), dev(v), heads=H, head_dim=D, scale=D ** -0.5, mask=mask.to(torch.uint8).cuda(), split3=split)
+    check(f"attention_masked_d32[{name}]", out, ref, tol)
+    out2 = ops.attention(dev(q), dev(q), dev(q), heads=H, head_dim=D, scale=D ** -0.5, split3=split)
+    check(f"attention_self_d32[{name}]", out2, _attn_ref(*(q.to(adt).float(),) * 3, D ** -0.5), tol)
+
+
+@pytest.mark.parametrize("adt", [torch.float32, torch.bfloat16])
+def test_resize_and_pointwise(adt):
+    ops = _ops()
+    tol = 1e-5 if adt == torch.float32 else 8e-3
+    x = gen(2, 32, 9, 13, seed=33)
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda().to(adt)
+    xr = x.to(adt).float()
+    for (size, ac) in [((18, 26), True), ((18, 26), False), ((36, 52), False), ((5, 7), False), ((4, 6), False)]:
+        out = ops.resize_bilinear(xg, size, ac, out_dtype=torch.float32)
+        ref = F.interpolate(xr, size=size, mode="bilinear", align_corners=ac).permute(0, 2, 3, 1)
+        check(f"resize {size} align={ac} [{adt}]", out, ref, tol)
+    x2 = gen(2, 32, 8, 12, seed=34)
+    half = F.interpolate(x2, scale_factor=0.5, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    out = ops.resize_bilinear(x2.permute(0, 2, 3, 1).contiguous().cuda(), (4, 6), False)
+    check("resize scale 0.5", out, half, 1e-5)
+    add = gen(2, 18, 26, 32, seed=35)
+    sc, sh = gen(32, seed=36) + 1.5, gen(32, seed=37)
+    out = ops.resize_bilinear(xg, (18, 26), False, addend=add.cuda(), ch_scale=sc.cuda(), ch_shift=sh.cuda(), out_dtype=torch.float32)
+    ref = (F.interpolate(xr, size=(18, 26), mode="bilinear", align_corners=False).permute(0, 2, 3, 1) + add) * sc + sh
+    check(f"resize+add+affine [{adt}]", out, ref, tol)
+    out = ops.affine_add(xg, xg, sc.cuda(), sh.cuda(), out_dtype=torch.float32)
+    check(f"affine_add [{adt}]", out, (2 * xr.permute(0, 2, 3, 1)) * sc + sh, tol)
+    out = ops.maxpool3x3s2(xg)
+    check(f"maxpool [{adt}]", out, F.max_pool2d(xr, 3, 2, 1).permute(0, 2, 3, 1), tol)
+    a, b = gen(6, 5, 64, seed=38), gen(5, 64, seed=39)
+    check("add broadcast", ops.add(a.cuda(), b.cuda()), a + b, 1e-6)
+    gamma, beta = gen(32, seed=40) + 1.0, gen(32, seed=41)
+    gn_in = gen(2, 64, 9, 13, seed=42) * 2 + 0.3
+    out = ops.groupnorm(gn_in.permute(0, 2, 3, 1).contiguous().cuda().to(adt), F.pad(gamma, (0, 32), value=1.0).cuda(),
+                        F.pad(beta, (0, 32)).cuda(), groups=8, relu=True, out_dtype=torch.float32)
+    ref = F.relu(F.group_norm(gn_in.to(adt).float(), 8, F.pad(gamma, (0, 32), value=1.0), F.pad(beta, (0, 32)), 1e-5)).permute(0, 2, 3, 1)
+    check(f"groupnorm+relu [{adt}]", out, ref, 2e-5 if adt == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("adt", [torch.float32, torch.bfloat16])
+def test_dwconv_gelu(adt):
+    ops = _ops()
+    B, H, W, Cc = 2, 4, 6, 32
+    n = H * W // 4
+    x = gen(B, 21 * n, Cc, seed=43)
+    w, b = gen(Cc, 1, 3, 3, seed=44), gen(Cc, seed=45)
+    xr = x.to(adt).float()
+    outs = []
+    for (a, e, hh, ww) in ((0, 16 * n, 2 * H, 2 * W), (16 * n, 20 * n, H, W), (20 * n, 21 * n, H // 2, W // 2)):
+        t = xr[:, a:e].transpose(1, 2).reshape(B, Cc, hh, ww)
+        outs.append(F.conv2d(t, w, b, padding=1, groups=Cc).flatten(2).transpose(1, 2))
+    ref = F.gelu(torch.cat(outs, 1))
+    w9c = w.reshape(Cc, 9).t().contiguous()
+    out = ops.dwconv3x3_gelu(x.cuda().to(adt), w9c.cuda(), b.cuda(), H, W)
+    check(f"dwconv3x3_gelu [{adt}]", out, ref, 1e-5 if adt == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("adt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(16, 64, 1, 4), (8, 32, 3, 4)], ids=["adapter", "pixdec"])
+def test_msdeform_sample(adt, cfg):
+    from oracle import siu3r_oracle as O
+
+    ops = _ops()
+    heads, d, L, P = cfg
+    B = 2
+    shapes = [(6, 8)] if L == 1 else [(3, 4), (6, 8), (12, 16)]
+    S = sum(a * b for a, b in shapes)
+    qshapes = [(12, 16), (6, 8), (3, 4)] if L == 1 else shapes
+    ref_pts = O.reference_points(qshapes)
+    Q = ref_pts.shape[0]
+    ref_l = ref_pts[:, None, :].expand(-1, L, -1).contiguous()
+    value = gen(B, S, heads * d, seed=46)
+    offs = gen(B, Q, heads, L, P, 2, seed=47, scale=3.0)  # several pixels, some samples fall outside
+    logits = gen(B, Q, heads, L * P, seed=48, scale=2.0)
+    norm = torch.tensor([[s[1], s[0]] for s in shapes], dtype=torch.float32)
+    loc = ref_l[None, :, None, :, None, :] + offs / norm[None, None, None, :, None, :]
+    aw = logits.softmax(-1).view(B, Q, heads, L, P)
+    ref = O.msdeform_core(value.to(adt).float().view(B, S, heads, d), shapes, loc, aw)
+    offs_aw = torch.cat([offs.reshape(B, Q, -1), logits.reshape(B, Q, -1)], -1).contiguous()
+    out = ops.msdeform_sample(value.cuda().to(adt), offs_aw.cuda(), ref_l.cuda(), shapes, heads, P, torch.float32)
+    check(f"msdeform_sample [{adt}] L={L}", out, ref, 2e-5 if adt == torch.float32 else 8e-3)
+
+
+def test_pts3d_and_gaussian_adapter():
+    from oracle import siu3r_oracle as O
+
+    ops = _ops()
+    xyz = gen(1000, 3, seed=49, scale=2.0)
+    xyz[0] = 0.0  # |xyz| = 0 -> clip(min=1e-8) branch
+    d = xyz.norm(dim=-1, keepdim=True)
+    ref = xyz / d.clip(min=1e-8) * torch.expm1(d)
+    check("pts3d_exp", ops.pts3d_exp_(xyz.cuda().clone()), ref, 2e-6)
+    raw = gen(3, 333, 83, seed=50, scale=4.0)
+    raw[0, 0, 1:4] = 30.0  # softplus threshold + scale clamp 0.3
+    raw[0, 1, 4:8] = 0.0   # zero quaternion -> eps path
+    g = O.gaussian_adapter(torch.zeros(3, 333, 3), raw)
+    for adt in (torch.float32,):
+        out = ops.gaussian_adapter(raw.cuda().to(adt))
+        for kk in ("opacities", "scales", "rotations", "harmonics"):
+            check(f"gaussian_adapter.{kk}", out[kk], g[kk], 3e-6)
+        check("gaussian_adapter.covariances", out["covariances"], g["covariances"], 3e-5)
+
+
+def test_m2f_attn_mask():
+    ops = _ops()
+    B, T, IH, IW, Q = 2, 2, 8, 12, 100
+    ml = gen(B, Q, T, IH, IW, seed=51, scale=3.0)
+    ml[0, 3] = -5.0  # fully blocked row -> must be re-opened (video_seg_decoder.py:1306-1308)
+    for size in [(4, 6), (8, 12), (2, 3)]:
+        am = F.interpolate(ml.flatten(0, 1), size=size, mode="bilinear", align_corners=False)
+        am = am.view(B, Q, T, *size).sigmoid().flatten(2) < 0.5
+        am[torch.where(am.sum(-1) == am.shape[-1])] = False
+        out = ops.m2f_attn_mask(ml.permute(0, 2, 3, 4, 1).contiguous().cuda(), size)
+        mism = (out.cpu().bool() != am).float().mean().item()
+        print(f"[parity] m2f_attn_mask {size}: mismatch fraction {mism:.2e}")
+        assert mism <= 1e-4  # boolean threshold of an fp32 bilinear sample: ties at |x|<1e-7 only
+        assert not out[0, 3].any()
+
+
+def test_split_bf16_exact():
+    ops = _ops()
+    x = gen(7, 100, seed=52)
+    hi, lo, kpad = ops.split_bf16(x.cuda(), True)
+    assert kpad == 128 and float(hi[:, 100:].float().abs().max()) == 0.0
+    h = x.bfloat16()
+    assert torch.equal(hi[:, :100].cpu(), h)
+    assert torch.equal(lo[:, :100].cpu(), (x - h.float()).bfloat16())
