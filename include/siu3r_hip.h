@@ -135,6 +135,24 @@ int siu3r_m2f_attn_mask(const float* mask_logits, uint8_t* out, int32_t* row_cou
  * weight / operand pre-packing for siu3r_gemm. */
 int siu3r_split_bf16(const float* x, void* hi, void* lo, int64_t rows, int k, int kpad, int64_t ldx, void* stream);
 
+/* ---- panoptic post-process on device (integer outputs).  Replaces
+ * VideoMask2FormerImageProcessor.post_process_panoptic_segmentation
+ * (reference src/models/mask2former/image_processing_video_mask2former.py:1238-1481) and the label scatter of
+ * SIU3RModel.post_process_gaussians (reference src/models/model.py:267-294).
+ * class_logits [B,Q,C] fp32; mask_logits_cl [B,T,IH,IW,Q] fp32 (channel-last).  All other pointers are outputs /
+ * workspaces: probs [B,Q,C], scores [B,Q], labels/kept_idx [B,Q] i32, n_keep [B] i32, p256 [B,T,ms,ms,Q] fp32,
+ * lab_map [B,T,H,W] i32, area/orig [B,Q] i32, per-kept-query table seg_id/seg_label/seg_fused [B,Q] i32 + seg_score
+ * [B,Q] fp32, acc_list [B,Q] / n_acc [B] i32, and the maps seg/sem/ins [B,T,H,W] i32.  fuse_mask bit c = class c fuses. */
+int siu3r_panoptic_stage1(const float* class_logits, const float* mask_logits_cl, float* probs, float* scores,
+                          int32_t* labels, int32_t* kept_idx, int32_t* n_keep, float* p256, int32_t* lab_map,
+                          int32_t* area, int32_t* orig, int32_t* seg_id, int32_t* seg_label, int32_t* seg_fused,
+                          float* seg_score, int32_t* acc_list, int32_t* n_acc, int32_t* seg, int32_t* sem, int32_t* ins,
+                          int B, int T, int Q, int C, int IH, int IW, int H, int W, int mask_size, float threshold,
+                          float mask_threshold, float overlap, uint32_t fuse_mask, void* stream);
+/* query_class_logits of batch item b in Gaussian-major layout out[(t,y,x), j, c] (model.py:261-263) */
+int siu3r_panoptic_qcl(const float* p256, const float* probs, const int32_t* kept_idx, const int32_t* acc_list, int nq,
+                       float* out, int b, int T, int H, int W, int mask_size, int Q, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

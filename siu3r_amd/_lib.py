@@ -68,6 +68,8 @@ SIGNATURES = {
     "siu3r_gaussian_adapter": [_P, _I, _P, _P, _P, _P, _P, _L, _P],
     "siu3r_m2f_attn_mask": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "siu3r_split_bf16": [_P, _P, _P, _L, _I, _I, _L, _P],
+    "siu3r_panoptic_stage1": [_P] * 20 + [_I] * 9 + [_F, _F, _F, C.c_uint32, _P],
+    "siu3r_panoptic_qcl": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
 }
 _RESTYPES = {"siu3r_last_error": C.c_char_p}
 

@@ -543,12 +543,12 @@ inline dim3 grid1d(int64_t total, int block = 256) { return dim3((unsigned)cdiv6
 // ================================ C ABI ==========================================================
 extern "C" int siu3r_rope2d(void* tokens, int dtype, int B, int N, int H, int D, int64_t sb, int64_t sn, int64_t sh,
                             const int64_t* positions, float base, float fwd, void* stream) {
-  SIU3R_CHECK(tokens && positions, "rope_2d: null pointer");
   SIU3R_CHECK(D % 4 == 0, "token dim must be multiple of 4");  // kernels.cu:94
   SIU3R_CHECK(dtype == SIU3R_F32 || dtype == SIU3R_BF16, "rope_2d: unsupported dtype %d", dtype);
   SIU3R_CHECK(B >= 0 && N >= 0 && H >= 0, "rope_2d: negative size");
   const int64_t total = (int64_t)B * N * (D / 2);
-  if (total == 0 || H == 0) return 0;
+  if (total == 0 || H == 0) return 0;  // empty launch is a no-op, like a 0-block CUDA launch
+  SIU3R_CHECK(tokens && positions, "rope_2d: null pointer");
   hipStream_t s = (hipStream_t)stream;
   if (dtype == SIU3R_F32)
     hipLaunchKernelGGL(rope2d_kernel<float>, grid1d(total), dim3(256), 0, s, (float*)tokens, positions, B, N, H, D, sb, sn, sh, base, fwd);

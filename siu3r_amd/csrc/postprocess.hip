@@ -1,0 +1,249 @@
+// Panoptic post-processing on device (integer outputs), restating
+// VideoMask2FormerImageProcessor.post_process_panoptic_segmentation
+// (reference src/models/mask2former/image_processing_video_mask2former.py:1238-1481) and the label scatter
+// of SIU3RModel.post_process_gaussians (reference src/models/model.py:267-294).
+//
+// Pipeline (no host sync until the segment table is read back):
+//   pp_class   : softmax over classes, (score,label)=max, keep = label != void && score > thr, compaction
+//   pp_mask256 : mask logits [B,T,h,w,Q] -> bilinear (256,256) -> sigmoid            (the hard-coded mask_size)
+//   pp_argmax  : bilinear (256,256)->(H,W) of the kept queries' probabilities, argmax_k(prob*score),
+//                area_k = #(argmax==k), orig_k = #(prob*score >= 0.5)
+//   pp_accept  : sequential acceptance (area/orig > 0.8), segment ids, stuff fusing       (1 thread / item)
+//   pp_write   : segmentation / semantic / instance maps from the per-query table
+//   pp_qcl     : query_class_logits[(t,y,x), j, c] = class_prob[k_j, c] * mask_prob[t, k_j, y, x]
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void src_idx(int o, int in, int out, int& i0, int& i1, float& l1) {
+  const float scale = (float)in / (float)out;
+  float src = scale * (o + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - i0;
+}
+
+// one block (64 threads) per batch item; thread q handles query q (Q <= 1024 via loop)
+__global__ void pp_class_kernel(const float* logits, float* probs, float* scores, int32_t* labels, int32_t* kept_idx,
+                                int32_t* n_keep, int Q, int C, float thr) {
+  const int b = blockIdx.x;
+  __shared__ int keep_flag[1024];
+  for (int q = threadIdx.x; q < Q; q += blockDim.x) {
+    const float* l = logits + ((int64_t)b * Q + q) * C;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, l[c]);
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(l[c] - mx);
+    float best = -1.f;
+    int bi = 0;
+    for (int c = 0; c < C; ++c) {
+      const float pr = expf(l[c] - mx) / den;
+      probs[((int64_t)b * Q + q) * C + c] = pr;
+      if (pr > best) {
+        best = pr;
+        bi = c;
+      }
+    }
+    scores[b * Q + q] = best;
+    labels[b * Q + q] = bi;
+    keep_flag[q] = (bi != C - 1) && (best > thr);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (int q = 0; q < Q; ++q)
+      if (keep_flag[q]) kept_idx[b * Q + n++] = q;
+    n_keep[b] = n;
+  }
+}
+
+__global__ void pp_mask256_kernel(const float* ml, float* out, int BT, int IH, int IW, int OS, int Q) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)BT * OS * OS * Q) return;
+  const int q = (int)(idx % Q);
+  int64_t r = idx / Q;
+  const int ox = (int)(r % OS);
+  r /= OS;
+  const int oy = (int)(r % OS);
+  const int bt = (int)(r / OS);
+  int y0, y1, x0, x1;
+  float ly, lx;
+  src_idx(oy, IH, OS, y0, y1, ly);
+  src_idx(ox, IW, OS, x0, x1, lx);
+  const int64_t base = (int64_t)bt * IH * IW;
+  const float v00 = ml[(base + (int64_t)y0 * IW + x0) * Q + q], v01 = ml[(base + (int64_t)y0 * IW + x1) * Q + q];
+  const float v10 = ml[(base + (int64_t)y1 * IW + x0) * Q + q], v11 = ml[(base + (int64_t)y1 * IW + x1) * Q + q];
+  const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+  out[idx] = 1.f / (1.f + expf(-v));
+}
+
+__device__ __forceinline__ float sample256(const float* p256, int64_t base, int MS, int Q, int q, int y0, int y1, int x0,
+                                           int x1, float ly, float lx) {
+  const float v00 = p256[(base + (int64_t)y0 * MS + x0) * Q + q], v01 = p256[(base + (int64_t)y0 * MS + x1) * Q + q];
+  const float v10 = p256[(base + (int64_t)y1 * MS + x0) * Q + q], v11 = p256[(base + (int64_t)y1 * MS + x1) * Q + q];
+  return (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+}
+
+// grid: (ceil(T*H*W/256), B)
+__global__ __launch_bounds__(256) void pp_argmax_kernel(const float* p256, const float* scores, const int32_t* kept_idx,
+                                                        const int32_t* n_keep, int32_t* lab_map, int32_t* area,
+                                                        int32_t* orig, int T, int H, int W, int MS, int Q,
+                                                        float mask_thr) {
+  const int b = blockIdx.y;
+  const int nk = n_keep[b];
+  __shared__ int s_area[128], s_orig[128];
+  for (int i = threadIdx.x; i < 128; i += 256) s_area[i] = s_orig[i] = 0;
+  __syncthreads();
+  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t npix = (int64_t)T * H * W;
+  if (pix < npix && nk > 0) {
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int t = (int)(pix / ((int64_t)W * H));
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_idx(y, MS, H, y0, y1, ly);
+    src_idx(x, MS, W, x0, x1, lx);
+    const int64_t base = ((int64_t)b * T + t) * MS * MS;
+    float best = -INFINITY;
+    int bk = 0;
+    for (int k = 0; k < nk; ++k) {
+      const int q = kept_idx[b * Q + k];
+      const float wv = sample256(p256, base, MS, Q, q, y0, y1, x0, x1, ly, lx) * scores[b * Q + q];
+      if (wv > best) {  // strict: first maximum wins, like torch.argmax
+        best = wv;
+        bk = k;
+      }
+      if (wv >= mask_thr) atomicAdd(&s_orig[k], 1);
+    }
+    lab_map[(int64_t)b * npix + pix] = bk;
+    atomicAdd(&s_area[bk], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nk && i < 128; i += 256) {
+    if (s_area[i]) atomicAdd(&area[b * Q + i], s_area[i]);
+    if (s_orig[i]) atomicAdd(&orig[b * Q + i], s_orig[i]);
+  }
+}
+
+// table per (b, k): seg_id (0 = rejected), label, fused flag, score ; n_acc[b]; acc_list[b, j] = k of j-th accepted
+__global__ void pp_accept_kernel(const int32_t* area, const int32_t* orig, const int32_t* kept_idx, const int32_t* n_keep,
+                                 const int32_t* labels, const float* scores, int32_t* seg_id, int32_t* seg_label,
+                                 int32_t* seg_fused, float* seg_score, int32_t* acc_list, int32_t* n_acc, int Q,
+                                 float overlap, uint32_t fuse_mask, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int nk = n_keep[b];
+  int cur = 0, na = 0;
+  int stuff_mem[32];
+  for (int i = 0; i < 32; ++i) stuff_mem[i] = 0;
+  for (int k = 0; k < Q; ++k) seg_id[b * Q + k] = 0;
+  for (int k = 0; k < nk; ++k) {
+    const int q = kept_idx[b * Q + k];
+    const int cls = labels[b * Q + q];
+    const bool fuse = cls < 32 && ((fuse_mask >> cls) & 1u);
+    const int a = area[b * Q + k], o = orig[b * Q + k];
+    bool exists = a > 0 && o > 0;
+    if (exists) {
+      const float ratio = (float)a / (float)o;
+      if (!(ratio > overlap)) exists = false;
+    }
+    if (!exists) continue;
+    int sid_f;
+    if (cls < 32 && stuff_mem[cls] != 0) {
+      sid_f = stuff_mem[cls];
+    } else {
+      cur += 1;
+      sid_f = cur;
+    }
+    const int sid = fuse ? sid_f : cur;
+    seg_id[b * Q + k] = sid;
+    seg_label[b * Q + k] = cls;
+    seg_fused[b * Q + k] = fuse ? 1 : 0;
+    seg_score[b * Q + k] = scores[b * Q + q];
+    acc_list[b * Q + na++] = k;
+    if (fuse && cls < 32 && stuff_mem[cls] == 0) stuff_mem[cls] = cur;
+  }
+  n_acc[b] = na;
+}
+
+__global__ void pp_write_kernel(const int32_t* lab_map, const int32_t* seg_id, const int32_t* seg_label,
+                                const int32_t* n_keep, int32_t* seg, int32_t* sem, int32_t* ins, int64_t npix, int Q) {
+  const int b = blockIdx.y;
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  int s = 0, se = 0, in = 0;
+  if (n_keep[b] > 0) {
+    const int k = lab_map[(int64_t)b * npix + pix];
+    const int id = seg_id[b * Q + k];
+    if (id > 0) {
+      s = id;
+      se = seg_label[b * Q + k] + 1;  // +1: 0 is background (model.py:282-284)
+      in = id;
+    }
+  }
+  seg[(int64_t)b * npix + pix] = s;
+  sem[(int64_t)b * npix + pix] = se;
+  ins[(int64_t)b * npix + pix] = in;
+}
+
+// out [(T*H*W), nq, C] for ONE batch item; acc = device list of accepted k (indices into kept_idx)
+__global__ void pp_qcl_kernel(const float* p256, const float* probs, const int32_t* kept_idx, const int32_t* acc, int nq,
+                              float* out, int b, int T, int H, int W, int MS, int Q, int C) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t npix = (int64_t)T * H * W;
+  if (idx >= npix * nq) return;
+  const int j = (int)(idx % nq);
+  const int64_t pix = idx / nq;
+  const int x = (int)(pix % W);
+  const int y = (int)((pix / W) % H);
+  const int t = (int)(pix / ((int64_t)W * H));
+  int y0, y1, x0, x1;
+  float ly, lx;
+  src_idx(y, MS, H, y0, y1, ly);
+  src_idx(x, MS, W, x0, x1, lx);
+  const int q = kept_idx[b * Q + acc[b * Q + j]];
+  const float mp = sample256(p256, ((int64_t)b * T + t) * MS * MS, MS, Q, q, y0, y1, x0, x1, ly, lx);
+  const float* cp = probs + ((int64_t)b * Q + q) * C;
+  float* o = out + idx * C;
+  for (int c = 0; c < C; ++c) o[c] = cp[c] * mp;
+}
+
+inline dim3 g1(int64_t n, int blk = 256) { return dim3((unsigned)cdiv64(n, blk)); }
+
+}  // namespace
+
+extern "C" int siu3r_panoptic_stage1(const float* class_logits, const float* mask_logits_cl, float* probs, float* scores,
+                                     int32_t* labels, int32_t* kept_idx, int32_t* n_keep, float* p256,
+                                     int32_t* lab_map, int32_t* area, int32_t* orig, int32_t* seg_id, int32_t* seg_label,
+                                     int32_t* seg_fused, float* seg_score, int32_t* acc_list, int32_t* n_acc,
+                                     int32_t* seg, int32_t* sem, int32_t* ins, int B, int T, int Q, int C, int IH,
+                                     int IW, int H, int W, int mask_size, float threshold, float mask_threshold,
+                                     float overlap, uint32_t fuse_mask, void* stream) {
+  SIU3R_CHECK(class_logits && mask_logits_cl && probs && p256 && lab_map && seg, "panoptic_stage1: null pointer");
+  SIU3R_CHECK(Q <= 128 && C <= 64, "panoptic_stage1: supports up to 128 queries / 64 classes (Q=%d C=%d)", Q, C);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(pp_class_kernel, dim3(B), dim3(64), 0, s, class_logits, probs, scores, labels, kept_idx, n_keep, Q, C, threshold);
+  hipLaunchKernelGGL(pp_mask256_kernel, g1((int64_t)B * T * mask_size * mask_size * Q), dim3(256), 0, s, mask_logits_cl, p256, B * T, IH, IW, mask_size, Q);
+  if (hipMemsetAsync(area, 0, sizeof(int32_t) * B * Q, s) != hipSuccess || hipMemsetAsync(orig, 0, sizeof(int32_t) * B * Q, s) != hipSuccess) {
+    siu3r_set_error("panoptic_stage1: memset failed");
+    return 2;
+  }
+  const int64_t npix = (int64_t)T * H * W;
+  hipLaunchKernelGGL(pp_argmax_kernel, dim3((unsigned)cdiv64(npix, 256), B), dim3(256), 0, s, p256, scores, kept_idx, n_keep, lab_map, area, orig, T, H, W, mask_size, Q, mask_threshold);
+  hipLaunchKernelGGL(pp_accept_kernel, g1(B, 64), dim3(64), 0, s, area, orig, kept_idx, n_keep, labels, scores, seg_id, seg_label, seg_fused, seg_score, acc_list, n_acc, Q, overlap, fuse_mask, B);
+  hipLaunchKernelGGL(pp_write_kernel, dim3((unsigned)cdiv64(npix, 256), B), dim3(256), 0, s, lab_map, seg_id, seg_label, n_keep, seg, sem, ins, npix, Q);
+  SIU3R_LAUNCH_CHECK("siu3r_panoptic_stage1");
+  return 0;
+}
+
+extern "C" int siu3r_panoptic_qcl(const float* p256, const float* probs, const int32_t* kept_idx, const int32_t* acc_list,
+                                  int nq, float* out, int b, int T, int H, int W, int mask_size, int Q, int C,
+                                  void* stream) {
+  SIU3R_CHECK(p256 && probs && kept_idx && acc_list && out && nq > 0, "panoptic_qcl: bad arguments");
+  hipLaunchKernelGGL(pp_qcl_kernel, g1((int64_t)T * H * W * nq), dim3(256), 0, (hipStream_t)stream, p256, probs, kept_idx, acc_list, nq, out, b, T, H, W, mask_size, Q, C);
+  SIU3R_LAUNCH_CHECK("siu3r_panoptic_qcl");
+  return 0;
+}

@@ -1,0 +1,679 @@
+"""Host-side mirror of the reference's ``src/models`` interface for the MI355X path.
+
+Module / attribute names, ``forward`` signatures and state-dict keys follow the reference
+(src/models/model.py:31-389, backbone_croco.py:24-347, vit_adapter/vit_adapter.py:305-441,
+heads/dpt_head.py, heads/dpt_gs_head.py, gaussian_adapter.py:50-110,
+mask2former/video_seg_decoder.py:2257-2477) so that a reference checkpoint loads unmodified.
+All arithmetic runs in libsiu3r_hip.so through ``siu3r_amd.ops``; PyTorch only allocates tensors and
+provides the stream.  Activations are channel-last and (batch, view)-major: row b*V + v.
+
+precision = "bf16"   : bf16 MFMA operands, bf16 inter-kernel activations, fp32 residual streams.
+precision = "bf16x3" : fp32 activations, every product as three bf16 MFMAs (hi*hi + hi*lo + lo*hi);
+                       this is the mode that meets the 1e-3 parity bar against the fp32 oracle.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU
+from .gaussians_types import Gaussians
+from . import postprocess as pp
+
+ENC_HEADS, DEC_HEADS = 16, 12
+ADAPTER_IDX = (5, 11, 17, 23)  # vit_adapter.py:317
+DPT_HOOKS = (0, 6, 9, 12)      # dpt_head.py:141
+
+
+class _Weights:
+    """Packed parameters on the GPU, keyed by reference state-dict names."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device, split: bool):
+        self.sd, self.dev, self.split = sd, device, split
+        self.lin: Dict[str, ops.PackedWeight] = {}
+        self.vec: Dict[str, torch.Tensor] = {}
+
+    def t(self, name):  # raw fp32 tensor on the GPU
+        return self.sd[name].to(self.dev, torch.float32)
+
+    def v(self, name):  # cached fp32 vector
+        if name not in self.vec:
+            self.vec[name] = self.t(name).contiguous()
+        return self.vec[name]
+
+    def linear(self, name, key=None, extra_bias=None):
+        key = key or name
+        if key not in self.lin:
+            w = self.t(name + ".weight")
+            w = w.reshape(w.shape[0], -1)
+            b = self.t(name + ".bias") if (name + ".bias") in self.sd else None
+            if extra_bias is not None:
+                b = extra_bias if b is None else b + extra_bias
+            self.lin[key] = ops.pack_matrix(w, b, self.split)
+        return self.lin[key]
+
+    def merged(self, key, names):
+        if key not in self.lin:
+            w = torch.cat([self.t(n + ".weight") for n in names], 0)
+            b = torch.cat([self.t(n + ".bias") for n in names], 0)
+            self.lin[key] = ops.pack_matrix(w, b, self.split)
+        return self.lin[key]
+
+    def conv(self, name, cin_pad=None, bn=None):
+        if name not in self.lin:
+            w = self.t(name + ".weight")
+            b = self.t(name + ".bias") if (name + ".bias") in self.sd else None
+            if bn is not None:  # fold eval-mode BatchNorm (eps 1e-5) into the convolution
+                s = self.t(bn + ".weight") / torch.sqrt(self.t(bn + ".running_var") + 1e-5)
+                w = w * s[:, None, None, None]
+                b0 = b if b is not None else torch.zeros_like(s)
+                b = (b0 - self.t(bn + ".running_mean")) * s + self.t(bn + ".bias")
+            self.lin[name] = ops.pack_conv(w, b, self.split, cin_pad=cin_pad)
+        return self.lin[name]
+
+    def convT(self, name):
+        if name not in self.lin:
+            self.lin[name] = ops.pack_conv_transpose(self.t(name + ".weight"), self.t(name + ".bias"), self.split)
+        return self.lin[name]
+
+    def bn_affine(self, name):
+        key = name + "#affine"
+        if key not in self.vec:
+            s = self.t(name + ".weight") / torch.sqrt(self.t(name + ".running_var") + 1e-5)
+            self.vec[key] = s.contiguous()
+            self.vec[key + "b"] = (self.t(name + ".bias") - self.t(name + ".running_mean") * s).contiguous()
+        return self.vec[key], self.vec[key + "b"]
+
+
+class _Ctx:
+    def __init__(self, w: _Weights, precision: str):
+        assert precision in ("bf16", "bf16x3")
+        self.w = w
+        self.precision = precision
+        self.split = precision == "bf16x3"
+        self.act = torch.float32 if self.split else torch.bfloat16
+        self.dev = w.dev
+        self.cache: Dict = {}
+
+    def ln(self, name, x, eps, out_dtype=None):
+        return ops.layernorm(x, self.w.v(name + ".weight"), self.w.v(name + ".bias"), eps, out_dtype or self.act)
+
+
+# ==================================================================================================
+# backbone  (reference backbone_croco.py:24-347; croco/blocks.py:81-191)
+# ==================================================================================================
+class AsymmetricCroCo:
+    def __init__(self, ctx: _Ctx, enc_depth=24, dec_depth=12, enc_embed_dim=1024, dec_embed_dim=768):
+        self.ctx = ctx
+        self.enc_depth, self.dec_depth = enc_depth, dec_depth
+        self.enc_embed_dim, self.dec_embed_dim = enc_embed_dim, dec_embed_dim
+        self.depth_mode = ("exp", -float("inf"), float("inf"))
+        self.conf_mode = None
+
+    # ---- constant tables
+    def _positions(self, B2, h, w):
+        key = ("pos", B2, h, w)
+        c = self.ctx.cache
+        if key not in c:
+            y, x = torch.arange(h), torch.arange(w)
+            pos = torch.cartesian_prod(y, x).view(1, h * w, 2)
+            extra = torch.tensor([[[h, 0]]])  # intrinsics token at (y = h, x = 0)  (backbone_croco.py:147-150)
+            pos = torch.cat((pos, extra), 1).expand(B2, -1, 2).contiguous().to(self.ctx.dev)
+            c[key] = pos
+        return c[key]
+
+    def _rope(self, max_pos, D=64, base=100.0):
+        key = ("rope", max_pos, D)
+        c = self.ctx.cache
+        if key not in c:
+            Q = D // 4
+            q = torch.arange(Q, dtype=torch.float32)
+            inv = 1.0 / torch.pow(torch.tensor(base, dtype=torch.float32), q / Q)
+            ang = torch.arange(max_pos, dtype=torch.float32)[:, None] * inv[None]
+            c[key] = (torch.cos(ang).contiguous().to(self.ctx.dev), torch.sin(ang).contiguous().to(self.ctx.dev))
+        return c[key]
+
+    def _attn(self, p, xn, pos, rope, heads):
+        """Attention.forward (blocks.py:94-112) on normalised tokens xn [Z, N, C] -> pre-projection context."""
+        ctx = self.ctx
+        Z, N, Cc = xn.shape
+        qkv = ops.linear(xn, ctx.w.linear(p + ".qkv"), out_dtype=ctx.act).view(Z, N, 3, heads, Cc // heads)
+        return ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], heads=heads, head_dim=Cc // heads,
+                             scale=(Cc // heads) ** -0.5, rope=rope, qpos=pos, kpos=pos, split3=ctx.split)
+
+    def _mlp(self, p, x, ln_name):
+        ctx = self.ctx
+        h = ops.linear(ctx.ln(ln_name, x, 1e-6), ctx.w.linear(p + ".fc1"), out_dtype=ctx.act, act=ACT_GELU)
+        return ops.linear(h, ctx.w.linear(p + ".fc2"), out_dtype=torch.float32, residual=x)
+
+    def _enc_block(self, p, x, pos, rope):
+        ctx = self.ctx
+        a = self._attn(p + ".attn", ctx.ln(p + ".norm1", x, 1e-6), pos, rope, ENC_HEADS)
+        x = ops.linear(a, ctx.w.linear(p + ".attn.proj"), out_dtype=torch.float32, residual=x)
+        return self._mlp(p + ".mlp", x, p + ".norm2")
+
+    def _dec_block(self, p, x, y, xpos, ypos, rope):
+        """DecoderBlock.forward (blocks.py:186-191); x, y are [B, N, C] fp32 strided views."""
+        ctx = self.ctx
+        B, N, Cc = x.shape
+        d = Cc // DEC_HEADS
+        a = self._attn(p + ".attn", ctx.ln(p + ".norm1", x, 1e-6), xpos, rope, DEC_HEADS)
+        x = ops.linear(a, ctx.w.linear(p + ".attn.proj"), out_dtype=torch.float32, residual=x)
+        y_ = ctx.ln(p + ".norm_y", y, 1e-6)
+        q = ops.linear(ctx.ln(p + ".norm2", x, 1e-6), ctx.w.linear(p + ".cross_attn.projq"), out_dtype=ctx.act).view(B, N, DEC_HEADS, d)
+        kv = ops.linear(y_, ctx.w.merged(p + ".cross_attn.projkv", [p + ".cross_attn.projk", p + ".cross_attn.projv"]),
+                        out_dtype=ctx.act).view(B, N, 2, DEC_HEADS, d)
+        a = ops.attention(q, kv[:, :, 0], kv[:, :, 1], heads=DEC_HEADS, head_dim=d, scale=d ** -0.5, rope=rope,
+                          qpos=xpos, kpos=ypos, split3=ctx.split)
+        x = ops.linear(a, ctx.w.linear(p + ".cross_attn.proj"), out_dtype=torch.float32, residual=x)
+        return self._mlp(p + ".mlp", x, p + ".norm3")
+
+    def forward(self, context: dict, symmetrize_batch=False, return_views=False):
+        """reference signature backbone_croco.py:263-268; context = {"image": [B,2,3,H,W], "intrinsics": [B,2,3,3]}."""
+        assert not symmetrize_batch, "symmetrize_batch is a training-time option"
+        ctx = self.ctx
+        images, K = context["image"], context["intrinsics"]
+        B, V, _, H, W = images.shape
+        assert V == 2
+        assert H % 16 == 0, f"Input image height ({H}) is not a multiple of patch size (16)."
+        assert W % 16 == 0, f"Input image width ({W}) is not a multiple of patch size (16)."
+        h, w = H // 16, W // 16
+        N = h * w
+        Z = B * V
+        img = images.reshape(Z, 3, H, W).contiguous().float()
+        x = torch.empty((Z, N + 1, self.enc_embed_dim), dtype=torch.float32, device=ctx.dev)
+        pe = ctx.w.lin.get("backbone.patch_embed.proj") or ctx.w.linear("backbone.patch_embed.proj")
+        ops.patch_embed(img, pe, x)
+        # intrinsics token: Linear(9 -> 1024) on the flattened K (backbone_croco.py:278), K padded to 16 columns
+        if "backbone.intrinsic_encoder" not in ctx.w.lin:
+            wi = F.pad(ctx.w.t("backbone.intrinsic_encoder.weight"), (0, 7))
+            ctx.w.lin["backbone.intrinsic_encoder"] = ops.pack_matrix(wi, ctx.w.t("backbone.intrinsic_encoder.bias"), ctx.split)
+        kin = torch.zeros((Z, 16), dtype=torch.float32, device=ctx.dev)
+        kin[:, :9] = K.reshape(Z, 9).float()
+        ops.linear(kin, ctx.w.lin["backbone.intrinsic_encoder"], out=x[:, N])
+        pos = self._positions(Z, h, w)
+        rope = self._rope(max(h, w) + 1)
+        all_feat = []
+        for i in range(self.enc_depth):
+            x = self._enc_block(f"backbone.enc_blocks.{i}", x, pos, rope)
+            all_feat.append(x)
+        f = ctx.ln("backbone.enc_norm", x, 1e-6, out_dtype=torch.float32)
+        g = ops.linear(f, ctx.w.linear("backbone.decoder_embed"), out_dtype=torch.float32)
+        fv = f.view(B, V, N + 1, -1)
+        pv = pos.view(B, V, N + 1, 2)
+        pos1, pos2 = pv[:, 0].contiguous(), pv[:, 1].contiguous()
+        outs1, outs2 = [fv[:, 0]], [fv[:, 1]]
+        for i in range(self.dec_depth):
+            gv = g.view(B, V, N + 1, -1)
+            n1 = self._dec_block(f"backbone.dec_blocks.{i}", gv[:, 0], gv[:, 1], pos1, pos2, rope)
+            n2 = self._dec_block(f"backbone.dec_blocks2.{i}", gv[:, 1], gv[:, 0], pos2, pos1, rope)
+            g = torch.stack((n1, n2), dim=1)  # layout plumbing: keep (b, v)-major for the next layer
+            outs1.append(n1)
+            outs2.append(n2)
+        outs1[-1] = ctx.ln("backbone.dec_norm", outs1[-1], 1e-6, out_dtype=torch.float32)
+        outs2[-1] = ctx.ln("backbone.dec_norm", outs2[-1], 1e-6, out_dtype=torch.float32)
+        strip = lambda t: t[..., :-1, :]
+        av = [t.view(B, V, N + 1, -1) for t in all_feat]
+        feat1, feat2 = strip(fv[:, 0]), strip(fv[:, 1])
+        all_feat1, all_feat2 = [strip(t[:, 0]) for t in av], [strip(t[:, 1]) for t in av]
+        dec1, dec2 = [strip(t) for t in outs1], [strip(t) for t in outs2]
+        shape = torch.tensor([[H, W]] * B)
+        self._all_feat_bv = [strip(t) for t in av]  # [B, V, N, C] views for the (b,v)-batched adapter
+        res = (feat1, feat2, all_feat1, all_feat2, dec1, dec2, shape, shape.clone())
+        if return_views:
+            res = res + ({"img": images[:, 0]}, {"img": images[:, 1]})
+        return res
+
+    __call__ = forward
+
+    @property
+    def patch_size(self):
+        return 16
+
+    @property
+    def d_out(self):
+        return 1024
+
+
+# ==================================================================================================
+# DPT heads (heads/dpt_block.py, dpt_head.py:36-79, dpt_gs_head.py:121-171)
+# ==================================================================================================
+class _DPTHead:
+    def __init__(self, ctx: _Ctx, prefix: str, gs: bool):
+        self.ctx, self.p, self.gs = ctx, prefix, gs
+
+    def _rcu(self, q, x, extra=None):
+        """ResidualConvUnit_custom (dpt_block.py:126-147): conv2(relu(conv1(relu(x)))) + x (+ extra)."""
+        ctx = self.ctx
+        o = ops.conv2d(x, ctx.w.conv(q + ".conv1"), pad=1, out_dtype=ctx.act, act=ACT_RELU, relu_in=True)
+        res = x if extra is None else ops.affine_add(x, extra, None, None)
+        return ops.conv2d(o, ctx.w.conv(q + ".conv2"), pad=1, out_dtype=ctx.act, residual=res)
+
+    def _fusion(self, q, x0, x1):
+        """FeatureFusionBlock_custom.forward (dpt_block.py:198-237).  out_conv (1x1) commutes with the
+        align_corners=True bilinear x2 (both linear, weights sum to 1), so it runs at the low resolution."""
+        ctx = self.ctx
+        out = x0 if x1 is None else self._rcu(q + ".resConfUnit1", x1, extra=x0)
+        out = self._rcu(q + ".resConfUnit2", out)
+        out = ops.linear(out, ctx.w.linear(q + ".out_conv"), out_dtype=ctx.act)
+        B, hh, ww, Cc = out.shape
+        return ops.resize_bilinear(out, (2 * hh, 2 * ww), True)
+
+    def trunk(self, tokens: Sequence[torch.Tensor], H, W):
+        ctx, p = self.ctx, self.p
+        nh, nw = H // 16, W // 16
+        layers = []
+        for i, hk in enumerate(DPT_HOOKS):
+            t = tokens[hk]  # [B, N, C] fp32 strided view
+            B = t.shape[0]
+            a = f"{p}.dpt.act_postprocess.{i}"
+            l = ops.linear(t, ctx.w.linear(a + ".0"), out_dtype=ctx.act).view(B, nh, nw, -1)
+            if i in (0, 1):
+                l = ops.conv_transpose2d(l, ctx.w.convT(a + ".1"), out_dtype=ctx.act)
+            elif i == 3:
+                l = ops.conv2d(l, ctx.w.conv(a + ".1"), stride=2, pad=1, out_dtype=ctx.act)
+            l = ops.conv2d(l, ctx.w.conv(f"{p}.dpt.scratch.layer_rn.{i}"), pad=1, out_dtype=ctx.act)
+            layers.append(l)
+        s = f"{p}.dpt.scratch"
+        path4 = self._fusion(s + ".refinenet4", layers[3], None)
+        path3 = self._fusion(s + ".refinenet3", path4, layers[2])
+        path2 = self._fusion(s + ".refinenet2", path3, layers[1])
+        return self._fusion(s + ".refinenet1", path2, layers[0])
+
+    def forward_pts3d(self, tokens, H, W):
+        """PixelwiseTaskWithDPT.forward + postprocess 'exp' (dpt_head.py:113-120; postprocess.py:45-61)."""
+        ctx, p = self.ctx, self.p
+        x = self.trunk(tokens, H, W)
+        x = ops.conv2d(x, ctx.w.conv(f"{p}.dpt.head.0"), pad=1, out_dtype=ctx.act)
+        x = ops.resize_bilinear(x, (H, W), True)
+        x = ops.conv2d(x, ctx.w.conv(f"{p}.dpt.head.2"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
+        xyz = ops.linear(x, ctx.w.linear(f"{p}.dpt.head.4"), out_dtype=torch.float32)
+        return {"pts3d": ops.pts3d_exp_(xyz)}
+
+    def forward_gs(self, tokens, img_nhwc8, H, W):
+        """dpt_gs_head.py:121-171: feat_up(path_1) + ReLU(conv7x7(img)) fused into the 7x7 conv's epilogue."""
+        ctx, p = self.ctx, self.p
+        path1 = self.trunk(tokens, H, W)
+        x = ops.conv2d(img_nhwc8, ctx.w.conv(f"{p}.dpt.input_merger.0", cin_pad=8), pad=3, out_dtype=ctx.act,
+                       act=ACT_RELU, up_src=path1)
+        x = ops.conv2d(x, ctx.w.conv(f"{p}.dpt.head.0"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
+        return ops.linear(x, ctx.w.linear(f"{p}.dpt.head.4"), out_dtype=torch.float32)  # [B,H,W,83]
+
+
+class UnifiedGaussianAdapter:
+    """gaussian_adapter.py:50-110."""
+
+    def __init__(self, gaussian_scale_min=0.5, gaussian_scale_max=15.0, sh_degree=4):
+        assert sh_degree == 4, "the HIP adapter kernel is specialised for sh_degree 4 (83 raw channels)"
+        self.sh_degree = sh_degree
+
+    @property
+    def d_sh(self):
+        return (self.sh_degree + 1) ** 2
+
+    @property
+    def d_in(self):
+        return 7 + 3 * self.d_sh
+
+    def forward(self, means, raw_gaussians, eps: float = 1e-8) -> Gaussians:
+        g = ops.gaussian_adapter(raw_gaussians.contiguous())
+        return Gaussians(means=means, **g)
+
+
+# ==================================================================================================
+# ViT-Adapter (vit_adapter/vit_adapter.py:305-441)
+# ==================================================================================================
+class CroCoViTAdapter:
+    def __init__(self, ctx: _Ctx, size):
+        self.ctx = ctx
+        self.H, self.W = size[0] // 16, size[1] // 16
+
+    def _ref(self, Hi, Wi):
+        key = ("adapter_ref", Hi, Wi)
+        c = self.ctx.cache
+        if key not in c:
+            pts = []
+            for (hh, ww) in ((Hi // 8, Wi // 8), (Hi // 16, Wi // 16), (Hi // 32, Wi // 32)):
+                ry, rx = torch.meshgrid(torch.linspace(0.5, hh - 0.5, hh), torch.linspace(0.5, ww - 0.5, ww), indexing="ij")
+                pts.append(torch.stack((rx.reshape(-1) / ww, ry.reshape(-1) / hh), -1))
+            c[key] = torch.cat(pts, 0)[:, None, :].contiguous().to(self.ctx.dev)
+        return c[key]
+
+    def _extractor(self, p, c, ref, feat, h, w):
+        """Extractor.forward (vit_adapter.py:96-121); MSDeformAttn.forward (blocks.py:147-213)."""
+        ctx = self.ctx
+        qn = ctx.ln(p + ".query_norm", c, 1e-6)
+        fn = ctx.ln(p + ".feat_norm", feat, 1e-6)
+        offs_aw = ops.linear(qn, ctx.w.merged(p + ".attn.offs_aw", [p + ".attn.sampling_offsets", p + ".attn.attention_weights"]), out_dtype=torch.float32)
+        value = ops.linear(fn, ctx.w.linear(p + ".attn.value_proj"), out_dtype=ctx.act)
+        samp = ops.msdeform_sample(value, offs_aw, ref, [(h, w)], 16, 4, ctx.act)
+        c = ops.linear(samp, ctx.w.linear(p + ".attn.output_proj"), out_dtype=torch.float32, residual=c)
+        f1 = ops.linear(ctx.ln(p + ".ffn_norm", c, 1e-6), ctx.w.linear(p + ".ffn.fc1"), out_dtype=ctx.act)
+        wk = p + ".ffn.dwconv.dwconv"
+        if wk + "#w9c" not in ctx.w.vec:
+            ctx.w.vec[wk + "#w9c"] = ctx.w.t(wk + ".weight").reshape(-1, 9).t().contiguous()
+        f2 = ops.dwconv3x3_gelu(f1, ctx.w.vec[wk + "#w9c"], ctx.w.v(wk + ".bias"), h, w)
+        return ops.linear(f2, ctx.w.linear(p + ".ffn.fc2"), out_dtype=torch.float32, residual=c)
+
+    def forward_nhwc(self, img: torch.Tensor, img8: torch.Tensor, all_feat: Sequence[torch.Tensor]):
+        """img [Z,3,Hi,Wi]; all_feat: 24 x [Z, N, 1024] fp32 (strided views).  Returns 4 NHWC maps [Z,h_l,w_l,1024]."""
+        ctx = self.ctx
+        Z, _, Hi, Wi = img.shape
+        h, w = Hi // 16, Wi // 16
+        ref = self._ref(Hi, Wi)
+        sp = "adapter.spm"
+        c = ops.conv2d(img8, ctx.w.conv(sp + ".stem.0", cin_pad=8, bn=sp + ".stem.1"), stride=2, pad=1, out_dtype=ctx.act, act=ACT_RELU)
+        c = ops.conv2d(c, ctx.w.conv(sp + ".stem.3", bn=sp + ".stem.4"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
+        c = ops.conv2d(c, ctx.w.conv(sp + ".stem.6", bn=sp + ".stem.7"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
+        c1 = ops.maxpool3x3s2(c)
+        c2 = ops.conv2d(c1, ctx.w.conv(sp + ".conv2.0", bn=sp + ".conv2.1"), stride=2, pad=1, out_dtype=ctx.act, act=ACT_RELU)
+        c3 = ops.conv2d(c2, ctx.w.conv(sp + ".conv3.0", bn=sp + ".conv3.1"), stride=2, pad=1, out_dtype=ctx.act, act=ACT_RELU)
+        c4 = ops.conv2d(c3, ctx.w.conv(sp + ".conv4.0", bn=sp + ".conv4.1"), stride=2, pad=1, out_dtype=ctx.act, act=ACT_RELU)
+        le = ctx.w.t("adapter.level_embed")
+        n2, n3, n4 = 4 * h * w, h * w, h * w // 4
+        cc = torch.empty((Z, n2 + n3 + n4, 1024), dtype=torch.float32, device=ctx.dev)
+        c1 = ops.linear(c1, ctx.w.linear(sp + ".fc1"), out_dtype=torch.float32)  # [Z,4h,4w,1024]
+        # level_embed is folded into the fc biases (vit_adapter.py:387-391)
+        ops.linear(c2.view(Z, n2, -1), ctx.w.linear(sp + ".fc2", key=sp + ".fc2+le", extra_bias=le[0]), out=cc[:, :n2])
+        ops.linear(c3.view(Z, n3, -1), ctx.w.linear(sp + ".fc3", key=sp + ".fc3+le", extra_bias=le[1]), out=cc[:, n2:n2 + n3])
+        ops.linear(c4.view(Z, n4, -1), ctx.w.linear(sp + ".fc4", key=sp + ".fc4+le", extra_bias=le[2]), out=cc[:, n2 + n3:])
+        outs = []
+        for i, idx in enumerate(ADAPTER_IDX):
+            x = all_feat[idx]
+            cc = self._extractor(f"adapter.interactions.{i}.extractor", cc, ref, x, h, w)
+            if i == 3:
+                for j in range(2):
+                    cc = self._extractor(f"adapter.interactions.3.extra_extractors.{j}", cc, ref, x, h, w)
+            outs.append(x.contiguous().view(Z, h, w, -1))  # layout plumbing: strip-view -> dense NHWC
+        c2 = cc[:, :n2].contiguous().view(Z, 2 * h, 2 * w, -1)
+        c3 = cc[:, n2:n2 + n3].contiguous().view(Z, h, w, -1)
+        c4 = cc[:, n2 + n3:].contiguous().view(Z, h // 2, w // 2, -1)
+        c1 = ops.conv_transpose2d(c2, ctx.w.convT("adapter.up"), out_dtype=torch.float32, residual=c1)
+        x1, x2, x3, x4 = outs
+        s1, b1 = ctx.w.bn_affine("adapter.norm1")
+        s2, b2 = ctx.w.bn_affine("adapter.norm2")
+        s3, b3 = ctx.w.bn_affine("adapter.norm3")
+        s4, b4 = ctx.w.bn_affine("adapter.norm4")
+        f1 = ops.resize_bilinear(x1, (4 * h, 4 * w), False, addend=c1, ch_scale=s1, ch_shift=b1, out_dtype=ctx.act)
+        f2 = ops.resize_bilinear(x2, (2 * h, 2 * w), False, addend=c2, ch_scale=s2, ch_shift=b2, out_dtype=ctx.act)
+        f3 = ops.affine_add(x3, c3, s3, b3, out_dtype=ctx.act)
+        f4 = ops.resize_bilinear(x4, (h // 2, w // 2), False, addend=c4, ch_scale=s4, ch_shift=b4, out_dtype=ctx.act)
+        return [f1, f2, f3, f4]
+
+    def forward(self, x, all_feat):
+        """reference signature (vit_adapter.py:393): returns [f1..f4] as NCHW-shaped (channels-last) tensors."""
+        img8 = ops.pack_image_nhwc8(x.contiguous().float(), self.ctx.act)
+        return [f.permute(0, 3, 1, 2) for f in self.forward_nhwc(x, img8, all_feat)]
+
+    __call__ = forward
+
+
+# ==================================================================================================
+# Mask2Former (mask2former/video_seg_decoder.py)
+# ==================================================================================================
+def _sine_pos_2d(h, w, npf=128):
+    """VideoMask2FormerSinePositionEmbedding (video_seg_decoder.py:704-735), normalize=True -> [h*w, 2*npf]."""
+    y = torch.arange(1, h + 1, dtype=torch.float32)[:, None].expand(h, w)
+    x = torch.arange(1, w + 1, dtype=torch.float32)[None, :].expand(h, w)
+    eps, scale = 1e-6, 2 * math.pi
+    y = y / (y[-1:, :] + eps) * scale
+    x = x / (x[:, -1:] + eps) * scale
+    dim_t = torch.arange(npf, dtype=torch.float32)
+    dim_t = 10000 ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / npf)
+    px, py = x[:, :, None] / dim_t, y[:, :, None] / dim_t
+    px = torch.stack((px[:, :, 0::2].sin(), px[:, :, 1::2].cos()), dim=3).flatten(2)
+    py = torch.stack((py[:, :, 0::2].sin(), py[:, :, 1::2].cos()), dim=3).flatten(2)
+    return torch.cat((py, px), dim=2).reshape(h * w, 2 * npf)
+
+
+def _sine_pos_3d(t, h, w, npf=128):
+    """VideoMask2Former3DSinePositionEmbedding (video_seg_decoder.py:628-679) -> [t*h*w, 2*npf]."""
+    z = torch.arange(1, t + 1, dtype=torch.float32)[:, None, None].expand(t, h, w)
+    y = torch.arange(1, h + 1, dtype=torch.float32)[None, :, None].expand(t, h, w)
+    x = torch.arange(1, w + 1, dtype=torch.float32)[None, None, :].expand(t, h, w)
+    eps, scale = 1e-6, 2 * math.pi
+    y = y / (y[:, -1:, :] + eps) * scale
+    x = x / (x[:, :, -1:] + eps) * scale
+    z = z / (z[-1:, :, :] + eps) * scale
+    dim_t = torch.arange(npf, dtype=torch.float32)
+    dim_t = 10000 ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / npf)
+    dim_tz = torch.arange(npf * 2, dtype=torch.float32)
+    dim_tz = 10000 ** (2 * torch.div(dim_tz, 2, rounding_mode="floor") / (npf * 2))
+    px, py, pz = x[..., None] / dim_t, y[..., None] / dim_t, z[..., None] / dim_tz
+    f = lambda p_: torch.stack((p_[..., 0::2].sin(), p_[..., 1::2].cos()), dim=4).flatten(3)
+    return (torch.cat((f(py), f(px)), dim=3) + f(pz)).reshape(t * h * w, 2 * npf)
+
+
+class VideoMask2FormerForVideoSegmentationOutput(dict):
+    """Attribute-style output like the reference's ModelOutput (video_seg_decoder.py:2464-2471)."""
+
+    __getattr__ = dict.get
+
+
+class VideoMask2FormerForVideoSegmentation:
+    def __init__(self, ctx: _Ctx, num_queries=100):
+        self.ctx, self.num_queries = ctx, num_queries
+        self.heads = 8
+
+    # ---- pixel decoder (video_seg_decoder.py:2072-2196), feats NHWC [N2, h_l, w_l, 1024], strides 4,8,16,32
+    def _pixel_decoder(self, feats):
+        ctx = self.ctx
+        pd = "mask2former.model.pixel_decoder"
+        N2 = feats[0].shape[0]
+        lv = list(feats)[::-1][:3]
+        shapes = [(f.shape[1], f.shape[2]) for f in lv]
+        S = sum(a * b for a, b in shapes)
+        key = ("pd_const", tuple(shapes))
+        if key not in ctx.cache:
+            le = ctx.w.t(pd + ".level_embed").cpu()
+            pos = torch.cat([_sine_pos_2d(a, b) + le[i] for i, (a, b) in enumerate(shapes)], 0)
+            pts = []
+            for (hh, ww) in shapes:
+                ry, rx = torch.meshgrid(torch.linspace(0.5, hh - 0.5, hh), torch.linspace(0.5, ww - 0.5, ww), indexing="ij")
+                pts.append(torch.stack((rx.reshape(-1) / ww, ry.reshape(-1) / hh), -1))
+            ref = torch.cat(pts, 0)[:, None, :].expand(-1, 3, -1).contiguous()
+            ctx.cache[key] = (pos.contiguous().to(ctx.dev), ref.to(ctx.dev))
+        pos, ref = ctx.cache[key]
+        hs = torch.empty((N2, S, 256), dtype=torch.float32, device=ctx.dev)
+        o = 0
+        for lvl, x in enumerate(lv):
+            e = ops.linear(x, ctx.w.linear(f"{pd}.input_projections.{lvl}.0"), out_dtype=torch.float32)
+            e = ops.groupnorm(e, ctx.w.v(f"{pd}.input_projections.{lvl}.1.weight"), ctx.w.v(f"{pd}.input_projections.{lvl}.1.bias"))
+            n = shapes[lvl][0] * shapes[lvl][1]
+            hs[:, o:o + n] = e.view(N2, n, 256)  # layout plumbing: concatenate levels
+            o += n
+        for i in range(6):
+            p = f"{pd}.encoder.layers.{i}"
+            q = ops.add(hs, pos)
+            offs_aw = ops.linear(q, ctx.w.merged(p + ".self_attn.offs_aw", [p + ".self_attn.sampling_offsets", p + ".self_attn.attention_weights"]), out_dtype=torch.float32)
+            value = ops.linear(hs, ctx.w.linear(p + ".self_attn.value_proj"), out_dtype=ctx.act)
+            samp = ops.msdeform_sample(value, offs_aw, ref, shapes, 8, 4, ctx.act)
+            a = ops.linear(samp, ctx.w.linear(p + ".self_attn.output_proj"), out_dtype=torch.float32, residual=hs)
+            hs = ctx.ln(p + ".self_attn_layer_norm", a, 1e-5, out_dtype=torch.float32)
+            f_ = ops.linear(hs, ctx.w.linear(p + ".fc1"), out_dtype=ctx.act, act=ACT_RELU)
+            f_ = ops.linear(f_, ctx.w.linear(p + ".fc2"), out_dtype=torch.float32, residual=hs)
+            hs = ctx.ln(p + ".final_layer_norm", f_, 1e-5, out_dtype=torch.float32)
+        outs, o = [], 0
+        for (hh, ww) in shapes:
+            outs.append(hs[:, o:o + hh * ww].contiguous().view(N2, hh, ww, 256))
+            o += hh * ww
+        f0 = feats[0]
+        lat = ops.linear(f0, ctx.w.linear(pd + ".adapter_1.0"), out_dtype=torch.float32)
+        up = ops.resize_bilinear(outs[-1], (f0.shape[1], f0.shape[2]), False)
+        out = ops.groupnorm(lat, ctx.w.v(pd + ".adapter_1.1.weight"), ctx.w.v(pd + ".adapter_1.1.bias"), addend=up, out_dtype=ctx.act)
+        out = ops.conv2d(out, ctx.w.conv(pd + ".layer_1.0"), pad=1, out_dtype=torch.float32)
+        out = ops.groupnorm(out, ctx.w.v(pd + ".layer_1.1.weight"), ctx.w.v(pd + ".layer_1.1.bias"), relu=True, out_dtype=ctx.act)
+        mask_features = ops.linear(out, ctx.w.linear(pd + ".mask_projection"), out_dtype=torch.float32)
+        return mask_features, outs
+
+    def _mask_predictor(self, inter, mask_features_bt, size):
+        """VideoMask2FormerMaskPredictor.forward (video_seg_decoder.py:1448-1480).  inter [B,Q,256] fp32 (layer-normed);
+        mask_features_bt [B, T*H4*W4, 256].  Returns (mask logits [B,T,H4,W4,Q] fp32, attention mask uint8 [B,Q,T*h*w])."""
+        ctx = self.ctx
+        p = "mask2former.model.transformer_module.decoder.mask_predictor.mask_embedder"
+        e = ops.linear(inter, ctx.w.linear(p + ".0.0"), out_dtype=ctx.act, act=ACT_RELU)
+        e = ops.linear(e, ctx.w.linear(p + ".1.0"), out_dtype=ctx.act, act=ACT_RELU)
+        e = ops.linear(e, ctx.w.linear(p + ".2.0"), out_dtype=torch.float32)
+        B, Q, Cc = e.shape
+        hi, lo, kpad = ops.split_bf16(e.view(B * Q, Cc), ctx.split)
+        m = ops.bmm_nt(mask_features_bt, hi.view(B, Q, kpad), None if lo is None else lo.view(B, Q, kpad), Q, Cc)
+        m = m.view(B, self._T, self._H4, self._W4, Q)
+        am = ops.m2f_attn_mask(m, size) if size is not None else None
+        return m, am
+
+    def _decoder(self, ms, mask_features, B, T):
+        """TransformerModule.forward + MaskedAttentionDecoder.forward (video_seg_decoder.py:1506-1575,1204-1360)."""
+        ctx = self.ctx
+        tm = "mask2former.model.transformer_module"
+        dp = tm + ".decoder"
+        H4, W4 = mask_features.shape[1], mask_features.shape[2]
+        self._T, self._H4, self._W4 = T, H4, W4
+        mf_bt = mask_features.view(B, T * H4 * W4, 256)
+        sizes = [(f.shape[1], f.shape[2]) for f in ms]
+        key = ("m2f_pos3d", T, tuple(sizes))
+        if key not in ctx.cache:
+            ctx.cache[key] = [_sine_pos_3d(T, a, b).contiguous().to(ctx.dev) for (a, b) in sizes]
+        pos3 = ctx.cache[key]
+        le = ctx.w.t(tm + ".level_embed.weight")
+        ones = ctx.cache.setdefault("ones256", torch.ones(256, device=ctx.dev))
+        feats, keys_in = [], []
+        for i in range(3):
+            f_ = ops.affine_add(ms[i], None, ones, le[i].contiguous(), out_dtype=torch.float32)
+            f_ = f_.view(B, T * sizes[i][0] * sizes[i][1], 256)
+            feats.append(f_)
+            keys_in.append(ops.add(f_, pos3[i]))
+        Q = self.num_queries
+        qf = ctx.w.t(tm + ".queries_features.weight")
+        qe = ctx.w.t(tm + ".queries_embedder.weight").contiguous()
+        hs = qf.unsqueeze(0).expand(B, -1, -1).contiguous()
+        d = 32
+        inter = ctx.ln(dp + ".layernorm", hs, 1e-5, out_dtype=torch.float32)
+        masks, inters = [], [inter]
+        m, am = self._mask_predictor(inter, mf_bt, sizes[0])
+        masks.append(m)
+        for idx in range(9):
+            p = f"{dp}.layers.{idx}"
+            lvl = idx % 3
+            if p + ".cross_attn.q" not in ctx.w.lin:
+                wi, bi = ctx.w.t(p + ".cross_attn.in_proj_weight"), ctx.w.t(p + ".cross_attn.in_proj_bias")
+                ctx.w.lin[p + ".cross_attn.q"] = ops.pack_matrix(wi[:256], bi[:256], ctx.split)
+                ctx.w.lin[p + ".cross_attn.k"] = ops.pack_matrix(wi[256:512], bi[256:512], ctx.split)
+                ctx.w.lin[p + ".cross_attn.v"] = ops.pack_matrix(wi[512:], bi[512:], ctx.split)
+            # masked cross-attention (nn.MultiheadAttention, :975-983): q from hs + query pos, k from feats + pos3d, v from feats
+            qin = ops.add(hs, qe)
+            q = ops.linear(qin, ctx.w.lin[p + ".cross_attn.q"], out_dtype=ctx.act).view(B, Q, 8, d)
+            k = ops.linear(keys_in[lvl], ctx.w.lin[p + ".cross_attn.k"], out_dtype=ctx.act).view(B, -1, 8, d)
+            v = ops.linear(feats[lvl], ctx.w.lin[p + ".cross_attn.v"], out_dtype=ctx.act).view(B, -1, 8, d)
+            a = ops.attention(q, k, v, heads=8, head_dim=d, scale=d ** -0.5, mask=am, split3=ctx.split)
+            a = ops.linear(a, ctx.w.linear(p + ".cross_attn.out_proj"), out_dtype=torch.float32, residual=hs)
+            hs = ctx.ln(p + ".cross_attn_layer_norm", a, 1e-5, out_dtype=torch.float32)
+            # self-attention, DETR style (:782-912): pos added to q and k, v from hs
+            qin = ops.add(hs, qe)
+            qk = ops.linear(qin, ctx.w.merged(p + ".self_attn.qk", [p + ".self_attn.q_proj", p + ".self_attn.k_proj"]), out_dtype=ctx.act).view(B, Q, 2, 8, d)
+            v = ops.linear(hs, ctx.w.linear(p + ".self_attn.v_proj"), out_dtype=ctx.act).view(B, Q, 8, d)
+            a = ops.attention(qk[:, :, 0], qk[:, :, 1], v, heads=8, head_dim=d, scale=d ** -0.5, split3=ctx.split)
+            a = ops.linear(a, ctx.w.linear(p + ".self_attn.out_proj"), out_dtype=torch.float32, residual=hs)
+            hs = ctx.ln(p + ".self_attn_layer_norm", a, 1e-5, out_dtype=torch.float32)
+            f_ = ops.linear(hs, ctx.w.linear(p + ".fc1"), out_dtype=ctx.act, act=ACT_RELU)
+            f_ = ops.linear(f_, ctx.w.linear(p + ".fc2"), out_dtype=torch.float32, residual=hs)
+            hs = ctx.ln(p + ".final_layer_norm", f_, 1e-5, out_dtype=torch.float32)
+            inter = ctx.ln(dp + ".layernorm", hs, 1e-5, out_dtype=torch.float32)
+            m, am = self._mask_predictor(inter, mf_bt, sizes[(idx + 1) % 3])
+            masks.append(m)
+            inters.append(inter)
+        class_logits = ops.linear(inters[-1], ctx.w.linear("mask2former.class_predictor"), out_dtype=torch.float32)
+        return class_logits, masks[-1], masks, inters
+
+    def forward_nhwc(self, feats_nhwc: Sequence[torch.Tensor], B: int, T: int):
+        mask_features, ms = self._pixel_decoder(feats_nhwc)
+        class_logits, mask_cl, all_masks, inters = self._decoder(ms, mask_features, B, T)
+        out = VideoMask2FormerForVideoSegmentationOutput(
+            loss=None, class_queries_logits=class_logits,
+            masks_queries_logits=mask_cl.permute(0, 4, 1, 2, 3),  # [B,Q,T,h,w] view of the channel-last buffer
+            auxiliary_logits=None, attentions=None, word_embeddings=None,
+        )
+        out["_masks_channel_last"] = mask_cl
+        out["_mask_features"], out["_ms"] = mask_features, ms
+        return out
+
+    def forward(self, multi_scale_feat: List[torch.Tensor], word_embeddings=None, mask_labels=None, class_labels=None, **kw):
+        """reference signature (video_seg_decoder.py:2351-2361); multi_scale_feat: 4 x [B,T,C,h,w]."""
+        assert word_embeddings is None and mask_labels is None and class_labels is None, "inference path only"
+        B, T = multi_scale_feat[0].shape[:2]
+        feats = [f.flatten(0, 1).permute(0, 2, 3, 1).contiguous() for f in multi_scale_feat]
+        return self.forward_nhwc(feats, B, T)
+
+    __call__ = forward
+
+
+# ==================================================================================================
+# whole model (model.py:31-389)
+# ==================================================================================================
+class SIU3RModel:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], image_size=(512, 512), precision="bf16", device="cuda",
+                 num_queries=100, seg_threshold=0.5, label_ids_to_fuse=(0, 1), sh_degree=4):
+        if not torch.cuda.is_available():
+            raise RuntimeError("SIU3RModel (siu3r_amd) needs an MI355X GPU: there is no CPU fallback")
+        self.image_size = tuple(image_size)
+        self.precision = precision
+        self.seg_threshold, self.label_ids_to_fuse = seg_threshold, set(label_ids_to_fuse)
+        sd = {k[len("model."):] if k.startswith("model.") else k: v for k, v in state_dict.items()}
+        self._w = _Weights(sd, torch.device(device), precision == "bf16x3")
+        self._ctx = _Ctx(self._w, precision)
+        self.backbone = AsymmetricCroCo(self._ctx)
+        self.adapter = CroCoViTAdapter(self._ctx, image_size)
+        self.mask2former = VideoMask2FormerForVideoSegmentation(self._ctx, num_queries)
+        self.downstream_head1 = _DPTHead(self._ctx, "downstream_head1", gs=False)
+        self.downstream_head2 = _DPTHead(self._ctx, "downstream_head2", gs=False)
+        self.gaussian_param_head1 = _DPTHead(self._ctx, "gaussian_param_head1", gs=True)
+        self.gaussian_param_head2 = _DPTHead(self._ctx, "gaussian_param_head2", gs=True)
+        self.gaussian_adapter = UnifiedGaussianAdapter(sh_degree=sh_degree)
+        self.processor = pp.VideoMask2FormerImageProcessor()
+        self.raw_gs_dim = (sh_degree + 1) ** 2 * 3 + 3 + 4 + 1
+
+    def eval(self):
+        return self
+
+    def release_source_weights(self):
+        """Drop the fp32 source state dict once every layer has been packed (after the first forward)."""
+        self._w.sd = {k: v for k, v in self._w.sd.items() if False}
+
+    def forward(self, context_views_images, context_views_intrinsics, mask_labels=None, class_labels=None,
+                enable_query_class_logit_lift=False, return_intermediates=False):
+        """reference signature model.py:314-321."""
+        assert mask_labels is None and class_labels is None, "inference path only (training losses are out of scope)"
+        ctx = self._ctx
+        images = context_views_images.to(ctx.dev)
+        B, V, _, H, W = images.shape
+        (feat1, feat2, all_feat1, all_feat2, dec1, dec2, shape1, shape2, view1, view2) = self.backbone(
+            {"image": images, "intrinsics": context_views_intrinsics.to(ctx.dev), "near": 0.1, "far": 100}, return_views=True)
+        Z = B * V
+        img_bv = images.reshape(Z, 3, H, W).contiguous().float()
+        img8 = ops.pack_image_nhwc8(img_bv, ctx.act)
+        # the adapter is shared by both views (model.py:342-345): one (b,v)-batched pass
+        allf = [t.reshape(Z, t.shape[2], t.shape[3]) if t.is_contiguous() else t.flatten(0, 1) for t in self.backbone._all_feat_bv]
+        ms_nhwc = self.adapter.forward_nhwc(img_bv, img8, allf)
+        img8_bv = img8.view(B, V, H, W, 8)
+        res1 = self.downstream_head1.forward_pts3d(dec1, H, W)
+        res2 = self.downstream_head2.forward_pts3d(dec2, H, W)
+        gs1 = self.gaussian_param_head1.forward_gs(dec1, img8_bv[:, 0].contiguous(), H, W)
+        gs2 = self.gaussian_param_head2.forward_gs(dec2, img8_bv[:, 1].contiguous(), H, W)
+        means = torch.stack((res1["pts3d"].view(B, H * W, 3), res2["pts3d"].view(B, H * W, 3)), dim=1)
+        raw = torch.stack((gs1.view(B, H * W, -1), gs2.view(B, H * W, -1)), dim=1)
+        gaussians = self.gaussian_adapter.forward(means, raw)
+        seg_out = self.mask2former.forward_nhwc(ms_nhwc, B, V)
+        results = self.processor.post_process_panoptic_segmentation(
+            seg_out, threshold=self.seg_threshold, target_sizes=[(H, W)] * B, label_ids_to_fuse=self.label_ids_to_fuse)
+        gaussians, masks, infos, qcl, qscores = pp.post_process_gaussians(gaussians, results, B, V, H, W, enable_query_class_logit_lift)
+        if return_intermediates:
+            self._last = dict(dec1=dec1, dec2=dec2, all_feat1=all_feat1, all_feat2=all_feat2, ms=ms_nhwc, pts1=res1["pts3d"],
+                              pts2=res2["pts3d"], gs_raw1=gs1, gs_raw2=gs2, seg_out=seg_out)
+        if enable_query_class_logit_lift:
+            return gaussians, seg_out, masks, infos, qscores
+        return gaussians, seg_out, masks, infos
+
+    __call__ = forward

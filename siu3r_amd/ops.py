@@ -116,36 +116,63 @@ def _fill_common(p: GemmParams, a, pw: PackedWeight, out, act, residual, relu_in
         raise RuntimeError("bf16x3 weights need fp32 activations")
 
 
+def _rows_layout(t: torch.Tensor):
+    """Describe a [..., C] tensor (last dim contiguous) as Z batches of M rows: (Z, M, row_stride, batch_stride)."""
+    assert t.stride(-1) == 1
+    if t.dim() == 1:
+        return 1, 1, t.shape[0], 0
+    if t.dim() == 2:
+        return 1, t.shape[0], t.stride(0), 0
+    # collapse leading dims when they form a single row stride
+    shape, stride = t.shape[:-1], t.stride()[:-1]
+    ok = all(stride[i] == stride[i + 1] * shape[i + 1] for i in range(len(shape) - 1))
+    if ok:
+        m = 1
+        for s_ in shape:
+            m *= s_
+        return 1, m, stride[-1], 0
+    if t.dim() == 3:
+        return t.shape[0], t.shape[1], t.stride(1), t.stride(0)
+    # [Z, ..., C] with collapsible inner dims
+    inner_ok = all(stride[i] == stride[i + 1] * shape[i + 1] for i in range(1, len(shape) - 1))
+    if inner_ok:
+        m = 1
+        for s_ in shape[1:]:
+            m *= s_
+        return shape[0], m, stride[-1], stride[0]
+    raise RuntimeError(f"unsupported strided layout {tuple(t.shape)} / {tuple(t.stride())}")
+
+
 def linear(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=ACT_NONE,
            residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, relu_in=False):
-    """y[..., N] = act(x[..., K] @ W^T + b) (+ residual).  x may be a strided 2-D/3-D view whose last
-    dim is contiguous and whose leading dims collapse to one row stride (or [B, M, K] with a batch stride)."""
+    """y[..., N] = act(x[..., K] @ W^T + b) (+ residual).  x / out / residual may be strided views whose last
+    dim is contiguous and which decompose into Z batches of M rows (e.g. tokens[:, :-1])."""
     _gpu(x, residual, out)
-    K = x.shape[-1]
-    assert K == pw.k, (K, pw.k)
-    assert x.stride(-1) == 1
+    assert x.shape[-1] == pw.k, (x.shape, pw.k)
+    if out is None:
+        out = torch.empty((*x.shape[:-1], pw.n), dtype=out_dtype, device=x.device)
+    zx, mx, lda, sa = _rows_layout(x)
+    zo, mo, ldc, sc = _rows_layout(out)
+    layouts = [(zx, mx), (zo, mo)]
+    zr = mr = ldr = sr = 0
+    if residual is not None:
+        zr, mr, ldr, sr = _rows_layout(residual)
+        layouts.append((zr, mr))
+    Z = max(z for z, _ in layouts)
+    total = zx * mx
+    assert all(z * m == total for z, m in layouts), layouts
     p = GemmParams()
-    if x.dim() == 3 and not (x.stride(0) == x.shape[1] * x.stride(1)):
-        B, M = x.shape[0], x.shape[1]
-        if out is None:
-            out = torch.empty((B, M, pw.n), dtype=out_dtype, device=x.device)
-        _fill_common(p, x, pw, out, act, residual, relu_in)
-        p.m, p.lda, p.ldc = M, x.stride(1), out.stride(1)
-        p.batch, p.sa, p.sw, p.sc = B, x.stride(0), 0, out.stride(0)
-        if residual is not None:
-            p.ldr, p.sr = residual.stride(1), residual.stride(0)
+    _fill_common(p, x, pw, out, act, residual, relu_in)
+    if Z == 1:
+        p.m, p.lda, p.ldc, p.ldr = total, lda, ldc, ldr
     else:
-        lead = x.shape[:-1]
-        M = 1
-        for s in lead:
-            M *= s
-        lda = x.stride(-2) if x.dim() >= 2 else K
-        if out is None:
-            out = torch.empty((*lead, pw.n), dtype=out_dtype, device=x.device)
-        _fill_common(p, x, pw, out, act, residual, relu_in)
-        p.m, p.lda, p.ldc = M, lda, out.stride(-2) if out.dim() >= 2 else pw.n
-        if residual is not None:
-            p.ldr = residual.stride(-2) if residual.dim() >= 2 else pw.n
+        M = total // Z
+        def bs(z, m, ld, s):  # a collapsed operand is re-split into Z batches of M rows
+            return s if z == Z else M * ld
+        assert all(z in (1, Z) for z, _ in layouts)
+        p.m, p.lda, p.ldc, p.ldr = M, lda, ldc, ldr
+        p.batch, p.sa, p.sw, p.sc = Z, bs(zx, mx, lda, sa), 0, bs(zo, mo, ldc, sc)
+        p.sr = bs(zr, mr, ldr, sr) if residual is not None else 0
     _gemm_launch(p)
     return out
 

@@ -1,0 +1,104 @@
+"""End-to-end parity of the HIP SIU3R forward (through libsiu3r_hip.so) against the CPU oracle on the same
+seeded synthetic weights and inputs.
+
+Tolerances (documented in DESIGN.md):
+  precision="bf16x3": 1e-3 (north-star bar: "within 1e-3 rel on fp32"), metric = max|err| / max|ref| per tensor
+  precision="bf16"  : 6e-2 max-normalised / 3e-2 rel-L2 -- bf16 operands cannot meet 1e-3 (the reference itself
+                      moves by ~1e-2 under bf16 autocast); reported, not hidden.
+Integer outputs (segmentation / semantic / instance ids) must be bit-exact in both modes.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+_STATE = {}
+
+
+def _setup(H, W, B=1):
+    key = (H, W, B)
+    if key in _STATE:
+        return _STATE[key]
+    from oracle import siu3r_oracle as O
+    from oracle import weights as OW
+
+    if "sd" not in _STATE:
+        _STATE["sd"] = OW.make_weights(0)
+    sd = _STATE["sd"]
+    g = torch.Generator().manual_seed(7)
+    img = torch.rand(B, 2, 3, H, W, generator=g)
+    K = torch.tensor([[318 / 256, 0, 0.5], [0, 318 / 256, 0.5], [0, 0, 1]])[None, None].repeat(B, 2, 1, 1)
+    with torch.no_grad():
+        ref = O.model_forward(sd, img, K)
+    _STATE[key] = (sd, img, K, ref)
+    return _STATE[key]
+
+
+def _errs(got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    mx = ((got - ref).abs().max() / (ref.abs().max() + 1e-30)).item()
+    l2 = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+    return mx, l2
+
+
+def _report(name, got, ref, tol_max, tol_l2, fails):
+    mx, l2 = _errs(got, ref)
+    ok = math.isfinite(mx) and mx <= tol_max and l2 <= tol_l2
+    print(f"[model-parity] {name:34s} max_norm_err={mx:.3e} rel_l2={l2:.3e} {'ok' if ok else 'FAIL'}")
+    if not ok:
+        fails.append((name, mx, l2))
+
+
+def _run(precision, H, W, B=1):
+    from siu3r_amd.model import SIU3RModel
+
+    sd, img, K, ref = _setup(H, W, B)
+    model = SIU3RModel(sd, image_size=(H, W), precision=precision)
+    with torch.no_grad():
+        g, seg, masks, infos, qs = model(img.cuda(), K.cuda(), enable_query_class_logit_lift=True, return_intermediates=True)
+    torch.cuda.synchronize()
+    return model, (g, seg, masks, infos, qs), ref
+
+
+@pytest.mark.parametrize("precision,tol_max,tol_l2", [("bf16x3", 1e-3, 1e-3), ("bf16", 6e-2, 3e-2)])
+@pytest.mark.parametrize("size", [(128, 128), (256, 192)], ids=["128", "256x192"])
+def test_forward_parity(precision, tol_max, tol_l2, size):
+    H, W = size
+    model, (g, seg, masks, infos, qs), ref = _run(precision, H, W)
+    fails = []
+    last = model._last
+    bb = ref["bb"]
+    for i in (0, 5, 11, 23):
+        _report(f"enc_block{i}.view1", last["all_feat1"][i], bb["all_feat1"][i], tol_max, tol_l2, fails)
+    for i in (0, 1, 6, 12):
+        _report(f"dec1[{i}]", last["dec1"][i], bb["dec1"][i], tol_max, tol_l2, fails)
+        _report(f"dec2[{i}]", last["dec2"][i], bb["dec2"][i], tol_max, tol_l2, fails)
+    for lvl in range(4):
+        got = last["ms"][lvl].view(1, 2, *last["ms"][lvl].shape[1:])
+        _report(f"adapter.f{lvl+1}.view1", got[:, 0].permute(0, 3, 1, 2), ref["ms1"][lvl], tol_max, tol_l2, fails)
+        _report(f"adapter.f{lvl+1}.view2", got[:, 1].permute(0, 3, 1, 2), ref["ms2"][lvl], tol_max, tol_l2, fails)
+    _report("pts3d.view1", last["pts1"], ref["pts1"], tol_max, tol_l2, fails)
+    _report("pts3d.view2", last["pts2"], ref["pts2"], tol_max, tol_l2, fails)
+    _report("gs_raw.view1", last["gs_raw1"].flatten(1, 2), ref["gs_raw1"], tol_max, tol_l2, fails)
+    so = last["seg_out"]
+    _report("mask_features", so["_mask_features"].permute(0, 3, 1, 2), ref["mask_features"], tol_max, tol_l2, fails)
+    for i in range(3):
+        _report(f"pixel_decoder.ms{i}", so["_ms"][i].permute(0, 3, 1, 2), ref["ms"][i], tol_max, tol_l2, fails)
+    for f in ("means", "covariances", "harmonics", "opacities", "scales", "rotations"):
+        _report(f"gaussians.{f}", getattr(g, f), ref[f], tol_max, tol_l2, fails)
+    _report("class_queries_logits", seg.class_queries_logits, ref["class_queries_logits"], tol_max, tol_l2, fails)
+    _report("masks_queries_logits", seg.masks_queries_logits, ref["masks_queries_logits"], tol_max, tol_l2, fails)
+    # integer / structural outputs: bit-exact
+    assert torch.equal(g.semantic_labels.cpu(), ref["semantic_labels"]), "semantic labels differ"
+    assert torch.equal(g.instance_labels.cpu(), ref["instance_labels"]), "instance labels differ"
+    assert infos == ref["seg_infos"], (infos, ref["seg_infos"])
+    assert qs == ref["query_scores"]
+    for a, b in zip(masks, ref["seg_masks"]):
+        assert a.dtype == b.dtype and torch.equal(a.cpu(), b), "segmentation map differs"
+    for a, b in zip(g.seg_query_class_logits, ref["query_class_logits"]):
+        bb_ = b.permute(0, 3, 4, 1, 2).reshape(-1, b.shape[1], b.shape[2])
+        assert a.shape == bb_.shape and float((a.cpu() - bb_).abs().max()) <= 1e-5
+    assert not fails, f"parity failures: {fails}"
