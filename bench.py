@@ -1,0 +1,138 @@
+#!/usr/bin/env python
+"""SIU3R hot-path benchmark (driver contract: one JSON line on rank 0).
+
+A "step" is one pass of the hot path (SIU3RModel.forward incl. on-device panoptic post-process and
+query-class-logit lifting inputs) over one batch of synthetic image pairs at 2 x 512 x 512 (BASELINE.json
+configs[1]: single pair, ViT-L encoder/decoder + DPT 3DGS heads + ViT-Adapter/Mask2Former, bf16), with
+seeded synthetic weights of the reference architecture (no checkpoint is available offline) and inputs
+already resident in HBM.  value = image-pairs/s over all ranks (weak scaling: each rank runs its own pairs).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOPS_PER_PAIR_512 = 4059.0e9  # algorithmic 2*MAC of one pair @512^2 (torch flop counter on the reference)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="image pairs per step per GPU (configs[1] = 1)")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from siu3r_amd import distributed as D
+    from siu3r_amd import ops
+    from siu3r_amd.model import SIU3RModel
+    from oracle import weights as OW  # shared synthetic-weight generator (no checkpoint offline)
+
+    rank, local, world = D.init_from_env()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    H = W = args.size
+    B = args.batch
+
+    sd = OW.make_weights(0)
+    model = SIU3RModel(sd, image_size=(H, W), precision=args.precision, device=dev)
+    g = torch.Generator().manual_seed(1234 + rank)
+    images = torch.rand(B, 2, 3, H, W, generator=g).to(dev)
+    K = torch.tensor([[318 / 256, 0, 0.5], [0, 318 / 256, 0.5], [0, 0, 1]])[None, None].repeat(B, 2, 1, 1).to(dev)
+
+    def step():
+        with torch.no_grad():
+            return model(images, K, enable_query_class_logit_lift=True)
+
+    for _ in range(max(1, args.warmup)):
+        out = step()
+    model.release_source_weights()
+    del sd
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    dt = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+
+    # the path's single collective: per-rank additive statistics
+    gauss = out[0]
+    stats = dict(n_pairs=B * args.steps, n_images=2 * B * args.steps, n_gaussians=gauss.means.shape[1] * B,
+                 n_segments=sum(len(i) for i in out[3]), label_checksum=float(gauss.instance_labels.sum().item()))
+    gathered = D.all_gather_stats(D.pack_stats(stats), device=dev)
+    total = D.reduce_stats(gathered)
+
+    if rank != 0:
+        return
+    pairs = total["n_pairs"]
+    value = pairs / dt
+    result = {
+        "metric": "image-pairs/sec @2x512^2 (SIU3R network forward incl. panoptic post-process)",
+        "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (fp32 activations, 3-pass bf16 MFMA)",
+        "data": "synthetic (seeded uniform images, seeded synthetic weights of the reference architecture)",
+        "config": {"workload": f"configs[1]: single pair 2x{H}x{W} per step" if B == 1 else f"{B} pairs 2x{H}x{W} per step",
+                   "pairs_per_step_per_gpu": B, "image_size": [H, W], "precision": args.precision,
+                   "parallelism": f"dp{world} (independent pairs, one all-gather of metric statistics)"},
+        "network_tflops_algorithmic": value * FLOPS_PER_PAIR_512 * (H * W / (512 * 512)) / 1e12,
+    }
+
+    if not args.no_roofline:
+        timer = ops.KernelTimer()
+        ops.set_kernel_timer(timer)
+        step()
+        ops.set_kernel_timer(None)
+        summ = timer.summary()
+        dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        name, d = dom
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        result["roofline"] = {
+            "kernel": f"gemm_kernel ({name}; all Linear/Conv launches of one instrumented step after the timed region)",
+            "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+            "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+            "algorithmic_flops_per_launch_avg": d["flops"] / d["launches"],
+            "gemm_time_ms_per_step": d["ms"],
+            "all_variants": {k: {"launches": v["launches"], "ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()},
+        }
+
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import siu3r_oracle as O
+
+        torch.set_num_threads(os.cpu_count() or 1)
+        sd_cpu = OW.make_weights(0)
+        img_c, K_c = images[:1].cpu(), K[:1].cpu()
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            O.model_forward(sd_cpu, img_c, K_c, keep_intermediates=False)
+        t_cpu = time.perf_counter() - t1
+        result["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "image-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+                                  "sample": f"1 pair 2x{H}x{W}, fp32 oracle (oracle/siu3r_oracle.py, parity-pinned port of the reference), one forward = {t_cpu:.1f} s"}
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -99,8 +99,43 @@ def pack_conv_transpose(weight: torch.Tensor, bias, split) -> PackedWeight:
 # ------------------------------------------------------------------------------------------------
 # GEMM family
 # ------------------------------------------------------------------------------------------------
+class KernelTimer:
+    """Optional per-launch HIP-event timing of the MFMA GEMM kernel (bench.py's roofline leg).
+    Events are recorded on the stream the kernel is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []  # (variant, flops, ev0, ev1)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for variant, fl, e0, e1 in self.records:
+            d = out.setdefault(variant, dict(launches=0, flops=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += fl
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+_timer: Optional[KernelTimer] = None
+
+
+def set_kernel_timer(t: Optional[KernelTimer]):
+    global _timer
+    _timer = t
+
+
 def _gemm_launch(p: GemmParams):
+    if _timer is None:
+        check(_lib.lib().siu3r_gemm(C.byref(p), _stream()))
+        return
+    variant = "gemm_bf16x3" if p.w_lo else ("gemm_f32a" if p.a_dtype == F32 else "gemm_bf16")
+    flops = 2.0 * p.m * p.n * p.k * max(1, p.batch)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(_lib.lib().siu3r_gemm(C.byref(p), _stream()))
+    e1.record()
+    _timer.records.append((variant, flops, e0, e1))
 
 
 def _fill_common(p: GemmParams, a, pw: PackedWeight, out, act, residual, relu_in):
