@@ -81,6 +81,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime: import it first so that this library binds to the SAME runtime
+    # (two runtimes in one process -> "no ROCm-capable device is detected" on the second one)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m siu3r_amd.build` "

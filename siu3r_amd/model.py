@@ -373,7 +373,7 @@ class CroCoViTAdapter:
         c2 = ops.conv2d(c1, ctx.w.conv(sp + ".conv2.0", bn=sp + ".conv2.1"), stride=2, pad=1, out_dtype=ctx.act, act=ACT_RELU)
         c3 = ops.conv2d(c2, ctx.w.conv(sp + ".conv3.0", bn=sp + ".conv3.1"), stride=2, pad=1, out_dtype=ctx.act, act=ACT_RELU)
         c4 = ops.conv2d(c3, ctx.w.conv(sp + ".conv4.0", bn=sp + ".conv4.1"), stride=2, pad=1, out_dtype=ctx.act, act=ACT_RELU)
-        le = ctx.w.t("adapter.level_embed")
+        le = ctx.w.v("adapter.level_embed")
         n2, n3, n4 = 4 * h * w, h * w, h * w // 4
         cc = torch.empty((Z, n2 + n3 + n4, 1024), dtype=torch.float32, device=ctx.dev)
         c1 = ops.linear(c1, ctx.w.linear(sp + ".fc1"), out_dtype=torch.float32)  # [Z,4h,4w,1024]
@@ -538,7 +538,7 @@ class VideoMask2FormerForVideoSegmentation:
         if key not in ctx.cache:
             ctx.cache[key] = [_sine_pos_3d(T, a, b).contiguous().to(ctx.dev) for (a, b) in sizes]
         pos3 = ctx.cache[key]
-        le = ctx.w.t(tm + ".level_embed.weight")
+        le = ctx.w.v(tm + ".level_embed.weight")
         ones = ctx.cache.setdefault("ones256", torch.ones(256, device=ctx.dev))
         feats, keys_in = [], []
         for i in range(3):
@@ -547,8 +547,8 @@ class VideoMask2FormerForVideoSegmentation:
             feats.append(f_)
             keys_in.append(ops.add(f_, pos3[i]))
         Q = self.num_queries
-        qf = ctx.w.t(tm + ".queries_features.weight")
-        qe = ctx.w.t(tm + ".queries_embedder.weight").contiguous()
+        qf = ctx.w.v(tm + ".queries_features.weight")
+        qe = ctx.w.v(tm + ".queries_embedder.weight")
         hs = qf.unsqueeze(0).expand(B, -1, -1).contiguous()
         d = 32
         inter = ctx.ln(dp + ".layernorm", hs, 1e-5, out_dtype=torch.float32)
@@ -640,7 +640,7 @@ class SIU3RModel:
 
     def release_source_weights(self):
         """Drop the fp32 source state dict once every layer has been packed (after the first forward)."""
-        self._w.sd = {k: v for k, v in self._w.sd.items() if False}
+        self._w.sd = {k: v for k, v in self._w.sd.items() if v.numel() <= 65536}
 
     def forward(self, context_views_images, context_views_intrinsics, mask_labels=None, class_labels=None,
                 enable_query_class_logit_lift=False, return_intermediates=False):
