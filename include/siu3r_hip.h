@@ -63,6 +63,13 @@ typedef struct {
      (GS head: feat_up(path_1) + ReLU(conv7x7(img)), reference dpt_gs_head.py:160-162) */
   const void* up_src;     /* [B, oh/2, ow/2, n] or NULL */
   int32_t up_dtype;
+  /* fused RoPE2D epilogue (reference croco/blocks.py:101-103 + curope kernels.cu:17-82) for the QKV / projq /
+     projk GEMMs: output columns [0, rope_ncols) are heads of dim 64 laid out [u_Y v_Y u_X v_X]; row (z, m) is
+     the token with position rope_pos[(z*m_rows + m)*2 + {y,x}]; tables are fp32 [max_pos, 16]. NULL = off. */
+  const float* rope_cos;
+  const float* rope_sin;
+  const int64_t* rope_pos;
+  int32_t rope_ncols;
 } siu3r_gemm_params;
 int siu3r_gemm(const siu3r_gemm_params* p, void* stream);
 

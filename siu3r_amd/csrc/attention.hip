@@ -93,13 +93,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
   // D=64: thread -> (key = t>>2, chunk pair (c0, c0+2), c0 in {0,1,4,5});  D=32: (key = t>>2, chunk = t&3)
   const int ld_key = t >> 2;
   const int ld_c0 = (D == 64) ? ((t & 1) + 4 * ((t >> 1) & 1)) : (t & 3);
-  float kreg[CH][8], vreg[CH][8];
-  bool ld_ok = false;
+  struct KVRegs {
+    float k[CH][8], v[CH][8];
+  };
 
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, KVRegs& rg) {
+    float(&kreg)[CH][8] = rg.k;
+    float(&vreg)[CH][8] = rg.v;
     const int key = kt * KT + ld_key;
-    ld_ok = key < p.Nk;
-    if (ld_ok) {
+    if (key < p.Nk) {
       const unsigned char* kp = (const unsigned char*)p.k + ((int64_t)b * p.k_sb + (int64_t)key * p.k_sn + (int64_t)h * p.k_sh) * esz;
       const unsigned char* vp = (const unsigned char*)p.v + ((int64_t)b * p.v_sb + (int64_t)key * p.v_sn + (int64_t)h * p.v_sh) * esz;
 #pragma unroll
@@ -137,7 +139,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
     }
   };
 
-  auto store_tile = [&](int stage) {
+  auto store_tile = [&](int stage, const KVRegs& rg) {
+    const float(&kreg)[CH][8] = rg.k;
+    const float(&vreg)[CH][8] = rg.v;
     unsigned char* sK = smem + stage * STAGE;
     unsigned char* sV = sK + K_BYTES;
     unsigned char* sKl = sK + K_BYTES + V_BYTES;
@@ -174,13 +178,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
   const float sl2 = p.scale * 1.4426950408889634f;
   const int nkt = (p.Nk + KT - 1) / KT;
 
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1);
+  auto process = [&](int kt, int cur) {
     const unsigned char* sK = smem + cur * STAGE;
     const unsigned char* sV = sK + K_BYTES;
     const unsigned char* sKl = sK + K_BYTES + V_BYTES;
@@ -271,7 +269,23 @@ __global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, ph, oacc[dt], 0, 0, 0);
         }
       }
-    if (kt + 1 < nkt) store_tile(cur ^ 1);
+  };
+
+  // prefetch distance 2: two register sets alternate, LDS double buffer, one barrier per KV tile
+  KVRegs r0, r1;
+  load_tile(0, r0);
+  if (nkt > 1) load_tile(1, r1);
+  store_tile(0, r0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; kt += 2) {
+    if (kt + 2 < nkt) load_tile(kt + 2, r0);
+    process(kt, 0);
+    if (kt + 1 < nkt) store_tile(1, r1);
+    __syncthreads();
+    if (kt + 1 >= nkt) break;
+    if (kt + 3 < nkt) load_tile(kt + 3, r1);
+    process(kt + 1, 1);
+    if (kt + 2 < nkt) store_tile(0, r0);
     __syncthreads();
   }
 

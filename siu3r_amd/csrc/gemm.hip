@@ -1,11 +1,14 @@
 // MFMA GEMM / implicit-GEMM convolution for gfx950 (MI355X).
 //
 // C[M,N] = epilogue( A[M,K] x W[N,K]^T ), bf16 MFMA operands, fp32 accumulate.
-// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 tiles.
-// Operands are register-staged (global -> VGPR -> LDS) with the next K-tile's loads issued before
-// the current tile's MFMAs and a double-buffered, XOR-swizzled LDS image (one barrier per K-step).
+// Tile 128 x (64*NI) x 64, 256 threads = 4 waves (2x2), each wave 64 x 32*NI = 2 x NI
+// v_mfma_f32_32x32x16_bf16 tiles.  Operands are register-staged (global -> VGPR -> LDS) with a prefetch
+// distance of TWO K-tiles (two register sets, loads for tile k+2 are in flight while tile k is multiplied and
+// tile k+1 is written to LDS) and a double-buffered, XOR-swizzled LDS image (one barrier per K-step).
+// At batch 1 the SIU3R GEMMs have 50-550 tiles for 256 CUs, i.e. <= 1-2 workgroups per CU: the K-loop is
+// latency-bound, which is what the deep prefetch and the narrow NI=1 tile (2x the workgroups) address.
 // bf16x3 mode (SPLIT): A is fp32, split on the fly into hi+lo bf16; W carries a pre-split lo plane;
-// three MFMAs per product recover ~fp32 accuracy (fp32 residual of bf16 rounding is 2^-17 relative).
+// three MFMAs per product recover ~fp32 accuracy.
 //
 // A addressing modes: dense rows, NHWC implicit conv gather (any KHxKW/stride/pad, Cin % 8 == 0),
 // NCHW fp32 16x16 patchify (coalesced patch-embed im2col, reference croco/patch_embed.py:19-29).
@@ -13,19 +16,30 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand plane per stage
+constexpr int BM = 128, BK = 64;
+constexpr int A_TILE_BYTES = BM * BK * 2;  // 16 KiB
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   // row stride 128 B, 16-B chunks XOR-swizzled so that ds_read_b128 lane groups hit 16 distinct slots
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int A_F32, int SPLIT>
+template <int A_F32, int SPLIT, int NI>
+struct Regs {
+  float4 ra0[A_F32 ? 4 : 1], ra1[A_F32 ? 4 : 1];  // fp32 A: 8 floats per row-chunk
+  uint4 rab[A_F32 ? 1 : 4];                       // bf16 A
+  uint4 rwh[2 * NI], rwl[SPLIT ? 2 * NI : 1];
+};
+
+template <int A_F32, int SPLIT, int NI>
 __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
+  constexpr int BN = 64 * NI;
+  constexpr int B_TILE_BYTES = BN * BK * 2;
   constexpr int PLANES = SPLIT ? 2 : 1;
+  constexpr int STAGE_BYTES = PLANES * (A_TILE_BYTES + B_TILE_BYTES);
+  constexpr int WROWS = 2 * NI;  // weight rows per thread per K-tile
   // stage s: [A_hi | B_hi | (A_lo | B_lo)]
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * PLANES * TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -41,7 +55,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
   const u16* Wh = (const u16*)p.w_hi + (int64_t)z * p.sw;
   const u16* Wl = SPLIT ? (const u16*)p.w_lo + (int64_t)z * p.sw : nullptr;
 
-  // ---- per-thread load geometry: chunk (8 k-elements) x 4 rows
+  // ---- per-thread load geometry: chunk (8 k-elements) x 4 A rows, x WROWS weight rows
   const int chunk = t & 7, row0 = t >> 3;
   int64_t a_base[4];
   int a_iy0[4], a_ix0[4];
@@ -68,29 +82,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
       }
     }
   }
-  int64_t w_base[4];
-  bool w_ok[4];
+  int64_t w_base[WROWS];
+  bool w_ok[WROWS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < WROWS; ++i) {
     int n = tile_n * BN + row0 + 32 * i;
     w_ok[i] = n < p.n;
     w_base[i] = (int64_t)n * p.kpad + chunk * 8;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NI];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // register staging
-  float4 ra0[4], ra1[4];  // fp32 A: 8 floats per row-chunk
-  uint4 rab[4];           // bf16 A
-  uint4 rwh[4], rwl[4];
+  using R = Regs<A_F32, SPLIT, NI>;
 
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, R& rg) {
     const int k0 = kt * BK + chunk * 8;
     const bool k_ok = k0 < p.k;
     int ky = 0, kx = 0, c0 = 0;
@@ -117,44 +128,46 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
       } else {
         off = a_base[i] + koff;
       }
-      if (A_F32) {
+      if constexpr (A_F32) {
         if (ok) {
           const float4* q = (const float4*)(Ab + off * 4);
-          ra0[i] = q[0];
-          ra1[i] = q[1];
+          rg.ra0[i] = q[0];
+          rg.ra1[i] = q[1];
         } else {
-          ra0[i] = make_float4(0, 0, 0, 0);
-          ra1[i] = make_float4(0, 0, 0, 0);
+          rg.ra0[i] = make_float4(0, 0, 0, 0);
+          rg.ra1[i] = make_float4(0, 0, 0, 0);
         }
       } else {
-        rab[i] = ok ? *(const uint4*)(Ab + off * 2) : make_uint4(0, 0, 0, 0);
+        rg.rab[i] = ok ? *(const uint4*)(Ab + off * 2) : make_uint4(0, 0, 0, 0);
       }
+    }
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i) {
       if (w_ok[i]) {
-        rwh[i] = *(const uint4*)(Wh + w_base[i] + (int64_t)kt * BK);
-        if (SPLIT) rwl[i] = *(const uint4*)(Wl + w_base[i] + (int64_t)kt * BK);
+        rg.rwh[i] = *(const uint4*)(Wh + w_base[i] + (int64_t)kt * BK);
+        if constexpr (SPLIT) rg.rwl[i] = *(const uint4*)(Wl + w_base[i] + (int64_t)kt * BK);
       } else {
-        rwh[i] = make_uint4(0, 0, 0, 0);
-        if (SPLIT) rwl[i] = make_uint4(0, 0, 0, 0);
+        rg.rwh[i] = make_uint4(0, 0, 0, 0);
+        if constexpr (SPLIT) rg.rwl[i] = make_uint4(0, 0, 0, 0);
       }
     }
   };
 
-  auto store_tile = [&](int stage) {
-    unsigned char* sA = smem + stage * (2 * PLANES * TILE_BYTES);
-    unsigned char* sB = sA + TILE_BYTES;
-    unsigned char* sAl = sA + 2 * TILE_BYTES;
-    unsigned char* sBl = sA + 3 * TILE_BYTES;
+  auto store_tile = [&](int stage, const R& rg) {
+    unsigned char* sA = smem + stage * STAGE_BYTES;
+    unsigned char* sB = sA + A_TILE_BYTES;
+    unsigned char* sAl = sB + B_TILE_BYTES;
+    unsigned char* sBl = sAl + A_TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = row0 + 32 * i;
-      const int o = lds_off(r, chunk);
-      if (A_F32) {
-        float f[8] = {ra0[i].x, ra0[i].y, ra0[i].z, ra0[i].w, ra1[i].x, ra1[i].y, ra1[i].z, ra1[i].w};
+      const int o = lds_off(row0 + 32 * i, chunk);
+      if constexpr (A_F32) {
+        float f[8] = {rg.ra0[i].x, rg.ra0[i].y, rg.ra0[i].z, rg.ra0[i].w, rg.ra1[i].x, rg.ra1[i].y, rg.ra1[i].z, rg.ra1[i].w};
         if (p.relu_in) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
         }
-        if (SPLIT) {
+        if constexpr (SPLIT) {
           uint4 hi, lo;
           split_bf16x8(f, hi, lo);
           *(uint4*)(sA + o) = hi;
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
           *(uint4*)(sA + o) = pack_bf16x8(f);
         }
       } else {
-        uint4 v = rab[i];
+        uint4 v = rg.rab[i];
         if (p.relu_in) {
           uint32_t* w = (uint32_t*)&v;
 #pragma unroll
@@ -176,62 +189,77 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
         }
         *(uint4*)(sA + o) = v;
       }
-      *(uint4*)(sB + o) = rwh[i];
-      if (SPLIT) *(uint4*)(sBl + o) = rwl[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i) {
+      const int o = lds_off(row0 + 32 * i, chunk);
+      *(uint4*)(sB + o) = rg.rwh[i];
+      if constexpr (SPLIT) *(uint4*)(sBl + o) = rg.rwl[i];
     }
   };
 
-  const int nkt = p.kpad / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1);
-    const unsigned char* sA = smem + cur * (2 * PLANES * TILE_BYTES);
-    const unsigned char* sB = sA + TILE_BYTES;
-    const unsigned char* sAl = sA + 2 * TILE_BYTES;
-    const unsigned char* sBl = sA + 3 * TILE_BYTES;
+  auto compute = [&](int stage) {
+    const unsigned char* sA = smem + stage * STAGE_BYTES;
+    const unsigned char* sB = sA + A_TILE_BYTES;
+    const unsigned char* sAl = sB + B_TILE_BYTES;
+    const unsigned char* sBl = sAl + A_TILE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int c = ks * 2 + lh;
-      bf16x8 fa[2], fb[2], fal[2], fbl[2];
+      bf16x8 fa[2], fb[NI], fal[2], fbl[NI];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int ra = wm * 64 + i * 32 + l31;
-        const int rb = wn * 64 + i * 32 + l31;
         fa[i] = as_bf16x8(*(const uint4*)(sA + lds_off(ra, c)));
-        fb[i] = as_bf16x8(*(const uint4*)(sB + lds_off(rb, c)));
-        if (SPLIT) {
-          fal[i] = as_bf16x8(*(const uint4*)(sAl + lds_off(ra, c)));
-          fbl[i] = as_bf16x8(*(const uint4*)(sBl + lds_off(rb, c)));
-        }
+        if constexpr (SPLIT) fal[i] = as_bf16x8(*(const uint4*)(sAl + lds_off(ra, c)));
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int rb = wn * (32 * NI) + j * 32 + l31;
+        fb[j] = as_bf16x8(*(const uint4*)(sB + lds_off(rb, c)));
+        if constexpr (SPLIT) fbl[j] = as_bf16x8(*(const uint4*)(sBl + lds_off(rb, c)));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (SPLIT) {
+        for (int j = 0; j < NI; ++j) {
+          if constexpr (SPLIT) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fb[j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fbl[j], acc[i][j], 0, 0, 0);
           }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nkt) {
-      store_tile(cur ^ 1);
-    }
+  };
+
+  // ---- main loop: prefetch distance 2 (register sets r0/r1 alternate), LDS double buffer
+  const int nkt = p.kpad / BK;
+  R r0, r1;
+  load_tile(0, r0);
+  if (nkt > 1) load_tile(1, r1);
+  store_tile(0, r0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; kt += 2) {
+    // even step: tile kt is in LDS stage 0, tile kt+1 in r1; fetch tile kt+2 into r0
+    if (kt + 2 < nkt) load_tile(kt + 2, r0);
+    compute(0);
+    if (kt + 1 < nkt) store_tile(1, r1);
+    __syncthreads();
+    if (kt + 1 >= nkt) break;
+    // odd step: tile kt+1 is in LDS stage 1, tile kt+2 in r0; fetch tile kt+3 into r1
+    if (kt + 3 < nkt) load_tile(kt + 3, r1);
+    compute(1);
+    if (kt + 2 < nkt) store_tile(0, r0);
     __syncthreads();
   }
 
-  // ---- epilogue
+  // ---- epilogue (per 32x32 MFMA tile: gather residual / upsample terms first, then store)
   unsigned char* Cb = (unsigned char*)p.c;
   const unsigned char* Rb = (const unsigned char*)p.residual;
   const int64_t c_boff = (int64_t)z * p.sc, r_boff = (int64_t)z * p.sr;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = tile_n * BN + wn * 64 + j * 32 + l31;
+  for (int j = 0; j < NI; ++j) {
+    const int n = tile_n * BN + wn * (32 * NI) + j * 32 + l31;
     if (n >= p.n) continue;
     int co = n, kidx = 0;
     if (p.out_mode == 1) {
@@ -239,53 +267,96 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
       co = n - kidx * p.cout;
     }
     const float bv = p.bias ? p.bias[co] : 0.f;
+    // fused RoPE2D: column n is element d = n % 64 of a head [u_Y v_Y u_X v_X]; its rotation partner d +- 16
+    // lives in lane l31 ^ 16 of the same 32-column MFMA tile.  rope_ncols % 32 == 0 keeps this wave-uniform.
+    const bool do_rope = p.rope_cos != nullptr && (n - l31) < p.rope_ncols;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      if (do_rope) {
+        const int d = n & 63, axis = d >> 5, q = d & 15;
+        const bool upper = (d & 16) != 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = tile_m * BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= p.m) continue;
-        float v = acc[i][j][r] + bv;
-        if (p.act == 1)
-          v = gelu_erf(v);
-        else if (p.act == 2)
-          v = fmaxf(v, 0.f);
-        int64_t oidx;
-        if (p.out_mode == 0) {
-          oidx = (int64_t)m * p.ldc + n;
-        } else {
-          const int ihw = p.ih * p.iw;
-          const int b = m / ihw, rr = m - b * ihw;
-          const int iy = rr / p.iw, ix = rr - iy * p.iw;
-          const int ky = kidx / p.up, kx = kidx - ky * p.up;
-          oidx = (((int64_t)b * (p.ih * p.up) + iy * p.up + ky) * (p.iw * p.up) + ix * p.up + kx) * p.cout + co;
+        for (int r = 0; r < 16; ++r) {
+          int m = tile_m * BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m > p.m - 1) m = p.m - 1;
+          const int64_t pos = p.rope_pos[((int64_t)z * p.m + m) * 2 + axis];
+          const float c = p.rope_cos[pos * 16 + q], sn = p.rope_sin[pos * 16 + q];
+          const float v = acc[i][j][r] + bv;
+          const float pv = __shfl_xor(v, 16);
+          acc[i][j][r] = (upper ? (v * c + pv * sn) : (v * c - pv * sn)) - bv;  // bias is re-added below
         }
-        if (p.up_src) {
-          // + bilinear x2 (align_corners=True) sample of a low-res NHWC map with n channels
-          const int ohw = p.oh * p.ow;
-          const int b = m / ohw, rr = m - b * ohw;
-          const int oy = rr / p.ow, ox = rr - oy * p.ow;
-          const int sh = p.oh >> 1, sw = p.ow >> 1;
-          const float fy = (p.oh > 1) ? (float)(sh - 1) / (float)(p.oh - 1) * oy : 0.f;
-          const float fx = (p.ow > 1) ? (float)(sw - 1) / (float)(p.ow - 1) * ox : 0.f;
-          const int y0 = (int)fy, x0 = (int)fx;
-          const int y1 = y0 + (y0 < sh - 1 ? 1 : 0), x1 = x0 + (x0 < sw - 1 ? 1 : 0);
-          const float ly = fy - y0, lx = fx - x0;
-          const int64_t sb = (int64_t)b * sh * sw;
-          const float v00 = load_as_f32(p.up_src, p.up_dtype, (sb + (int64_t)y0 * sw + x0) * p.n + n);
-          const float v01 = load_as_f32(p.up_src, p.up_dtype, (sb + (int64_t)y0 * sw + x1) * p.n + n);
-          const float v10 = load_as_f32(p.up_src, p.up_dtype, (sb + (int64_t)y1 * sw + x0) * p.n + n);
-          const float v11 = load_as_f32(p.up_src, p.up_dtype, (sb + (int64_t)y1 * sw + x1) * p.n + n);
-          v += (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // 4 consecutive rows per group: gather extras first, then store
+        int64_t oidx[4];
+        float extra[4];
+#pragma unroll
+        for (int rr4 = 0; rr4 < 4; ++rr4) {
+          const int m = tile_m * BM + wm * 64 + i * 32 + rr4 + 8 * g + 4 * lh;
+          extra[rr4] = 0.f;
+          oidx[rr4] = -1;
+          if (m >= p.m) continue;
+          if (p.out_mode == 0) {
+            oidx[rr4] = (int64_t)m * p.ldc + n;
+          } else {
+            const int ihw = p.ih * p.iw;
+            const int b = m / ihw, rr = m - b * ihw;
+            const int iy = rr / p.iw, ix = rr - iy * p.iw;
+            const int ky = kidx / p.up, kx = kidx - ky * p.up;
+            oidx[rr4] = (((int64_t)b * (p.ih * p.up) + iy * p.up + ky) * (p.iw * p.up) + ix * p.up + kx) * p.cout + co;
+          }
+          if (p.up_src) {
+            // + bilinear x2 (align_corners=True) sample of a low-res NHWC map with n channels
+            const int ohw = p.oh * p.ow;
+            const int b = m / ohw, rr = m - b * ohw;
+            const int oy = rr / p.ow, ox = rr - oy * p.ow;
+            const int sh = p.oh >> 1, sw = p.ow >> 1;
+            const float fy = (p.oh > 1) ? (float)(sh - 1) / (float)(p.oh - 1) * oy : 0.f;
+            const float fx = (p.ow > 1) ? (float)(sw - 1) / (float)(p.ow - 1) * ox : 0.f;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < sh - 1 ? 1 : 0), x1 = x0 + (x0 < sw - 1 ? 1 : 0);
+            const float ly = fy - y0, lx = fx - x0;
+            const int64_t sb = (int64_t)b * sh * sw;
+            const float v00 = load_as_f32(p.up_src, p.up_dtype, (sb + (int64_t)y0 * sw + x0) * p.n + n);
+            const float v01 = load_as_f32(p.up_src, p.up_dtype, (sb + (int64_t)y0 * sw + x1) * p.n + n);
+            const float v10 = load_as_f32(p.up_src, p.up_dtype, (sb + (int64_t)y1 * sw + x0) * p.n + n);
+            const float v11 = load_as_f32(p.up_src, p.up_dtype, (sb + (int64_t)y1 * sw + x1) * p.n + n);
+            extra[rr4] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+          }
+          if (Rb) {
+            const int64_t ridx = (p.out_mode == 0) ? (int64_t)m * p.ldr + n : oidx[rr4];
+            extra[rr4] += load_as_f32(Rb, p.r_dtype, r_boff + ridx);
+          }
         }
-        if (Rb) {
-          const int64_t ridx = (p.out_mode == 0) ? (int64_t)m * p.ldr + n : oidx;
-          v += load_as_f32(Rb, p.r_dtype, r_boff + ridx);
+#pragma unroll
+        for (int rr4 = 0; rr4 < 4; ++rr4) {
+          if (oidx[rr4] < 0) continue;
+          float v = acc[i][j][4 * g + rr4] + bv;
+          if (p.act == 1)
+            v = gelu_erf(v);
+          else if (p.act == 2)
+            v = fmaxf(v, 0.f);
+          store_from_f32(Cb, p.c_dtype, c_boff + oidx[rr4], v + extra[rr4]);
         }
-        store_from_f32(Cb, p.c_dtype, c_boff + oidx, v);
       }
     }
   }
+}
+
+template <int NI>
+int launch(const siu3r_gemm_params& p, hipStream_t s) {
+  constexpr int BN = 64 * NI;
+  const int tiles = ((p.m + BM - 1) / BM) * ((p.n + BN - 1) / BN);
+  dim3 grid(tiles, 1, p.batch > 0 ? p.batch : 1), block(256);
+  if (p.w_lo) {
+    hipLaunchKernelGGL((gemm_kernel<1, 1, NI>), grid, block, 0, s, p);
+  } else if (p.a_dtype == SIU3R_F32) {
+    hipLaunchKernelGGL((gemm_kernel<1, 0, NI>), grid, block, 0, s, p);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<0, 0, NI>), grid, block, 0, s, p);
+  }
+  SIU3R_LAUNCH_CHECK("siu3r_gemm");
+  return 0;
 }
 
 }  // namespace
@@ -310,17 +381,12 @@ extern "C" int siu3r_gemm(const siu3r_gemm_params* pp, void* stream) {
                 "siu3r_gemm: patchify mode needs fp32 NCHW input, k=768, H,W multiples of 16");
   }
   if (p.out_mode == 1) SIU3R_CHECK(p.n == p.up * p.up * p.cout && p.m % (p.ih * p.iw) == 0, "siu3r_gemm: bad conv-transpose geometry");
+  if (p.rope_cos) SIU3R_CHECK(p.rope_sin && p.rope_pos && p.rope_ncols % 64 == 0 && p.rope_ncols <= p.n && p.act == 0 && p.out_mode == 0,
+                              "siu3r_gemm: bad RoPE epilogue arguments");
   if (p.up_src) SIU3R_CHECK(p.a_mode == 1 && p.out_mode == 0 && p.oh % 2 == 0 && p.ow % 2 == 0, "siu3r_gemm: up_src needs conv mode with even output size");
-  const int tiles = ((p.m + BM - 1) / BM) * ((p.n + BN - 1) / BN);
-  dim3 grid(tiles, 1, p.batch > 0 ? p.batch : 1), block(256);
+  // narrow tiles when 128x128 tiling would leave most of the 256 CUs without a workgroup, or N <= 64
+  const int64_t tiles128 = (int64_t)((p.m + BM - 1) / BM) * ((p.n + 127) / 128) * (p.batch > 0 ? p.batch : 1);
+  const bool narrow = (p.n <= 64) || (tiles128 < 384 && p.n > 64);
   hipStream_t s = (hipStream_t)stream;
-  if (p.w_lo) {
-    hipLaunchKernelGGL((gemm_kernel<1, 1>), grid, block, 0, s, p);
-  } else if (p.a_dtype == SIU3R_F32) {
-    hipLaunchKernelGGL((gemm_kernel<1, 0>), grid, block, 0, s, p);
-  } else {
-    hipLaunchKernelGGL((gemm_kernel<0, 0>), grid, block, 0, s, p);
-  }
-  SIU3R_LAUNCH_CHECK("siu3r_gemm");
-  return 0;
+  return narrow ? launch<1>(p, s) : launch<2>(p, s);
 }

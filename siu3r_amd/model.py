@@ -141,9 +141,10 @@ class AsymmetricCroCo:
         """Attention.forward (blocks.py:94-112) on normalised tokens xn [Z, N, C] -> pre-projection context."""
         ctx = self.ctx
         Z, N, Cc = xn.shape
-        qkv = ops.linear(xn, ctx.w.linear(p + ".qkv"), out_dtype=ctx.act).view(Z, N, 3, heads, Cc // heads)
+        # RoPE2D on q and k is fused into the QKV GEMM epilogue (columns [0, 2C) = q | k heads)
+        qkv = ops.linear(xn, ctx.w.linear(p + ".qkv"), out_dtype=ctx.act, rope=(rope[0], rope[1], pos, 2 * Cc)).view(Z, N, 3, heads, Cc // heads)
         return ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], heads=heads, head_dim=Cc // heads,
-                             scale=(Cc // heads) ** -0.5, rope=rope, qpos=pos, kpos=pos, split3=ctx.split)
+                             scale=(Cc // heads) ** -0.5, split3=ctx.split)
 
     def _mlp(self, p, x, ln_name):
         ctx = self.ctx
@@ -164,11 +165,11 @@ class AsymmetricCroCo:
         a = self._attn(p + ".attn", ctx.ln(p + ".norm1", x, 1e-6), xpos, rope, DEC_HEADS)
         x = ops.linear(a, ctx.w.linear(p + ".attn.proj"), out_dtype=torch.float32, residual=x)
         y_ = ctx.ln(p + ".norm_y", y, 1e-6)
-        q = ops.linear(ctx.ln(p + ".norm2", x, 1e-6), ctx.w.linear(p + ".cross_attn.projq"), out_dtype=ctx.act).view(B, N, DEC_HEADS, d)
+        q = ops.linear(ctx.ln(p + ".norm2", x, 1e-6), ctx.w.linear(p + ".cross_attn.projq"), out_dtype=ctx.act,
+                       rope=(rope[0], rope[1], xpos, Cc)).view(B, N, DEC_HEADS, d)
         kv = ops.linear(y_, ctx.w.merged(p + ".cross_attn.projkv", [p + ".cross_attn.projk", p + ".cross_attn.projv"]),
-                        out_dtype=ctx.act).view(B, N, 2, DEC_HEADS, d)
-        a = ops.attention(q, kv[:, :, 0], kv[:, :, 1], heads=DEC_HEADS, head_dim=d, scale=d ** -0.5, rope=rope,
-                          qpos=xpos, kpos=ypos, split3=ctx.split)
+                        out_dtype=ctx.act, rope=(rope[0], rope[1], ypos, Cc)).view(B, N, 2, DEC_HEADS, d)
+        a = ops.attention(q, kv[:, :, 0], kv[:, :, 1], heads=DEC_HEADS, head_dim=d, scale=d ** -0.5, split3=ctx.split)
         x = ops.linear(a, ctx.w.linear(p + ".cross_attn.proj"), out_dtype=torch.float32, residual=x)
         return self._mlp(p + ".mlp", x, p + ".norm3")
 

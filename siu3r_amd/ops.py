@@ -179,9 +179,11 @@ def _rows_layout(t: torch.Tensor):
 
 
 def linear(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=ACT_NONE,
-           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, relu_in=False):
+           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, relu_in=False,
+           rope=None):
     """y[..., N] = act(x[..., K] @ W^T + b) (+ residual).  x / out / residual may be strided views whose last
-    dim is contiguous and which decompose into Z batches of M rows (e.g. tokens[:, :-1])."""
+    dim is contiguous and which decompose into Z batches of M rows (e.g. tokens[:, :-1]).
+    rope = (cos, sin, positions int64 [rows, 2] contiguous, ncols): fused RoPE2D on output columns [0, ncols)."""
     _gpu(x, residual, out)
     assert x.shape[-1] == pw.k, (x.shape, pw.k)
     if out is None:
@@ -208,6 +210,10 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=AC
         p.m, p.lda, p.ldc, p.ldr = M, lda, ldc, ldr
         p.batch, p.sa, p.sw, p.sc = Z, bs(zx, mx, lda, sa), 0, bs(zo, mo, ldc, sc)
         p.sr = bs(zr, mr, ldr, sr) if residual is not None else 0
+    if rope is not None:
+        cos, sin, pos, ncols = rope
+        assert pos.dtype == torch.int64 and pos.is_contiguous() and pos.numel() == 2 * total and cos.shape[1] == 16
+        p.rope_cos, p.rope_sin, p.rope_pos, p.rope_ncols = _p(cos), _p(sin), _p(pos), ncols
     _gemm_launch(p)
     return out
 

@@ -62,6 +62,27 @@ def test_gemm_dense(mode):
 
 
 @pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
+def test_gemm_rope_epilogue(mode):
+    """QKV GEMM with RoPE2D fused on the q|k columns == linear followed by the oracle's rope2d."""
+    from oracle import siu3r_oracle as O
+
+    ops = _ops()
+    name, adt, split, tol = mode
+    B, N, H, D, K = 2, 37, 3, 64, 128
+    x = gen(B, N, K, seed=60)
+    w, b = gen(3 * H * D, K, seed=61, scale=0.3), gen(3 * H * D, seed=62)
+    pos = torch.randint(0, 20, (B, N, 2), generator=torch.Generator().manual_seed(5))
+    cos, sin = O.rope2d_table(20, D)
+    qkv = (x.to(adt).float() @ w.t() + b).view(B, N, 3, H, D)
+    q = O.rope2d(qkv[:, :, 0].permute(0, 2, 1, 3), pos).permute(0, 2, 1, 3)
+    k = O.rope2d(qkv[:, :, 1].permute(0, 2, 1, 3), pos).permute(0, 2, 1, 3)
+    ref = torch.stack((q, k, qkv[:, :, 2]), dim=2).reshape(B, N, 3 * H * D)
+    pw = ops.pack_linear(w.cuda(), b.cuda(), split)
+    out = ops.linear(x.cuda().to(adt), pw, out_dtype=torch.float32, rope=(cos.cuda(), sin.cuda(), pos.cuda(), 2 * H * D))
+    check(f"gemm_rope_epilogue[{name}]", out, ref, tol)
+
+
+@pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
 def test_gemm_batched_strided(mode):
     """tokens[:, :-1] view (strip the intrinsics token) feeding a 1x1 conv / linear."""
     ops = _ops()
