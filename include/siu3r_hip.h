@@ -70,6 +70,7 @@ typedef struct {
   const float* rope_sin;
   const int64_t* rope_pos;
   int32_t rope_ncols;
+  int32_t map_gx, map_rm, map_rn; /* filled by the launcher (XCD-aware tile map); callers leave them 0 */
 } siu3r_gemm_params;
 int siu3r_gemm(const siu3r_gemm_params* p, void* stream);
 

@@ -30,6 +30,7 @@ class GemmParams(C.Structure):
         ("out_mode", C.c_int32), ("up", C.c_int32), ("cout", C.c_int32),
         ("up_src", C.c_void_p), ("up_dtype", C.c_int32),
         ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("rope_pos", C.c_void_p), ("rope_ncols", C.c_int32),
+        ("map_gx", C.c_int32), ("map_rm", C.c_int32), ("map_rn", C.c_int32),
     ]
 
 

@@ -46,8 +46,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  const int tiles_n = (p.n + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+  // XCD-aware block -> tile map.  Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only):
+  // the tile grid is cut into gy x gx = 8 rectangular regions, one per XCD, and an XCD's workgroups walk its
+  // region row-major, so that the ~32 workgroups co-resident on an XCD form a compact patch that shares A-row
+  // and W-column panels in that XCD's private 4 MiB L2 instead of re-fetching them over the fabric.
+  const int tiles_m = (p.m + BM - 1) / BM, tiles_n = (p.n + BN - 1) / BN;
+  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+  const int ry = xcd / p.map_gx, rx = xcd - ry * p.map_gx;
+  const int lm = li / p.map_rn, ln = li - lm * p.map_rn;
+  const int tile_m = ry * p.map_rm + lm, tile_n = rx * p.map_rn + ln;
+  if (lm >= p.map_rm || tile_m >= tiles_m || tile_n >= tiles_n) return;
   const int z = blockIdx.z;
 
   const int esz_a = A_F32 ? 4 : 2;
@@ -344,9 +352,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
 }
 
 template <int NI>
-int launch(const siu3r_gemm_params& p, hipStream_t s) {
+int launch(const siu3r_gemm_params& pin, hipStream_t s) {
   constexpr int BN = 64 * NI;
-  const int tiles = ((p.m + BM - 1) / BM) * ((p.n + BN - 1) / BN);
+  siu3r_gemm_params p = pin;
+  const int tm = (p.m + BM - 1) / BM, tn = (p.n + BN - 1) / BN;
+  // choose the 8-region factorisation (gy x gx) with the smallest per-XCD operand footprint
+  int best = -1;
+  long best_cost = 0;
+  for (int gx = 1; gx <= 8; gx *= 2) {
+    const int gy = 8 / gx;
+    const int rm = (tm + gy - 1) / gy, rn = (tn + gx - 1) / gx;
+    const long cost = (long)rm * BM + (long)rn * BN + (long)rm * rn;  // last term: prefer fewer idle slots
+    if (best < 0 || cost < best_cost) {
+      best = gx;
+      best_cost = cost;
+    }
+  }
+  p.map_gx = best;
+  p.map_rm = (tm + (8 / best) - 1) / (8 / best);
+  p.map_rn = (tn + best - 1) / best;
+  const int tiles = 8 * p.map_rm * p.map_rn;
   dim3 grid(tiles, 1, p.batch > 0 ? p.batch : 1), block(256);
   if (p.w_lo) {
     hipLaunchKernelGGL((gemm_kernel<1, 1, NI>), grid, block, 0, s, p);
