@@ -12,7 +12,12 @@
 //
 // A addressing modes: dense rows, NHWC implicit conv gather (any KHxKW/stride/pad, Cin % 8 == 0),
 // NCHW fp32 16x16 patchify (coalesced patch-embed im2col, reference croco/patch_embed.py:19-29).
+#include <stdlib.h>
+
 #include "common.h"
+
+int siu3r_gemm_dma_launch(const siu3r_gemm_params& p, int ni, void* stream);  // gemm_dma.hip (bf16 LDS-DMA fast path)
+static const bool g_disable_dma = getenv("SIU3R_GEMM_NO_DMA") != nullptr;     // debugging / A-B switch
 
 namespace {
 
@@ -71,10 +76,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int m = tile_m * BM + row0 + 32 * i;
-    a_ok[i] = m < p.m;
+    a_ok[i] = true;  // rows beyond M are clamped to M-1: their products are never stored
+    if (m > p.m - 1) m = p.m - 1;
     a_iy0[i] = a_ix0[i] = 0;
     a_base[i] = 0;
-    if (!a_ok[i]) continue;
     if (p.a_mode == 0) {
       a_base[i] = (int64_t)m * p.lda;
     } else {
@@ -95,7 +100,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
 #pragma unroll
   for (int i = 0; i < WROWS; ++i) {
     int n = tile_n * BN + row0 + 32 * i;
-    w_ok[i] = n < p.n;
+    w_ok[i] = true;  // columns beyond N are clamped: never stored
+    if (n > p.n - 1) n = p.n - 1;
     w_base[i] = (int64_t)n * p.kpad + chunk * 8;
   }
 
@@ -125,39 +131,36 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      bool ok = a_ok[i] && k_ok;
-      int64_t off = 0;
+      // branch-free: out-of-range taps / K tail read a clamped (valid) address and are zeroed by a select,
+      // so the loads stay in one basic block and the compiler can keep them in flight with counted vmcnt
+      bool ok = k_ok;
+      int64_t off;
       if (p.a_mode == 0) {
-        off = a_base[i] + k0;
+        off = a_base[i] + (k_ok ? k0 : 0);
       } else if (p.a_mode == 1) {
         int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
         ok = ok && iy >= 0 && iy < p.ih && ix >= 0 && ix < p.iw;
-        off = a_base[i] + ((int64_t)iy * p.iw + ix) * p.cin + c0;
+        iy = min(max(iy, 0), p.ih - 1);
+        ix = min(max(ix, 0), p.iw - 1);
+        off = a_base[i] + ((int64_t)iy * p.iw + ix) * p.cin + (k_ok ? c0 : 0);
       } else {
-        off = a_base[i] + koff;
+        off = a_base[i] + (k_ok ? koff : 0);
       }
       if constexpr (A_F32) {
-        if (ok) {
-          const float4* q = (const float4*)(Ab + off * 4);
-          rg.ra0[i] = q[0];
-          rg.ra1[i] = q[1];
-        } else {
-          rg.ra0[i] = make_float4(0, 0, 0, 0);
-          rg.ra1[i] = make_float4(0, 0, 0, 0);
-        }
+        const float4* q = (const float4*)(Ab + off * 4);
+        const float4 v0 = q[0], v1 = q[1];
+        const float4 zz = make_float4(0, 0, 0, 0);
+        rg.ra0[i] = ok ? v0 : zz;
+        rg.ra1[i] = ok ? v1 : zz;
       } else {
-        rg.rab[i] = ok ? *(const uint4*)(Ab + off * 2) : make_uint4(0, 0, 0, 0);
+        const uint4 v = *(const uint4*)(Ab + off * 2);
+        rg.rab[i] = ok ? v : make_uint4(0, 0, 0, 0);
       }
     }
 #pragma unroll
     for (int i = 0; i < WROWS; ++i) {
-      if (w_ok[i]) {
-        rg.rwh[i] = *(const uint4*)(Wh + w_base[i] + (int64_t)kt * BK);
-        if constexpr (SPLIT) rg.rwl[i] = *(const uint4*)(Wl + w_base[i] + (int64_t)kt * BK);
-      } else {
-        rg.rwh[i] = make_uint4(0, 0, 0, 0);
-        if constexpr (SPLIT) rg.rwl[i] = make_uint4(0, 0, 0, 0);
-      }
+      rg.rwh[i] = *(const uint4*)(Wh + w_base[i] + (int64_t)kt * BK);
+      if constexpr (SPLIT) rg.rwl[i] = *(const uint4*)(Wl + w_base[i] + (int64_t)kt * BK);
     }
   };
 
@@ -373,6 +376,7 @@ int launch(const siu3r_gemm_params& pin, hipStream_t s) {
   p.map_rn = (tn + best - 1) / best;
   const int tiles = 8 * p.map_rm * p.map_rn;
   dim3 grid(tiles, 1, p.batch > 0 ? p.batch : 1), block(256);
+  if (!p.w_lo && p.a_dtype == SIU3R_BF16 && p.a_mode != 2 && !g_disable_dma) return siu3r_gemm_dma_launch(p, NI, s);
   if (p.w_lo) {
     hipLaunchKernelGGL((gemm_kernel<1, 1, NI>), grid, block, 0, s, p);
   } else if (p.a_dtype == SIU3R_F32) {
