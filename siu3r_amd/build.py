@@ -24,7 +24,7 @@ def _sources():
 
 def _digest(path):
     h = hashlib.sha1()
-    for f in [path, os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "siu3r_hip.h")]:
+    for f in [path, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(HERE, "..", "include", "siu3r_hip.h")]:
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())

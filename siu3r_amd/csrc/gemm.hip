@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm_epilogue.h"
 
 int siu3r_gemm_dma_launch(const siu3r_gemm_params& p, int ni, void* stream);  // gemm_dma.hip (bf16 LDS-DMA fast path)
 static const bool g_disable_dma = getenv("SIU3R_GEMM_NO_DMA") != nullptr;     // debugging / A-B switch
@@ -264,94 +265,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
     __syncthreads();
   }
 
-  // ---- epilogue (per 32x32 MFMA tile: gather residual / upsample terms first, then store)
-  unsigned char* Cb = (unsigned char*)p.c;
-  const unsigned char* Rb = (const unsigned char*)p.residual;
-  const int64_t c_boff = (int64_t)z * p.sc, r_boff = (int64_t)z * p.sr;
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int n = tile_n * BN + wn * (32 * NI) + j * 32 + l31;
-    if (n >= p.n) continue;
-    int co = n, kidx = 0;
-    if (p.out_mode == 1) {
-      kidx = n / p.cout;
-      co = n - kidx * p.cout;
-    }
-    const float bv = p.bias ? p.bias[co] : 0.f;
-    // fused RoPE2D: column n is element d = n % 64 of a head [u_Y v_Y u_X v_X]; its rotation partner d +- 16
-    // lives in lane l31 ^ 16 of the same 32-column MFMA tile.  rope_ncols % 32 == 0 keeps this wave-uniform.
-    const bool do_rope = p.rope_cos != nullptr && (n - l31) < p.rope_ncols;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (do_rope) {
-        const int d = n & 63, axis = d >> 5, q = d & 15;
-        const bool upper = (d & 16) != 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int m = tile_m * BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m > p.m - 1) m = p.m - 1;
-          const int64_t pos = p.rope_pos[((int64_t)z * p.m + m) * 2 + axis];
-          const float c = p.rope_cos[pos * 16 + q], sn = p.rope_sin[pos * 16 + q];
-          const float v = acc[i][j][r] + bv;
-          const float pv = __shfl_xor(v, 16);
-          acc[i][j][r] = (upper ? (v * c + pv * sn) : (v * c - pv * sn)) - bv;  // bias is re-added below
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {  // 4 consecutive rows per group: gather extras first, then store
-        int64_t oidx[4];
-        float extra[4];
-#pragma unroll
-        for (int rr4 = 0; rr4 < 4; ++rr4) {
-          const int m = tile_m * BM + wm * 64 + i * 32 + rr4 + 8 * g + 4 * lh;
-          extra[rr4] = 0.f;
-          oidx[rr4] = -1;
-          if (m >= p.m) continue;
-          if (p.out_mode == 0) {
-            oidx[rr4] = (int64_t)m * p.ldc + n;
-          } else {
-            const int ihw = p.ih * p.iw;
-            const int b = m / ihw, rr = m - b * ihw;
-            const int iy = rr / p.iw, ix = rr - iy * p.iw;
-            const int ky = kidx / p.up, kx = kidx - ky * p.up;
-            oidx[rr4] = (((int64_t)b * (p.ih * p.up) + iy * p.up + ky) * (p.iw * p.up) + ix * p.up + kx) * p.cout + co;
-          }
-          if (p.up_src) {
-            // + bilinear x2 (align_corners=True) sample of a low-res NHWC map with n channels
-            const int ohw = p.oh * p.ow;
-            const int b = m / ohw, rr = m - b * ohw;
-            const int oy = rr / p.ow, ox = rr - oy * p.ow;
-            const int sh = p.oh >> 1, sw = p.ow >> 1;
-            const float fy = (p.oh > 1) ? (float)(sh - 1) / (float)(p.oh - 1) * oy : 0.f;
-            const float fx = (p.ow > 1) ? (float)(sw - 1) / (float)(p.ow - 1) * ox : 0.f;
-            const int y0 = (int)fy, x0 = (int)fx;
-            const int y1 = y0 + (y0 < sh - 1 ? 1 : 0), x1 = x0 + (x0 < sw - 1 ? 1 : 0);
-            const float ly = fy - y0, lx = fx - x0;
-            const int64_t sb = (int64_t)b * sh * sw;
-            const float v00 = load_as_f32(p.up_src, p.up_dtype, (sb + (int64_t)y0 * sw + x0) * p.n + n);
-            const float v01 = load_as_f32(p.up_src, p.up_dtype, (sb + (int64_t)y0 * sw + x1) * p.n + n);
-            const float v10 = load_as_f32(p.up_src, p.up_dtype, (sb + (int64_t)y1 * sw + x0) * p.n + n);
-            const float v11 = load_as_f32(p.up_src, p.up_dtype, (sb + (int64_t)y1 * sw + x1) * p.n + n);
-            extra[rr4] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
-          }
-          if (Rb) {
-            const int64_t ridx = (p.out_mode == 0) ? (int64_t)m * p.ldr + n : oidx[rr4];
-            extra[rr4] += load_as_f32(Rb, p.r_dtype, r_boff + ridx);
-          }
-        }
-#pragma unroll
-        for (int rr4 = 0; rr4 < 4; ++rr4) {
-          if (oidx[rr4] < 0) continue;
-          float v = acc[i][j][4 * g + rr4] + bv;
-          if (p.act == 1)
-            v = gelu_erf(v);
-          else if (p.act == 2)
-            v = fmaxf(v, 0.f);
-          store_from_f32(Cb, p.c_dtype, c_boff + oidx[rr4], v + extra[rr4]);
-        }
-      }
-    }
-  }
+  // ---- epilogue: LDS-staged, row-wise vectorised (gemm_epilogue.h)
+  siu3r_epi::run<NI>(p, acc, smem, tile_m, tile_n, z, t);
 }
 
 template <int NI>
@@ -409,7 +324,7 @@ extern "C" int siu3r_gemm(const siu3r_gemm_params* pp, void* stream) {
     SIU3R_CHECK(p.a_dtype == SIU3R_F32 && p.k == 768 && p.ih == p.oh * 16 && p.iw == p.ow * 16,
                 "siu3r_gemm: patchify mode needs fp32 NCHW input, k=768, H,W multiples of 16");
   }
-  if (p.out_mode == 1) SIU3R_CHECK(p.n == p.up * p.up * p.cout && p.m % (p.ih * p.iw) == 0, "siu3r_gemm: bad conv-transpose geometry");
+  if (p.out_mode == 1) SIU3R_CHECK(p.n == p.up * p.up * p.cout && p.m % (p.ih * p.iw) == 0 && p.cout % 8 == 0, "siu3r_gemm: bad conv-transpose geometry (cout %% 8 == 0 required)");
   if (p.rope_cos) SIU3R_CHECK(p.rope_sin && p.rope_pos && p.rope_ncols % 64 == 0 && p.rope_ncols <= p.n && p.act == 0 && p.out_mode == 0,
                               "siu3r_gemm: bad RoPE epilogue arguments");
   if (p.up_src) SIU3R_CHECK(p.a_mode == 1 && p.out_mode == 0 && p.oh % 2 == 0 && p.ow % 2 == 0, "siu3r_gemm: up_src needs conv mode with even output size");

@@ -7,6 +7,7 @@
 // to the per-lane SOURCE address (cdna_hip_programming.md rule 21).  Zero padding (conv borders, K tail) points the
 // lane at a 16-byte zero page instead of branching.  Same tiles, MFMA layout and epilogue as gemm.hip.
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace siu3r_gemm_dma {
 
@@ -88,30 +89,33 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const siu3r_gemm_params p
     w_ptr[i] = Wb + (int64_t)n * p.kpad + c * 8;
   }
 
-  auto issue = [&](int kt, int stage) {
+  // one A piece (index i) and/or W pieces of K-tile kt into ring stage `stage`
+  auto issue_a = [&](int kt, int stage, int i) {
     unsigned char* sA = smem + stage * STAGE_BYTES;
-    unsigned char* sB = sA + A_TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_DMA; ++i) {
-      const u16* src;
-      const int k0 = kt * BK + a_c[i] * 8;
-      if (CONV) {
-        const int tap = k0 / p.cin, c0 = k0 - tap * p.cin;
-        const int ky = tap / p.kw, kx = tap - ky * p.kw;
-        const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-        const bool ok = k0 < p.k && iy >= 0 && iy < p.ih && ix >= 0 && ix < p.iw;
-        src = ok ? a_ptr[i] + ((int64_t)iy * p.iw + ix) * p.cin + c0 : zero;
-      } else {
-        src = k0 < p.k ? a_ptr[i] + kt * BK : zero;
-      }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sA + (wave * A_DMA + i) * 1024), 16, 0, 0);
+    const u16* src;
+    const int k0 = kt * BK + a_c[i] * 8;
+    if (CONV) {
+      const int tap = k0 / p.cin, c0 = k0 - tap * p.cin;
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+      const bool ok = k0 < p.k && iy >= 0 && iy < p.ih && ix >= 0 && ix < p.iw;
+      src = ok ? a_ptr[i] + ((int64_t)iy * p.iw + ix) * p.cin + c0 : zero;
+    } else {
+      src = k0 < p.k ? a_ptr[i] + kt * BK : zero;
     }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(sA + (wave * A_DMA + i) * 1024), 16, 0, 0);
+  };
+  auto issue_w = [&](int kt, int stage, int i) {
+    unsigned char* sB = smem + stage * STAGE_BYTES + A_TILE_BYTES;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[i] + kt * BK),
+                                     (__attribute__((address_space(3))) void*)(sB + (wave * W_DMA + i) * 1024), 16, 0, 0);
+  };
+  auto issue = [&](int kt, int stage) {
 #pragma unroll
-    for (int i = 0; i < W_DMA; ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[i] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(sB + (wave * W_DMA + i) * 1024), 16, 0, 0);
-    }
+    for (int i = 0; i < A_DMA; ++i) issue_a(kt, stage, i);
+#pragma unroll
+    for (int i = 0; i < W_DMA; ++i) issue_w(kt, stage, i);
   };
 
   f32x16 acc[2][NI];
@@ -137,63 +141,65 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const siu3r_gemm_params p
   const int swzB0 = ((wn * (32 * NI) + l31) >> 1) & 7;
   const unsigned int relu_mask = p.relu_in ? 0xffffffffu : 0u;
 
-  auto compute = [&](int stage) {
+  // K-tile body: fragment reads of k-substep ks+1 are issued before the MFMAs of ks, and the DMA pieces of the
+  // K-tile two ahead are spread over the four MFMA groups so that their issue cost hides under the matrix pipe.
+  // Only lgkmcnt(0) is used for the reads (a counted wait could be satisfied by an unrelated scalar load).
+  auto read_frags = [&](unsigned int sA, unsigned int sB, int ks, u32x4 (&fa)[2], u32x4 (&fb)[NI]) {
+    const int c = ks * 2 + lh;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned int ad = sA + offA[i] + ((c ^ swzA0) << 4);
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fa[i]) : "v"(ad) : "memory");
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const unsigned int ad = sB + offB[j] + ((c ^ swzB0) << 4);
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fb[j]) : "v"(ad) : "memory");
+    }
+  };
+  auto compute = [&](int stage, int kt_next, int stage_next) {
     const unsigned int sA = lds_base + stage * STAGE_BYTES;
     const unsigned int sB = sA + A_TILE_BYTES;
     u32x4 fa[4][2], fb[4][NI];
+    read_frags(sA, sB, 0, fa[0], fb[0]);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int c = ks * 2 + lh;
+      if (NI == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[ks][0]), "+v"(fa[ks][1]), "+v"(fb[ks][0]), "+v"(fb[ks][NI - 1])::"memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[ks][0]), "+v"(fa[ks][1]), "+v"(fb[ks][0])::"memory");
+      if (ks < 3) read_frags(sA, sB, ks + 1, fa[ks + 1], fb[ks + 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 a[2], bq[NI];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const unsigned int ad = sA + offA[i] + ((c ^ swzA0) << 4);
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[ks][i]) : "v"(ad) : "memory");
+        u32x4 v = fa[ks][i];
+        // fused input ReLU (ResidualConvUnit): clear negative bf16 halves, branch-free
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned int neg = (v[e] >> 15) & 0x00010001u;
+          v[e] &= ~((neg * 0xffffu) & relu_mask);
+        }
+        union { u32x4 u; bf16x8 h; } cv;
+        cv.u = v;
+        a[i] = cv.h;
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        const unsigned int ad = sB + offB[j] + ((c ^ swzB0) << 4);
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fb[ks][j]) : "v"(ad) : "memory");
+        union { u32x4 u; bf16x8 h; } cv;
+        cv.u = fb[ks][j];
+        bq[j] = cv.h;
       }
-    }
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      if (half == 0) {
-        if (NI == 2)
-          asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fb[0][0]), "+v"(fb[0][NI - 1]), "+v"(fb[1][0]), "+v"(fb[1][NI - 1])::"memory");
-        else
-          asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fb[0][0]), "+v"(fb[1][0])::"memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), "+v"(fb[2][0]), "+v"(fb[2][NI - 1]), "+v"(fb[3][0]), "+v"(fb[3][NI - 1])::"memory");
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
+      if (kt_next >= 0) {  // wave-uniform
+        issue_a(kt_next, stage_next, ks);
+        if (NI == 2) issue_w(kt_next, stage_next, ks);
+        else if (ks < 2) issue_w(kt_next, stage_next, ks);
       }
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int ks = half * 2 + kk;
-        bf16x8 a[2], bq[NI];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          u32x4 v = fa[ks][i];
-          // fused input ReLU (ResidualConvUnit): clear negative bf16 halves, branch-free
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const unsigned int neg = (v[e] >> 15) & 0x00010001u;
-            v[e] &= ~((neg * 0xffffu) & relu_mask);
-          }
-          union { u32x4 u; bf16x8 h; } cv;
-          cv.u = v;
-          a[i] = cv.h;
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          union { u32x4 u; bf16x8 h; } cv;
-          cv.u = fb[ks][j];
-          bq[j] = cv.h;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
-      }
     }
   };
 
@@ -212,101 +218,15 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const siu3r_gemm_params p
     }
     __builtin_amdgcn_s_barrier();  // every wave's pieces of tile kt are in LDS; stage (kt+2)%3 is no longer read
     asm volatile("" ::: "memory");
-    if (kt + 2 < nkt) {
-      int s2 = st + 2;
-      if (s2 >= STAGES) s2 -= STAGES;
-      issue(kt + 2, s2);
-    }
-    compute(st);
+    int s2 = st + 2;
+    if (s2 >= STAGES) s2 -= STAGES;
+    compute(st, kt + 2 < nkt ? kt + 2 : -1, s2);
     st = (st + 1 == STAGES) ? 0 : st + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // ---- epilogue (identical semantics to gemm.hip)
-  unsigned char* Cb = (unsigned char*)p.c;
-  const unsigned char* Rb = (const unsigned char*)p.residual;
-  const int64_t c_boff = (int64_t)z * p.sc, r_boff = (int64_t)z * p.sr;
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int n = tile_n * BN + wn * (32 * NI) + j * 32 + l31;
-    if (n >= p.n) continue;
-    int co = n, kidx = 0;
-    if (p.out_mode == 1) {
-      kidx = n / p.cout;
-      co = n - kidx * p.cout;
-    }
-    const float bv = p.bias ? p.bias[co] : 0.f;
-    const bool do_rope = p.rope_cos != nullptr && (n - l31) < p.rope_ncols;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (do_rope) {
-        const int d = n & 63, axis = d >> 5, q = d & 15;
-        const bool upper = (d & 16) != 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int m = tile_m * BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m > p.m - 1) m = p.m - 1;
-          const int64_t pos = p.rope_pos[((int64_t)z * p.m + m) * 2 + axis];
-          const float c = p.rope_cos[pos * 16 + q], sn = p.rope_sin[pos * 16 + q];
-          const float v = acc[i][j][r] + bv;
-          const float pv = __shfl_xor(v, 16);
-          acc[i][j][r] = (upper ? (v * c + pv * sn) : (v * c - pv * sn)) - bv;
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        int64_t oidx[4];
-        float extra[4];
-#pragma unroll
-        for (int rr4 = 0; rr4 < 4; ++rr4) {
-          const int m = tile_m * BM + wm * 64 + i * 32 + rr4 + 8 * g + 4 * lh;
-          extra[rr4] = 0.f;
-          oidx[rr4] = -1;
-          if (m >= p.m) continue;
-          if (p.out_mode == 0) {
-            oidx[rr4] = (int64_t)m * p.ldc + n;
-          } else {
-            const int ihw = p.ih * p.iw;
-            const int b = m / ihw, rr = m - b * ihw;
-            const int iy = rr / p.iw, ix = rr - iy * p.iw;
-            const int ky = kidx / p.up, kx = kidx - ky * p.up;
-            oidx[rr4] = (((int64_t)b * (p.ih * p.up) + iy * p.up + ky) * (p.iw * p.up) + ix * p.up + kx) * p.cout + co;
-          }
-          if (p.up_src) {
-            const int ohw = p.oh * p.ow;
-            const int b = m / ohw, rr = m - b * ohw;
-            const int oy = rr / p.ow, ox = rr - oy * p.ow;
-            const int sh = p.oh >> 1, sw = p.ow >> 1;
-            const float fy = (p.oh > 1) ? (float)(sh - 1) / (float)(p.oh - 1) * oy : 0.f;
-            const float fx = (p.ow > 1) ? (float)(sw - 1) / (float)(p.ow - 1) * ox : 0.f;
-            const int y0 = (int)fy, x0 = (int)fx;
-            const int y1 = y0 + (y0 < sh - 1 ? 1 : 0), x1 = x0 + (x0 < sw - 1 ? 1 : 0);
-            const float ly = fy - y0, lx = fx - x0;
-            const int64_t sb = (int64_t)b * sh * sw;
-            const float v00 = load_as_f32(p.up_src, p.up_dtype, (sb + (int64_t)y0 * sw + x0) * p.n + n);
-            const float v01 = load_as_f32(p.up_src, p.up_dtype, (sb + (int64_t)y0 * sw + x1) * p.n + n);
-            const float v10 = load_as_f32(p.up_src, p.up_dtype, (sb + (int64_t)y1 * sw + x0) * p.n + n);
-            const float v11 = load_as_f32(p.up_src, p.up_dtype, (sb + (int64_t)y1 * sw + x1) * p.n + n);
-            extra[rr4] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
-          }
-          if (Rb) {
-            const int64_t ridx = (p.out_mode == 0) ? (int64_t)m * p.ldr + n : oidx[rr4];
-            extra[rr4] += load_as_f32(Rb, p.r_dtype, r_boff + ridx);
-          }
-        }
-#pragma unroll
-        for (int rr4 = 0; rr4 < 4; ++rr4) {
-          if (oidx[rr4] < 0) continue;
-          float v = acc[i][j][4 * g + rr4] + bv;
-          if (p.act == 1)
-            v = gelu_erf(v);
-          else if (p.act == 2)
-            v = fmaxf(v, 0.f);
-          store_from_f32(Cb, p.c_dtype, c_boff + oidx[rr4], v + extra[rr4]);
-        }
-      }
-    }
-  }
+  // ---- epilogue: LDS-staged, row-wise vectorised (gemm_epilogue.h)
+  siu3r_epi::run<NI>(p, acc, smem, tile_m, tile_n, z, t);
 }
 
 }  // namespace siu3r_gemm_dma
