@@ -84,7 +84,7 @@ int siu3r_layernorm(const float* x, void* y, int y_dtype, const float* gamma, co
  * the Mask2Former decoder attentions (video_seg_decoder.py:782-912, nn.MultiheadAttention 946-983).
  * q,k,v: element strides (batch, token, head); head_dim contiguous.  out [B,Nq,H*D] contiguous.
  * rope_cos/sin: fp32 [max_pos, D/4] tables or NULL; qpos/kpos int64 [B,N,2] (y,x).
- * mask: uint8 [B,Nq,Nk] (1 = blocked), shared by all heads, or NULL. split3 = bf16x3 mode (fp32 io). */
+ * mask: uint8 [B,Nq,mask_ld] (1 = blocked; row stride mask_ld >= Nk, multiple of 64), shared by all heads, or NULL. split3 = bf16x3 mode (fp32 io). */
 typedef struct {
   const void *q, *k, *v;
   void* out;
@@ -97,6 +97,7 @@ typedef struct {
   const int64_t *qpos, *kpos;
   const uint8_t* mask;
   int32_t split3;
+  int64_t mask_ld;        /* bytes per mask row (>= Nk, multiple of 64; padding bytes are ignored) */
 } siu3r_attn_params;
 int siu3r_attention(const siu3r_attn_params* p, void* stream);
 
@@ -135,9 +136,10 @@ int siu3r_pts3d_exp(float* xyz, int64_t n, void* stream);
 int siu3r_gaussian_adapter(const void* raw, int raw_dtype, float* opacities, float* scales, float* rotations,
                            float* harmonics, float* covariances, int64_t n, void* stream);
 /* Mask2Former attention mask (video_seg_decoder.py:1461-1478 + 1306-1308): mask logits
- * [B,T,IH,IW,Q] (channel-last) -> uint8 [B,Q,T*OH*OW], 1 = blocked; rows fully blocked are cleared. */
+ * [B,T,IH,IW,Q] (channel-last) -> uint8 [B,Q,out_ld] (first T*OH*OW bytes of each row), 1 = blocked; rows fully
+ * blocked are cleared. */
 int siu3r_m2f_attn_mask(const float* mask_logits, uint8_t* out, int32_t* row_counts_ws, int B, int T, int IH,
-                        int IW, int OH, int OW, int Q, void* stream);
+                        int IW, int OH, int OW, int Q, int64_t out_ld, void* stream);
 
 /* fp32 [rows, k] (row stride ldx) -> bf16 hi plane [rows,kpad] (+ optional lo = bf16(x - hi)), zero padded:
  * weight / operand pre-packing for siu3r_gemm. */

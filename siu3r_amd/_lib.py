@@ -45,7 +45,7 @@ class AttnParams(C.Structure):
         ("scale", C.c_float),
         ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("rope_max_pos", C.c_int32),
         ("qpos", C.c_void_p), ("kpos", C.c_void_p), ("mask", C.c_void_p),
-        ("split3", C.c_int32),
+        ("split3", C.c_int32), ("mask_ld", C.c_int64),
     ]
 
 
@@ -68,7 +68,7 @@ SIGNATURES = {
     "siu3r_groupnorm": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "siu3r_pts3d_exp": [_P, _L, _P],
     "siu3r_gaussian_adapter": [_P, _I, _P, _P, _P, _P, _P, _L, _P],
-    "siu3r_m2f_attn_mask": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "siu3r_m2f_attn_mask": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "siu3r_split_bf16": [_P, _P, _P, _L, _I, _I, _L, _P],
     "siu3r_panoptic_stage1": [_P] * 20 + [_I] * 9 + [_F, _F, _F, C.c_uint32, _P],
     "siu3r_panoptic_qcl": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],

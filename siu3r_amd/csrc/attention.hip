@@ -24,7 +24,7 @@ __device__ __forceinline__ int k_off(int row, int chunk) {
   return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
 }
 
-template <int D, int IN_F32, int SPLIT>
+template <int D, int IN_F32, int SPLIT, int MASK>
 __global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
   constexpr int PL = SPLIT ? 2 : 1;
   constexpr int K_BYTES = KT * D * 2;
@@ -93,55 +93,71 @@ __global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
   // D=64: thread -> (key = t>>2, chunk pair (c0, c0+2), c0 in {0,1,4,5});  D=32: (key = t>>2, chunk = t&3)
   const int ld_key = t >> 2;
   const int ld_c0 = (D == 64) ? ((t & 1) + 4 * ((t >> 1) & 1)) : (t & 3);
+  // Raw staging registers: the global loads are consumed only at LDS-store time (one tile later), so no wait is
+  // forced at the load site and two tiles stay in flight.  RoPE (when requested here rather than in the producing
+  // GEMM's epilogue) is applied at store time with the positions fetched alongside.
   struct KVRegs {
-    float k[CH][8], v[CH][8];
+    uint4 kb[IN_F32 ? 2 * CH : CH], vb[IN_F32 ? 2 * CH : CH];
+    int pos;
+    bool ok;
   };
 
   auto load_tile = [&](int kt, KVRegs& rg) {
-    float(&kreg)[CH][8] = rg.k;
-    float(&vreg)[CH][8] = rg.v;
-    const int key = kt * KT + ld_key;
-    if (key < p.Nk) {
-      const unsigned char* kp = (const unsigned char*)p.k + ((int64_t)b * p.k_sb + (int64_t)key * p.k_sn + (int64_t)h * p.k_sh) * esz;
-      const unsigned char* vp = (const unsigned char*)p.v + ((int64_t)b * p.v_sb + (int64_t)key * p.v_sn + (int64_t)h * p.v_sh) * esz;
+    int key = kt * KT + ld_key;
+    rg.ok = key < p.Nk;
+    if (key > p.Nk - 1) key = p.Nk - 1;  // clamped address, zeroed at store time (branch-free loads)
+    const unsigned char* kp = (const unsigned char*)p.k + ((int64_t)b * p.k_sb + (int64_t)key * p.k_sn + (int64_t)h * p.k_sh) * esz;
+    const unsigned char* vp = (const unsigned char*)p.v + ((int64_t)b * p.v_sb + (int64_t)key * p.v_sn + (int64_t)h * p.v_sh) * esz;
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const int ch = ld_c0 + 2 * c;
-        f32x8 a = load8_as_f32(kp, IN_F32 ? SIU3R_F32 : SIU3R_BF16, ch * 8);
-        f32x8 bb = load8_as_f32(vp, IN_F32 ? SIU3R_F32 : SIU3R_BF16, ch * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          kreg[c][j] = a.v[j];
-          vreg[c][j] = bb.v[j];
-        }
+    for (int c = 0; c < CH; ++c) {
+      const int ch = ld_c0 + 2 * c;
+      if constexpr (IN_F32) {
+        rg.kb[2 * c] = *(const uint4*)(kp + ch * 32);
+        rg.kb[2 * c + 1] = *(const uint4*)(kp + ch * 32 + 16);
+        rg.vb[2 * c] = *(const uint4*)(vp + ch * 32);
+        rg.vb[2 * c + 1] = *(const uint4*)(vp + ch * 32 + 16);
+      } else {
+        rg.kb[c] = *(const uint4*)(kp + ch * 16);
+        rg.vb[c] = *(const uint4*)(vp + ch * 16);
       }
-      if (rope && D == 64) {
-        const int ax = ld_c0 >> 2;
-        const int pos = (int)p.kpos[((int64_t)b * p.Nk + key) * 2 + ax];
-        const float* cs = p.rope_cos + (int64_t)pos * Q4 + (ld_c0 & 1) * 8;
-        const float* sn = p.rope_sin + (int64_t)pos * Q4 + (ld_c0 & 1) * 8;
+    }
+    rg.pos = 0;
+    if (rope && D == 64) rg.pos = (int)p.kpos[((int64_t)b * p.Nk + key) * 2 + (ld_c0 >> 2)];
+  };
+
+  auto unpack = [&](const uint4* raw, int c, float (&f)[8], bool ok) {
+    if constexpr (IN_F32) {
+      const float* a = (const float*)&raw[2 * c];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float c = cs[j], s = sn[j];
-          const float u = kreg[0][j], v = kreg[CH - 1][j];
-          kreg[0][j] = u * c - v * s;
-          kreg[CH - 1][j] = v * c + u * s;
-        }
-      }
+      for (int j = 0; j < 8; ++j) f[j] = ok ? a[j] : 0.f;
     } else {
+      const uint32_t* w = (const uint32_t*)&raw[c];
 #pragma unroll
-      for (int c = 0; c < CH; ++c)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          kreg[c][j] = 0.f;
-          vreg[c][j] = 0.f;
-        }
+      for (int j = 0; j < 4; ++j) {
+        f[2 * j] = ok ? bf16_bits_to_f32((u16)(w[j] & 0xffff)) : 0.f;
+        f[2 * j + 1] = ok ? bf16_bits_to_f32((u16)(w[j] >> 16)) : 0.f;
+      }
     }
   };
 
   auto store_tile = [&](int stage, const KVRegs& rg) {
-    const float(&kreg)[CH][8] = rg.k;
-    const float(&vreg)[CH][8] = rg.v;
+    float kreg[CH][8], vreg[CH][8];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      unpack(rg.kb, c, kreg[c], rg.ok);
+      unpack(rg.vb, c, vreg[c], rg.ok);
+    }
+    if (rope && D == 64) {
+      const float* cs = p.rope_cos + (int64_t)rg.pos * Q4 + (ld_c0 & 1) * 8;
+      const float* sn = p.rope_sin + (int64_t)rg.pos * Q4 + (ld_c0 & 1) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float c = cs[j], s2 = sn[j];
+        const float u = kreg[0][j], v = kreg[CH - 1][j];
+        kreg[0][j] = u * c - v * s2;
+        kreg[CH - 1][j] = v * c + u * s2;
+      }
+    }
     unsigned char* sK = smem + stage * STAGE;
     unsigned char* sV = sK + K_BYTES;
     unsigned char* sKl = sK + K_BYTES + V_BYTES;
@@ -178,7 +194,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
   const float sl2 = p.scale * 1.4426950408889634f;
   const int nkt = (p.Nk + KT - 1) / KT;
 
-  auto process = [&](int kt, int cur) {
+  // key mask (Mask2Former): the 64 mask bytes of this lane's query row for one KV tile, as 4 x 16-B loads that are
+  // issued one tile ahead; rows beyond Nq read a clamped row (never stored).  Requires Nk % 64 == 0.
+  const uint8_t* mrow = nullptr;
+  if constexpr (MASK) mrow = p.mask + ((int64_t)b * p.Nq + (q_ok ? q_row : p.Nq - 1)) * p.mask_ld;
+  auto load_mask = [&](int kt, uint4 (&mk)[4]) {
+    if constexpr (MASK) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mk[i] = *(const uint4*)(mrow + (int64_t)kt * KT + 16 * i);
+    }
+  };
+
+  auto process = [&](int kt, int cur, const uint4 (&mk)[4]) {
     const unsigned char* sK = smem + cur * STAGE;
     const unsigned char* sV = sK + K_BYTES;
     const unsigned char* sKl = sK + K_BYTES + V_BYTES;
@@ -204,14 +231,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
     }
     // scale, key-validity and mask; lane holds keys key(kb,r) = kt*64 + kb*32 + (r&3) + 8*(r>>2) + 4*lh
     float mx = NEG_BIG;
-    const uint8_t* mrow = (p.mask && q_ok) ? p.mask + ((int64_t)b * p.Nq + q_row) * p.Nk : nullptr;
+    // this lane's keys sit in dwords {lh, 2+lh, ...} of the 16 mask dwords: select even/odd once, index statically
+    uint32_t wsel[8];
+    if constexpr (MASK) {
+      const uint32_t* w = (const uint32_t*)&mk[0];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wsel[i] = lh ? w[2 * i + 1] : w[2 * i];
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kt * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         bool ok = key < p.Nk;
-        if (ok && mrow) ok = mrow[key] == 0;
+        if constexpr (MASK) ok = ok && ((wsel[kb * 4 + (r >> 2)] >> (8 * (r & 3))) & 0xffu) == 0;
         const float s = ok ? sacc[kb][r] * sl2 : NEG_BIG;
         sacc[kb][r] = s;
         mx = fmaxf(mx, s);
@@ -273,18 +306,22 @@ __global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
 
   // prefetch distance 2: two register sets alternate, LDS double buffer, one barrier per KV tile
   KVRegs r0, r1;
+  uint4 mA[4], mB[4];
   load_tile(0, r0);
+  load_mask(0, mA);
   if (nkt > 1) load_tile(1, r1);
   store_tile(0, r0);
   __syncthreads();
   for (int kt = 0; kt < nkt; kt += 2) {
     if (kt + 2 < nkt) load_tile(kt + 2, r0);
-    process(kt, 0);
+    if (kt + 1 < nkt) load_mask(kt + 1, mB);
+    process(kt, 0, mA);
     if (kt + 1 < nkt) store_tile(1, r1);
     __syncthreads();
     if (kt + 1 >= nkt) break;
     if (kt + 3 < nkt) load_tile(kt + 3, r1);
-    process(kt + 1, 1);
+    if (kt + 2 < nkt) load_mask(kt + 2, mA);
+    process(kt + 1, 1, mB);
     if (kt + 2 < nkt) store_tile(0, r0);
     __syncthreads();
   }
@@ -316,7 +353,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
 template <int D, int IN_F32, int SPLIT>
 int launch(const siu3r_attn_params& p, hipStream_t s) {
   dim3 grid((p.Nq + 127) / 128, p.H, p.B), block(256);
-  hipLaunchKernelGGL((attn_kernel<D, IN_F32, SPLIT>), grid, block, 0, s, p);
+  if (p.mask)
+    hipLaunchKernelGGL((attn_kernel<D, IN_F32, SPLIT, 1>), grid, block, 0, s, p);
+  else
+    hipLaunchKernelGGL((attn_kernel<D, IN_F32, SPLIT, 0>), grid, block, 0, s, p);
   SIU3R_LAUNCH_CHECK("siu3r_attention");
   return 0;
 }
@@ -330,6 +370,8 @@ extern "C" int siu3r_attention(const siu3r_attn_params* pp, void* stream) {
   SIU3R_CHECK(p.B > 0 && p.H > 0 && p.Nq > 0 && p.Nk > 0, "siu3r_attention: empty problem");
   SIU3R_CHECK(p.dtype == SIU3R_BF16 || p.dtype == SIU3R_F32, "siu3r_attention: bad dtype %d", p.dtype);
   SIU3R_CHECK(!(p.split3 && p.dtype != SIU3R_F32), "siu3r_attention: bf16x3 mode needs fp32 tensors");
+  SIU3R_CHECK(!(p.mask && (p.mask_ld % 64 != 0 || p.mask_ld < p.Nk || ((uintptr_t)p.mask & 15) != 0)),
+              "siu3r_attention: the key mask needs a 16-byte aligned buffer with row stride mask_ld %% 64 == 0 and >= Nk (mask_ld=%ld Nk=%d)", (long)p.mask_ld, p.Nk);
   SIU3R_CHECK(!(p.rope_cos && p.D != 64), "siu3r_attention: RoPE2D path is specialised for head_dim 64");
   SIU3R_CHECK(!(p.rope_cos && !(p.rope_sin && p.qpos && p.kpos)), "siu3r_attention: rope tables/positions missing");
   const int64_t al = p.dtype == SIU3R_F32 ? 4 : 8;  // 16-byte vector loads

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(128) void gaussian_adapter_kernel(const void* raw, 
 
 // ================================ Mask2Former attention mask ====================================
 __global__ void m2f_mask_kernel(const float* ml, uint8_t* out, int32_t* row_counts, int B, int T, int IH, int IW,
-                                int OH, int OW, int Q) {
+                                int OH, int OW, int Q, int64_t ld) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)B * T * OH * OW * Q;
   if (idx >= total) return;
@@ -514,14 +514,14 @@ __global__ void m2f_mask_kernel(const float* ml, uint8_t* out, int32_t* row_coun
   const float sg = 1.f / (1.f + expf(-v));
   const uint8_t blocked = sg < 0.5f ? 1 : 0;
   const int64_t nk = (int64_t)T * OH * OW;
-  out[((int64_t)b * Q + q) * nk + ((int64_t)t * OH + oy) * OW + ox] = blocked;
+  out[((int64_t)b * Q + q) * ld + ((int64_t)t * OH + oy) * OW + ox] = blocked;
   if (blocked) atomicAdd(&row_counts[b * Q + q], 1);
 }
-__global__ void m2f_mask_fix_kernel(uint8_t* out, const int32_t* row_counts, int64_t rows, int64_t nk) {
+__global__ void m2f_mask_fix_kernel(uint8_t* out, const int32_t* row_counts, int64_t rows, int64_t nk, int64_t ld) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * nk) return;
   const int64_t r = idx / nk;
-  if (row_counts[r] == nk) out[idx] = 0;
+  if (row_counts[r] == nk) out[r * ld + (idx - r * nk)] = 0;
 }
 
 // ================================ fp32 -> bf16 hi (+lo) planes, K zero-padded ====================
@@ -681,16 +681,17 @@ extern "C" int siu3r_gaussian_adapter(const void* raw, int raw_dtype, float* opa
 }
 
 extern "C" int siu3r_m2f_attn_mask(const float* mask_logits, uint8_t* out, int32_t* row_counts_ws, int B, int T,
-                                   int IH, int IW, int OH, int OW, int Q, void* stream) {
+                                   int IH, int IW, int OH, int OW, int Q, int64_t out_ld, void* stream) {
   SIU3R_CHECK(mask_logits && out && row_counts_ws, "m2f_attn_mask: null pointer");
+  SIU3R_CHECK(out_ld >= (int64_t)T * OH * OW, "m2f_attn_mask: out_ld too small");
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(row_counts_ws, 0, sizeof(int32_t) * B * Q, s) != hipSuccess) {
     siu3r_set_error("m2f_attn_mask: memset failed");
     return 2;
   }
   const int64_t nk = (int64_t)T * OH * OW;
-  hipLaunchKernelGGL(m2f_mask_kernel, grid1d((int64_t)B * nk * Q), dim3(256), 0, s, mask_logits, out, row_counts_ws, B, T, IH, IW, OH, OW, Q);
-  hipLaunchKernelGGL(m2f_mask_fix_kernel, grid1d((int64_t)B * Q * nk), dim3(256), 0, s, out, row_counts_ws, (int64_t)B * Q, nk);
+  hipLaunchKernelGGL(m2f_mask_kernel, grid1d((int64_t)B * nk * Q), dim3(256), 0, s, mask_logits, out, row_counts_ws, B, T, IH, IW, OH, OW, Q, out_ld);
+  hipLaunchKernelGGL(m2f_mask_fix_kernel, grid1d((int64_t)B * Q * nk), dim3(256), 0, s, out, row_counts_ws, (int64_t)B * Q, nk, out_ld);
   SIU3R_LAUNCH_CHECK("siu3r_m2f_attn_mask");
   return 0;
 }

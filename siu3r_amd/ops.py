@@ -316,9 +316,9 @@ def attention(q, k, v, *, heads: int, head_dim: int, scale: float, rope=None, qp
         p.rope_cos, p.rope_sin, p.rope_max_pos = _p(cos), _p(sin), cos.shape[0]
         assert qpos.dtype == torch.int64 and kpos.dtype == torch.int64 and qpos.is_contiguous() and kpos.is_contiguous()
         p.qpos, p.kpos = _p(qpos), _p(kpos)
-    if mask is not None:
-        assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.shape == (B, Nq, Nk)
-        p.mask = _p(mask)
+    if mask is not None:  # [B, Nq, ld] uint8, ld >= Nk and a multiple of 64 (padding ignored)
+        assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.shape[:2] == (B, Nq) and mask.shape[2] >= Nk
+        p.mask, p.mask_ld = _p(mask), mask.shape[2]
     p.split3 = int(split3)
     check(_lib.lib().siu3r_attention(C.byref(p), _stream()))
     return out
@@ -457,14 +457,16 @@ def gaussian_adapter(raw: torch.Tensor):
 
 
 def m2f_attn_mask(mask_logits: torch.Tensor, size):
-    """mask logits [B,T,IH,IW,Q] fp32 -> uint8 [B,Q,T*OH*OW] (1 = blocked, fully blocked rows cleared)."""
+    """mask logits [B,T,IH,IW,Q] fp32 -> uint8 [B,Q,ld] with ld = T*OH*OW rounded up to 64 (1 = blocked, fully blocked
+    rows cleared; the padding bytes are never read as keys)."""
     _gpu(mask_logits)
     assert mask_logits.is_contiguous() and mask_logits.dtype == torch.float32
     B, T, IH, IW, Q = mask_logits.shape
     OH, OW = size
-    out = torch.empty((B, Q, T * OH * OW), dtype=torch.uint8, device=mask_logits.device)
+    ld = ((T * OH * OW + 63) // 64) * 64
+    out = torch.empty((B, Q, ld), dtype=torch.uint8, device=mask_logits.device)
     ws = torch.empty((B * Q,), dtype=torch.int32, device=mask_logits.device)
-    check(_lib.lib().siu3r_m2f_attn_mask(_p(mask_logits), _p(out), _p(ws), B, T, IH, IW, OH, OW, Q, _stream()))
+    check(_lib.lib().siu3r_m2f_attn_mask(_p(mask_logits), _p(out), _p(ws), B, T, IH, IW, OH, OW, Q, ld, _stream()))
     return out
 
 
