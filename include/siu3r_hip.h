@@ -141,6 +141,61 @@ int siu3r_gaussian_adapter(const void* raw, int raw_dtype, float* opacities, flo
 int siu3r_m2f_attn_mask(const float* mask_logits, uint8_t* out, int32_t* row_counts_ws, int B, int T, int IH,
                         int IW, int OH, int OW, int Q, int64_t out_ld, void* stream);
 
+/* ---- Gaussian splat rasterizer (tile-binned).  Replaces the reference's two un-vendored CUDA dependencies at their
+ * call sites: GaussianRasterizer(settings)(means3D, ..., cov3D_precomp, ...) -> (image, radii, depth, opacity,
+ * n_touched) (reference src/models/cuda_splatting.py:90-118; mode 0) and gsplat.rasterization(means, covars,
+ * opacities, colors[N,C], viewmats, Ks, width, height, near_plane, far_plane) -> (colors, alphas, meta)
+ * (reference src/models/gaussian_renderer.py:92-106; mode 1).  One camera per call.  All constants of the published
+ * algorithms are explicit parameters. */
+typedef struct {
+  int32_t mode;        /* 0 = K2 (3DGS family), 1 = K3 (gsplat family) */
+  int32_t width, height;
+  float w2c[16];       /* world->camera, row-major (column-vector convention) */
+  float proj[16];      /* K2: full projection P = Proj * W2C, row-major */
+  float tanfovx, tanfovy;
+  float campos[3];
+  float bg[3];
+  int32_t sh_degree;   /* K2: 0..4 */
+  int32_t sh_band4;    /* K2: evaluate SH coefficients 16..24 (open question of the fork; default 0) */
+  float k2_znear_cull; /* 0.2 */
+  float fx, fy, cx, cy; /* K3: pixel-unit intrinsics */
+  float near_plane, far_plane;
+  float eps2d;         /* 0.3 */
+  float radius_clip;
+  float extent_sigma;  /* 3.33 */
+  int32_t opacity_aware_extent;
+  float alpha_min;     /* 1/255 */
+  float alpha_max;     /* 0.99 (K2) / 0.999 (K3) */
+  float t_min;         /* 1e-4 */
+  float dilation;      /* K2 low-pass 0.3 */
+} siu3r_raster_cam;
+/* stage 1+2: project G Gaussians (means [G,3], cov6 [G,6] upper-triangular, opacities [G], colors: mode 0 SH
+ * [G,channels,3], mode 1 unused) and count/scan tiles.  Outputs: mean2d [G,2], conic_op [G,4], depth [G], radii [G,2]
+ * i32, rect [G,4] i32, tiles_touched [G] i32, rgb [G,3] (mode 0), tile_count [T], tile_start [T+1], cursor [T] i32.
+ * tile_start[T] = D, the number of (tile, Gaussian) pairs, which sizes the key buffer of the next stage. */
+int siu3r_raster_bin(const siu3r_raster_cam* cam, int64_t G, const float* means, const float* cov6,
+                     const float* opacities, const float* colors, int channels, float* mean2d, float* conic_op,
+                     float* depth, int32_t* radii, int32_t* rect, int32_t* tiles_touched, float* rgb, int32_t* tile_count,
+                     int32_t* tile_start, int32_t* cursor, void* stream);
+/* stage 3+4: fill and sort the per-tile lists; keys [D] u64 (depth bits << 32 | id), ids [D] i32 (front to back) */
+int siu3r_raster_sort(const siu3r_raster_cam* cam, int64_t G, const int32_t* rect, const float* depth,
+                      const int32_t* tile_start, int32_t* cursor, uint64_t* keys, int32_t* ids, void* stream);
+/* stage 5 (mode 0): image [3,H,W], depth [H,W], accumulated opacity [H,W], n_touched [G] i32 */
+int siu3r_raster_composite_rgb(const siu3r_raster_cam* cam, const int32_t* tile_start, const int32_t* ids,
+                               const float* mean2d, const float* conic_op, const float* depth, const float* rgb,
+                               float* image, float* out_depth, float* out_alpha, int32_t* n_touched, int64_t G, void* stream);
+/* stage 5 (mode 1): feats [G,channels] -> out [H,W,channels] (+ alphas [H,W]), 32 channels per pass */
+int siu3r_raster_composite_feat(const siu3r_raster_cam* cam, const int32_t* tile_start, const int32_t* ids,
+                                const float* mean2d, const float* conic_op, const float* feats, int channels, float* out,
+                                float* out_alpha, void* stream);
+/* x *= s in place (the reference rescales the scene x10 in place, src/models/gaussian_renderer.py:43-46) */
+int siu3r_scale_inplace(float* x, int64_t n, float s, void* stream);
+/* query-class-logit lifting (reference src/pipeline.py:137-193): rendered [V,H,W,q*C] -> sem_id, ins_id int64 [V,H,W];
+ * first_pix [q] i32 workspace/out (first pixel owned by each query, or INT_MAX), q_label [q] i32 out */
+int siu3r_lift_ids(const float* qc, int V, int H, int W, int q, int C, float sem_threshold, int num_queries,
+                   uint32_t stuff_mask, int64_t* sem_id, int64_t* ins_id, int32_t* first_pix, int32_t* q_label,
+                   void* stream);
+
 /* fp32 [rows, k] (row stride ldx) -> bf16 hi plane [rows,kpad] (+ optional lo = bf16(x - hi)), zero padded:
  * weight / operand pre-packing for siu3r_gemm. */
 int siu3r_split_bf16(const float* x, void* hi, void* lo, int64_t rows, int k, int kpad, int64_t ldx, void* stream);

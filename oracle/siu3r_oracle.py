@@ -647,6 +647,33 @@ def scatter_labels(results, B: int, V: int, H: int, Wd: int):
     return sem.reshape(B, -1), ins.reshape(B, -1)
 
 
+def lift_ids(render_qc_logit: T, q_score, num_queries: int = 100, fuse=(0, 1), thr: float = 0.3):
+    """Query-class-logit lifting of one batch item (pipeline.py:137-193): render_qc_logit [v, q, c+1, h, w]."""
+    v, q, c, h, w_ = render_qc_logit.shape
+    c_logit, q_index = render_qc_logit.max(dim=1)
+    c_logit = torch.cat([c_logit[:, -1:], c_logit[:, :-1]], dim=1)
+    q_index = torch.cat([q_index[:, -1:], q_index[:, :-1]], dim=1)
+    sem_logits, sem_id = c_logit.max(dim=1)
+    q_index = q_index.gather(1, sem_id[:, None]).squeeze(1) + 1
+    sem_id = sem_id.clone()
+    sem_id[sem_logits < thr] = 0
+    q_index[sem_id == 0] = 0
+    info = []
+    for q_idx, sc in enumerate(q_score):
+        ids = sem_id[q_index == q_idx + 1]
+        if ids.numel() == 0:
+            continue
+        info.append({"id": q_idx + 1, "label_id": int(ids[0]), "was_fused": False, "score": sc})
+    for stuff in fuse:
+        m = sem_id == (stuff + 1)
+        q_index[m] = num_queries + stuff + 1
+        for i in info:
+            if i["label_id"] == stuff + 1:
+                i["was_fused"] = True
+                i["id"] = int(q_index[m][0])
+    return sem_id, q_index, info
+
+
 # ----------------------------------------------------------------------------------------
 # whole model (model.py:314-389)
 # ----------------------------------------------------------------------------------------

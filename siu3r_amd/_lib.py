@@ -49,6 +49,20 @@ class AttnParams(C.Structure):
     ]
 
 
+class RasterCam(C.Structure):
+    """siu3r_raster_cam (include/siu3r_hip.h); the CPU oracle's raster_cam has the same layout."""
+    _fields_ = [
+        ("mode", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+        ("w2c", C.c_float * 16), ("proj", C.c_float * 16),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("campos", C.c_float * 3), ("bg", C.c_float * 3),
+        ("sh_degree", C.c_int32), ("sh_band4", C.c_int32), ("k2_znear_cull", C.c_float),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("near_plane", C.c_float), ("far_plane", C.c_float), ("eps2d", C.c_float), ("radius_clip", C.c_float),
+        ("extent_sigma", C.c_float), ("opacity_aware_extent", C.c_int32),
+        ("alpha_min", C.c_float), ("alpha_max", C.c_float), ("t_min", C.c_float), ("dilation", C.c_float),
+    ]
+
+
 # name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/siu3r_hip.h.
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
@@ -70,6 +84,12 @@ SIGNATURES = {
     "siu3r_gaussian_adapter": [_P, _I, _P, _P, _P, _P, _P, _L, _P],
     "siu3r_m2f_attn_mask": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "siu3r_split_bf16": [_P, _P, _P, _L, _I, _I, _L, _P],
+    "siu3r_raster_bin": [C.POINTER(RasterCam), _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "siu3r_raster_sort": [C.POINTER(RasterCam), _L, _P, _P, _P, _P, _P, _P, _P],
+    "siu3r_raster_composite_rgb": [C.POINTER(RasterCam), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
+    "siu3r_raster_composite_feat": [C.POINTER(RasterCam), _P, _P, _P, _P, _P, _I, _P, _P, _P],
+    "siu3r_scale_inplace": [_P, _L, _F, _P],
+    "siu3r_lift_ids": [_P, _I, _I, _I, _I, _I, _F, _I, C.c_uint32, _P, _P, _P, _P, _P],
     "siu3r_panoptic_stage1": [_P] * 20 + [_I] * 9 + [_F, _F, _F, C.c_uint32, _P],
     "siu3r_panoptic_qcl": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
 }

@@ -247,3 +247,73 @@ extern "C" int siu3r_panoptic_qcl(const float* p256, const float* probs, const i
   SIU3R_LAUNCH_CHECK("siu3r_panoptic_qcl");
   return 0;
 }
+
+// ======================= query-class-logit lifting (reference src/pipeline.py:137-193) ==========================
+namespace {
+
+__global__ void lift_pixel_kernel(const float* qc, int64_t npix, int q, int C, float thr, int64_t* sem_id, int64_t* ins_id,
+                                  int32_t* first_pix) {
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const float* v = qc + pix * (int64_t)q * C;
+  float best_sem = -INFINITY;
+  int sem = 0, qsel = 0;
+  for (int cr = 0; cr < C; ++cr) {            // rolled class index: 0 <- void (last), k <- k-1   (:144-149)
+    const int orig = cr == 0 ? C - 1 : cr - 1;
+    float bq = -INFINITY;
+    int bi = 0;
+    for (int qi = 0; qi < q; ++qi) {          // max over queries, first maximum wins (:141)
+      const float x = v[qi * C + orig];
+      if (x > bq) {
+        bq = x;
+        bi = qi;
+      }
+    }
+    if (bq > best_sem) {                      // max over classes, first maximum wins (:150)
+      best_sem = bq;
+      sem = cr;
+      qsel = bi;
+    }
+  }
+  int qidx = qsel + 1;
+  if (best_sem < thr) sem = 0;                // (:161-162)
+  if (sem == 0) qidx = 0;                     // (:163)
+  sem_id[pix] = sem;
+  ins_id[pix] = qidx;
+  if (qidx > 0) atomicMin(&first_pix[qidx - 1], (int32_t)pix);
+}
+
+__global__ void lift_label_kernel(const int64_t* sem_id, const int32_t* first_pix, int32_t* q_label, int q) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= q) return;
+  q_label[i] = first_pix[i] == 0x7fffffff ? -1 : (int32_t)sem_id[first_pix[i]];  // sem_id of the first owned pixel (:166-170)
+}
+
+__global__ void lift_fuse_kernel(const int64_t* sem_id, int64_t* ins_id, int64_t npix, int num_queries, uint32_t stuff_mask) {
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int s = (int)sem_id[pix];
+  if (s >= 1 && s <= 32 && ((stuff_mask >> (s - 1)) & 1u)) ins_id[pix] = num_queries + (s - 1) + 1;  // (:180-184)
+}
+
+__global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+extern "C" int siu3r_lift_ids(const float* qc, int V, int H, int W, int q, int C, float sem_threshold, int num_queries,
+                              uint32_t stuff_mask, int64_t* sem_id, int64_t* ins_id, int32_t* first_pix, int32_t* q_label,
+                              void* stream) {
+  SIU3R_CHECK(qc && sem_id && ins_id && first_pix && q_label && q > 0 && C > 1, "lift_ids: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t npix = (int64_t)V * H * W;
+  SIU3R_CHECK(npix < 0x7fffffff, "lift_ids: too many pixels");
+  hipLaunchKernelGGL(fill_i32_kernel, g1(q), dim3(256), 0, s, first_pix, q, 0x7fffffff);
+  hipLaunchKernelGGL(lift_pixel_kernel, g1(npix), dim3(256), 0, s, qc, npix, q, C, sem_threshold, sem_id, ins_id, first_pix);
+  hipLaunchKernelGGL(lift_label_kernel, g1(q), dim3(256), 0, s, sem_id, first_pix, q_label, q);
+  hipLaunchKernelGGL(lift_fuse_kernel, g1(npix), dim3(256), 0, s, sem_id, ins_id, npix, num_queries, stuff_mask);
+  SIU3R_LAUNCH_CHECK("siu3r_lift_ids");
+  return 0;
+}

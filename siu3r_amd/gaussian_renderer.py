@@ -1,0 +1,113 @@
+"""Mirror of the reference's src/models/gaussian_renderer.py (SplattingCUDA.forward, :29-116) and of the
+query-class-logit lifting in src/pipeline.py:132-193, on top of the HIP rasterizer."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from . import _lib, raster
+from ._lib import check
+from .cuda_splatting import render_cuda
+from .gaussians_types import Gaussians
+from .ops import _gpu, _p, _stream
+
+
+class SplattingCUDA:
+    def __init__(self) -> None:
+        self.near = 0.1
+        self.far = 100.0
+        self.scale_factor = 1 / self.near
+        self.background_color = torch.tensor([0.0, 0.0, 0.0], dtype=torch.float32)
+
+    def forward(self, gaussians: Gaussians, extrinsics, intrinsics, image_shape, render_color: bool = True,
+                render_feature: bool = False, render_id: bool = False, render_qc_logits: bool = False,
+                cam_rot_delta=None, cam_trans_delta=None):
+        """reference signature gaussian_renderer.py:29-41.  extrinsics [b,v,4,4] camera-to-world (OpenCV),
+        intrinsics [b,v,3,3] normalised.  NOTE (quirk 1, reproduced): means / covariances are rescaled x10 / x100
+        IN PLACE on the Gaussians (:43-46)."""
+        b, v, _, _ = extrinsics.shape
+        extrinsics = extrinsics.detach().float().cpu().clone()
+        extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * self.scale_factor
+        raster.scale_inplace_(gaussians.covariances, self.scale_factor ** 2)
+        raster.scale_inplace_(gaussians.means, self.scale_factor)
+        near, far = 1.0, self.far * self.scale_factor
+        color = depth = None
+        all_qc: Optional[List[torch.Tensor]] = None
+        intr = intrinsics.detach().float().cpu()
+        if render_color:
+            colors, depths = [], []
+            for i in range(b):  # each batch item has its own Gaussians; its v views are rendered back to back
+                c_i, d_i = render_cuda(
+                    extrinsics[i], intr[i], torch.full((v,), near), torch.full((v,), far), image_shape,
+                    self.background_color[None].repeat(v, 1), gaussians.means[i][None].expand(v, -1, -1),
+                    gaussians.covariances[i][None].expand(v, -1, -1, -1), gaussians.harmonics[i][None].expand(v, -1, -1, -1),
+                    gaussians.opacities[i][None].expand(v, -1))
+                colors.append(c_i)
+                depths.append(d_i)
+            color = torch.stack(colors).clamp_(0.0, 1.0)  # (:73) clamp is pure data conditioning on the output buffer
+            depth = torch.stack(depths)
+        if render_qc_logits:
+            height, width = image_shape
+            all_qc = []
+            for i in range(b):
+                means, opac = gaussians.means[i], gaussians.opacities[i]
+                cov6 = raster.cov6_from_cov3x3(gaussians.covariances[i])
+                qcl = gaussians.seg_query_class_logits[i]  # [n, q, c]
+                n, q, c = qcl.shape
+                feats = qcl.reshape(n, q * c)
+                views = []
+                for j in range(v):
+                    K = intr[i, j].clone()
+                    K[0, :] *= width
+                    K[1, :] *= height
+                    w2c = torch.linalg.inv(extrinsics[i, j])
+                    cam = raster.make_cam_k3(w2c, K[0, 0], K[1, 1], K[0, 2], K[1, 2], width, height, near_plane=near, far_plane=far)
+                    out = raster.rasterize_k3(cam, means, cov6, opac, feats)
+                    views.append(out["colors"])  # [h, w, q*c]
+                stacked = torch.stack(views)  # [v, h, w, q*c]
+                # reference layout 'n h w (q c) -> n q c h w' as a view of the channel-last buffer
+                all_qc.append(stacked.view(v, height, width, q, c).permute(0, 3, 4, 1, 2))
+        return {"render_color": color, "render_depth": depth, "render_qc_logits": all_qc}
+
+    __call__ = forward
+
+
+def lift_query_class_logits(render_qc_logits: List[torch.Tensor], query_scores: List[List[float]], num_queries: int = 100,
+                            label_ids_to_fuse=(0, 1), sem_threshold: float = 0.3):
+    """Lifting of rendered query x class logit maps to per-pixel semantic / instance ids
+    (reference src/pipeline.py:132-193).  render_qc_logits: list(b) of [v, q, c+1, h, w] (views of channel-last buffers).
+    Returns (sem_ids [b,v,h,w] int64, ins_ids [b,v,h,w] int64, seg_infos)."""
+    all_sem, all_ins, seg_infos = [], [], []
+    stuff_mask = 0
+    for s in label_ids_to_fuse:
+        stuff_mask |= 1 << s
+    for qc, q_score in zip(render_qc_logits, query_scores):
+        _gpu(qc)
+        v, q, c, h, w = qc.shape
+        cl = qc.permute(0, 3, 4, 1, 2)  # channel-last [v,h,w,q,c]
+        if not cl.is_contiguous():
+            cl = cl.contiguous()
+        dev = qc.device
+        sem = torch.empty((v, h, w), dtype=torch.int64, device=dev)
+        ins = torch.empty((v, h, w), dtype=torch.int64, device=dev)
+        first = torch.empty((q,), dtype=torch.int32, device=dev)
+        qlab = torch.empty((q,), dtype=torch.int32, device=dev)
+        check(_lib.lib().siu3r_lift_ids(_p(cl), v, h, w, q, c, sem_threshold, num_queries, stuff_mask, _p(sem), _p(ins),
+                                        _p(first), _p(qlab), _stream()))
+        qlab_h = qlab.cpu().tolist()
+        info = []
+        for q_idx, sc in enumerate(q_score):
+            if q_idx >= q or qlab_h[q_idx] < 0:
+                continue
+            info.append({"id": q_idx + 1, "label_id": qlab_h[q_idx], "was_fused": False, "score": sc})
+        for stuff in label_ids_to_fuse:
+            for i_ in info:
+                if i_["label_id"] == stuff + 1:
+                    i_["was_fused"] = True
+                    i_["id"] = num_queries + stuff + 1
+        all_sem.append(sem)
+        all_ins.append(ins)
+        seg_infos.append(info)
+    return torch.stack(all_sem), torch.stack(all_ins), seg_infos
