@@ -458,10 +458,10 @@ extern "C" int siu3r_raster_bin(const siu3r_raster_cam* cam, int64_t G, const fl
                                 const float* opacities, const float* colors, int channels, float* mean2d, float* conic_op,
                                 float* depth, int32_t* radii, int32_t* rect, int32_t* tiles_touched, float* rgb,
                                 int32_t* tile_count, int32_t* tile_start, int32_t* cursor, void* stream) {
-  SIU3R_CHECK(cam && means && cov6 && opacities && mean2d && conic_op && depth && radii && rect && tiles_touched && tile_count && tile_start && cursor,
-              "raster_bin: null pointer");
+  SIU3R_CHECK(cam && tile_count && tile_start && cursor, "raster_bin: null pointer");
+  SIU3R_CHECK(G == 0 || (means && cov6 && opacities && mean2d && conic_op && depth && radii && rect && tiles_touched), "raster_bin: null per-Gaussian pointer");
   SIU3R_CHECK(cam->mode == 0 || cam->mode == 1, "raster_bin: bad mode %d", cam->mode);
-  SIU3R_CHECK(cam->mode == 1 || (colors && rgb && channels >= (cam->sh_degree + 1) * (cam->sh_degree + 1)), "raster_bin: SH colours missing / too few coefficients");
+  SIU3R_CHECK(cam->mode == 1 || G == 0 || (colors && rgb && channels >= (cam->sh_degree + 1) * (cam->sh_degree + 1)), "raster_bin: SH colours missing / too few coefficients");
   Cam c;
   to_cam(cam, &c);
   hipStream_t s = (hipStream_t)stream;
@@ -479,7 +479,7 @@ extern "C" int siu3r_raster_bin(const siu3r_raster_cam* cam, int64_t G, const fl
 
 extern "C" int siu3r_raster_sort(const siu3r_raster_cam* cam, int64_t G, const int32_t* rect, const float* depth,
                                  const int32_t* tile_start, int32_t* cursor, uint64_t* keys, int32_t* ids, void* stream) {
-  SIU3R_CHECK(cam && rect && depth && tile_start && cursor && keys && ids, "raster_sort: null pointer");
+  SIU3R_CHECK(cam && tile_start && cursor && keys && ids && (G == 0 || (rect && depth)), "raster_sort: null pointer");
   hipStream_t s = (hipStream_t)stream;
   const int gw = (cam->width + TILE - 1) / TILE, T = gw * ((cam->height + TILE - 1) / TILE);
   if (G > 0) hipLaunchKernelGGL(fill_kernel, g1(G), dim3(256), 0, s, G, rect, depth, cursor, keys, gw);
@@ -492,7 +492,7 @@ extern "C" int siu3r_raster_composite_rgb(const siu3r_raster_cam* cam, const int
                                           const float* mean2d, const float* conic_op, const float* depth, const float* rgb,
                                           float* image, float* out_depth, float* out_alpha, int32_t* n_touched, int64_t G,
                                           void* stream) {
-  SIU3R_CHECK(cam && tile_start && ids && mean2d && conic_op && depth && rgb && image && out_depth && out_alpha && n_touched, "raster_composite_rgb: null pointer");
+  SIU3R_CHECK(cam && tile_start && ids && image && out_depth && out_alpha && (G == 0 || (mean2d && conic_op && depth && rgb && n_touched)), "raster_composite_rgb: null pointer");
   Cam c;
   to_cam(cam, &c);
   hipStream_t s = (hipStream_t)stream;
