@@ -1,0 +1,73 @@
+"""CPU tests: the C-ABI shared library loads and exports every symbol include/siu3r_hip.h declares (no compute calls
+without a GPU), the ctypes structs match the C layouts, and the product fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "siu3r_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(siu3r_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from siu3r_amd import _lib
+
+    l = _lib.lib()
+    syms = _declared_symbols()
+    assert len(syms) >= 25, syms
+    for s in syms:
+        assert hasattr(l, s), f"{s} declared in include/siu3r_hip.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
+    assert set(_lib.SIGNATURES) <= set(syms) | {"siu3r_last_error", "siu3r_abi_version"}
+    assert l.siu3r_abi_version() == 1
+
+
+def test_struct_layouts_match_c():
+    """sizeof of the ctypes mirrors == sizeof of the C structs (compiled with the host compiler)."""
+    from siu3r_amd import _lib
+
+    src = '#include <stdio.h>\n#include "siu3r_hip.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(siu3r_gemm_params), sizeof(siu3r_attn_params), sizeof(siu3r_raster_cam));return 0;}\n'
+    exe = "/tmp/siu3r_sizeof"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
+    sizes = list(map(int, subprocess.run([exe], capture_output=True, check=True).stdout.split()))
+    assert sizes == [C.sizeof(_lib.GemmParams), C.sizeof(_lib.AttnParams), C.sizeof(_lib.RasterCam)], sizes
+
+
+def test_oracle_raster_struct_matches():
+    from oracle import raster_oracle as RO
+    from siu3r_amd import _lib
+
+    assert RO.lib().raster_ref_struct_size() == C.sizeof(_lib.RasterCam)
+
+
+def test_no_cpu_fallback():
+    """The product path refuses CPU tensors instead of silently computing on the host."""
+    from siu3r_amd import ops
+
+    with pytest.raises(RuntimeError):
+        ops.layernorm(torch.zeros(4, 64), torch.ones(64), torch.zeros(64), 1e-6)
+    with pytest.raises(RuntimeError):
+        ops.rope_2d(torch.zeros(1, 2, 2, 8), torch.zeros(1, 2, 2, dtype=torch.int64), 100.0, 1.0)
+    if not torch.cuda.is_available():
+        from siu3r_amd.model import SIU3RModel
+
+        with pytest.raises(RuntimeError):
+            SIU3RModel({}, image_size=(64, 64))
+
+
+def test_rows_layout_host_logic():
+    from siu3r_amd.ops import _rows_layout
+
+    x = torch.zeros(2, 9, 16)
+    assert _rows_layout(x) == (1, 18, 16, 0)
+    assert _rows_layout(x[:, :-1]) == (2, 8, 16, 144)
+    assert _rows_layout(torch.zeros(3, 4, 5, 8)[:, :, :, :]) == (1, 60, 8, 0)
+    assert _rows_layout(torch.zeros(2, 2, 9, 16)[:, 0]) == (2, 9, 16, 288)

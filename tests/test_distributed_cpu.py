@@ -1,0 +1,44 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU path: pair sharding + the single all-gather of metric statistics."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from siu3r_amd import distributed as D
+
+
+def _worker(rank, world, port, n_items, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, _, w = D.init_from_env(backend="gloo")
+    mine = D.shard_indices(n_items, r, w)
+    stats = dict(n_pairs=len(mine), n_images=2 * len(mine), sum_psnr=float(sum(20.0 + i for i in mine)) * 2, label_checksum=float(sum(mine)))
+    gathered = D.all_gather_stats(D.pack_stats(stats))
+    tot = D.reduce_stats(gathered)
+    t = D.max_over_ranks(float(rank + 1))
+    D.barrier()
+    q.put((rank, mine, tot, gathered.shape, t))
+    dist.destroy_process_group()
+
+
+def test_shard_and_gather_world2():
+    n_items, world, port = 7, 2, 29617
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(timeout=60) for p in ps]
+    assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5]          # i -> rank i mod world, no padding, nothing twice
+    for _, _, tot, shape, t in res:
+        assert tuple(shape) == (2, len(D.STAT_KEYS))
+        assert tot["n_pairs"] == n_items and tot["n_images"] == 2 * n_items
+        assert abs(tot["psnr"] - (20.0 + sum(range(n_items)) / n_items)) < 1e-12   # additive statistics == single-process result
+        assert tot["label_checksum"] == sum(range(n_items)) and t == 2.0
+
+
+def test_single_process_paths():
+    assert D.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
+    g = D.all_gather_stats(D.pack_stats(dict(n_pairs=3, n_images=6, sum_psnr=60.0)))
+    assert g.shape == (1, len(D.STAT_KEYS)) and D.reduce_stats(g)["psnr"] == 10.0
+    assert D.max_over_ranks(1.5) == 1.5

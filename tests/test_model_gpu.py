@@ -105,3 +105,31 @@ def test_forward_parity(precision, tol_max, tol_l2, size):
         bb_ = b.permute(0, 3, 4, 1, 2).reshape(-1, b.shape[1], b.shape[2])
         assert a.shape == bb_.shape and float((a.cpu() - bb_).abs().max()) <= 1e-5
     assert not fails, f"parity failures: {fails}"
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-3), ("bf16", 6e-2)])
+@pytest.mark.parametrize("size", [256, 512])
+def test_forward_against_reference_golden(precision, tol, size):
+    """HIP forward at the BASELINE sizes (256^2 shipped scripts, 512^2 benchmark) against the golden vectors produced by
+    the REFERENCE's own forward (tests/golden/make_golden.py): strided samples + L2 norms of every Gaussian field and of
+    the Mask2Former logits; integer label checksums and segment lists exact."""
+    from golden_utils import FIELDS, compare_summary, default_K, fixture_images, load_model_fixture
+    from oracle import weights as OW
+    from siu3r_amd.model import SIU3RModel
+
+    if "sd" not in _STATE:
+        _STATE["sd"] = OW.make_weights(0)
+    z, meta = load_model_fixture(size)
+    model = SIU3RModel(_STATE["sd"], image_size=(size, size), precision=precision)
+    with torch.no_grad():
+        g, seg, masks, infos, qs = model(fixture_images(size).cuda(), default_K().cuda(), enable_query_class_logit_lift=True)
+    torch.cuda.synchronize()
+    for f in FIELDS:
+        compare_summary(f, getattr(g, f), z, tol * (2 if (f == "covariances" and precision == "bf16") else 1))
+    compare_summary("class_queries_logits", seg.class_queries_logits, z, tol)
+    compare_summary("masks_queries_logits", seg.masks_queries_logits, z, tol)
+    assert int(g.semantic_labels.sum()) == int(z["semantic_labels.sum"]) and int(g.instance_labels.sum()) == int(z["instance_labels.sum"])
+    assert infos == meta["seg_infos"]
+    assert str(masks[0].dtype) == str(z["seg_mask.dtype"])
+    del model
+    torch.cuda.empty_cache()

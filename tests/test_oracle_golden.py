@@ -1,0 +1,85 @@
+"""CPU tests (-m "not gpu"): the oracle (oracle/) against the golden vectors produced by the REFERENCE's own code
+(tests/golden/make_golden.py, run in the build container).  This is what pins the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from crafted import crafted_panoptic_inputs, permuted
+from golden_utils import FIELDS, GOLDEN, compare_summary, default_K, fixture_images, load_model_fixture
+from oracle import siu3r_oracle as O
+from oracle import weights as OW
+
+_SD = {}
+
+
+def _weights():
+    if "sd" not in _SD:
+        _SD["sd"] = OW.make_weights(0)
+    return _SD["sd"]
+
+
+def test_small_ops_against_reference_vectors():
+    z = np.load(os.path.join(GOLDEN, "small_ops.npz"))
+    out = O.rope2d(torch.from_numpy(z["rope_tok"]), torch.from_numpy(z["rope_pos"]))
+    assert float((out - torch.from_numpy(z["rope_out"])).abs().max()) <= 2e-6  # reference RoPE2D (pos_embed.py:126-179)
+    raw = torch.from_numpy(z["ga_raw"])
+    g = O.gaussian_adapter(torch.zeros(3, 50, 3), raw)
+    for k, name in (("ga_cov", "covariances"), ("ga_sh", "harmonics"), ("ga_op", "opacities"), ("ga_scale", "scales"), ("ga_rot", "rotations")):
+        ref = torch.from_numpy(z[k])
+        assert float((g[name] - ref).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max())), name
+
+
+def test_projection_helpers_against_reference_vectors():
+    """get_fov / get_projection_matrix are host-side parameter code of the PRODUCT's renderer front-end; they contain no
+    GPU work, so they are pinned here against the reference's values (utils/projection.py:247-261, cuda_splatting.py:16-43)."""
+    from siu3r_amd import cuda_splatting as cs
+
+    z = np.load(os.path.join(GOLDEN, "small_ops.npz"))
+    K = torch.tensor([[318 / 256, 0, 0.5], [0, 318 / 256, 0.5], [0, 0, 1]])[None]
+    fov = cs.get_fov(K)
+    assert np.allclose(fov.numpy(), z["fov"], atol=1e-6)
+    proj = cs.get_projection_matrix(torch.tensor([1.0]), torch.tensor([1000.0]), fov[:, 0], fov[:, 1])
+    assert np.allclose(proj.numpy(), z["proj"], atol=1e-6)
+
+
+@pytest.mark.parametrize("oname,order", [("natural", [0, 1, 2, 3]), ("quirk_first", [2, 0, 3, 1])])
+def test_panoptic_postprocess_against_reference_vectors(oname, order):
+    z = np.load(os.path.join(GOLDEN, "panoptic_crafted.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "panoptic_crafted.json")))[oname]
+    cls, msk = permuted(*crafted_panoptic_inputs(), order)
+    res = O.panoptic_postprocess(cls, msk, (64, 64))
+    for b, r in enumerate(res):
+        seg = z[f"{oname}.{b}.segmentation"]
+        assert str(r["segmentation"].dtype) == meta[b]["dtype"]
+        assert np.array_equal(r["segmentation"].numpy(), seg)
+        assert r["segments_info"] == meta[b]["segments_info"] and r["query_scores"] == meta[b]["query_scores"]
+        assert list(r["query_class_logits"].shape) == list(z[f"{oname}.{b}.qcl_shape"])
+        assert np.array_equal(r["query_class_logits"].reshape(-1)[::97].numpy(), z[f"{oname}.{b}.qcl_sample"])
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_lifting_against_reference_vectors(case):
+    meta = json.load(open(os.path.join(GOLDEN, "lifting.json")))[case]
+    z = np.load(os.path.join(GOLDEN, f"lifting_{case}.npz"))
+    sem, ins, info = O.lift_ids(torch.from_numpy(z["x"]), meta["scores"])
+    assert np.array_equal(sem.numpy(), z["sem_id"]) and np.array_equal(ins.numpy(), z["ins_id"])
+    assert info == meta["info"]
+
+
+@pytest.mark.parametrize("size", [256, 512])
+def test_model_forward_against_reference_vectors(size):
+    """Full SIU3RModel.forward of the reference (synthetic weights, asset pair) vs the oracle: strided samples + norms."""
+    z, meta = load_model_fixture(size)
+    with torch.no_grad():
+        out = O.model_forward(_weights(), fixture_images(size), default_K(), keep_intermediates=False)
+    for f in FIELDS:
+        compare_summary(f, out[f], z, 2e-4)
+    compare_summary("class_queries_logits", out["class_queries_logits"], z, 2e-4)
+    compare_summary("masks_queries_logits", out["masks_queries_logits"], z, 2e-4)
+    assert int(out["semantic_labels"].sum()) == int(z["semantic_labels.sum"]) and int(out["instance_labels.sum"] if False else out["instance_labels"].sum()) == int(z["instance_labels.sum"])
+    assert out["seg_infos"] == meta["seg_infos"] and out["query_scores"] == meta["query_scores"]
+    assert str(out["seg_masks"][0].dtype) == str(z["seg_mask.dtype"])
+    assert np.array_equal(out["seg_masks"][0].unique().numpy(), z["seg_mask.unique"])
