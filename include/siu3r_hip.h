@@ -71,6 +71,7 @@ typedef struct {
   const int64_t* rope_pos;
   int32_t rope_ncols;
   int32_t map_gx, map_rm, map_rn; /* filled by the launcher (XCD-aware tile map); callers leave them 0 */
+  uint64_t* trace;                /* tuning aid, normally NULL: 8 shader-clock stamps per workgroup (tools/gemm_trace.py) */
 } siu3r_gemm_params;
 int siu3r_gemm(const siu3r_gemm_params* p, void* stream);
 

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsiu3r_hip.so")
+LIB_PATH = os.environ.get("SIU3R_LIB_OVERRIDE") or os.path.join(_HERE, "libsiu3r_hip.so")  # override: kernel A/B builds (tools/)
 
 BF16, F32 = 0, 1
 
@@ -31,6 +31,7 @@ class GemmParams(C.Structure):
         ("up_src", C.c_void_p), ("up_dtype", C.c_int32),
         ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("rope_pos", C.c_void_p), ("rope_ncols", C.c_int32),
         ("map_gx", C.c_int32), ("map_rm", C.c_int32), ("map_rn", C.c_int32),
+        ("trace", C.c_void_p),
     ]
 
 

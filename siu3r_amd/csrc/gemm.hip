@@ -19,6 +19,9 @@
 
 int siu3r_gemm_dma_launch(const siu3r_gemm_params& p, int ni, void* stream);  // gemm_dma.hip (bf16 LDS-DMA fast path)
 static const bool g_disable_dma = getenv("SIU3R_GEMM_NO_DMA") != nullptr;     // debugging / A-B switch
+// 128x64 tiles (two workgroups per CU) beat 128x128 (one per CU: 96 KiB ring) at every size measured on gfx950 --
+// finer wave quantisation and a second workgroup to overlap prologue/epilogue; 128x128 stays reachable for A/B runs
+static const int g_narrow_max = getenv("SIU3R_GEMM_NARROW_MAX") ? atoi(getenv("SIU3R_GEMM_NARROW_MAX")) : 0x7fffffff;
 
 namespace {
 
@@ -45,7 +48,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
   constexpr int STAGE_BYTES = PLANES * (A_TILE_BYTES + B_TILE_BYTES);
   constexpr int WROWS = 2 * NI;  // weight rows per thread per K-tile
   // stage s: [A_hi | B_hi | (A_lo | B_lo)]
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+  constexpr int SMEM_BYTES = 2 * STAGE_BYTES > siu3r_epi::staging_bytes<NI>() ? 2 * STAGE_BYTES : siu3r_epi::staging_bytes<NI>();
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -291,7 +295,10 @@ int launch(const siu3r_gemm_params& pin, hipStream_t s) {
   p.map_rn = (tn + best - 1) / best;
   const int tiles = 8 * p.map_rm * p.map_rn;
   dim3 grid(tiles, 1, p.batch > 0 ? p.batch : 1), block(256);
-  if (!p.w_lo && p.a_dtype == SIU3R_BF16 && p.a_mode != 2 && !g_disable_dma) return siu3r_gemm_dma_launch(p, NI, s);
+  if (!p.w_lo && p.a_dtype == SIU3R_BF16 && p.a_mode != 2 && !g_disable_dma) {
+    const int rc = siu3r_gemm_dma_launch(p, NI, s);
+    if (rc <= 0) return rc;  // 1: outside the buffer-addressed kernels' range -> register-staged kernel below
+  }
   if (p.w_lo) {
     hipLaunchKernelGGL((gemm_kernel<1, 1, NI>), grid, block, 0, s, p);
   } else if (p.a_dtype == SIU3R_F32) {
@@ -330,7 +337,7 @@ extern "C" int siu3r_gemm(const siu3r_gemm_params* pp, void* stream) {
   if (p.up_src) SIU3R_CHECK(p.a_mode == 1 && p.out_mode == 0 && p.oh % 2 == 0 && p.ow % 2 == 0, "siu3r_gemm: up_src needs conv mode with even output size");
   // narrow tiles when 128x128 tiling would leave most of the 256 CUs without a workgroup, or N <= 64
   const int64_t tiles128 = (int64_t)((p.m + BM - 1) / BM) * ((p.n + 127) / 128) * (p.batch > 0 ? p.batch : 1);
-  const bool narrow = (p.n <= 64) || (tiles128 < 384 && p.n > 64);
+  const bool narrow = (p.n <= 64) || (tiles128 < g_narrow_max && p.n > 64);
   hipStream_t s = (hipStream_t)stream;
   return narrow ? launch<1>(p, s) : launch<2>(p, s);
 }

@@ -1,11 +1,20 @@
 // bf16 fast-path GEMM / implicit-GEMM conv for gfx950: operands stream global -> LDS with the LDS-DMA
-// (global_load_lds_dwordx4, 16 B/lane, 1 KiB per wave-instruction) into a 3-stage ring; MFMA reads stage kt while
+// (buffer_load_dwordx4 ... lds, 16 B/lane, 1 KiB per wave-instruction) into a 3-stage ring; MFMA reads stage kt while
 // the DMAs of stages kt+1 and kt+2 are in flight.  The waits are hand-counted (s_waitcnt vmcnt(N), raw s_barrier):
 // hipcc neither tracks LDS-DMA completion nor inserts waits for it, and -- unlike the register-staged kernel in
 // gemm.hip, whose loads hipcc drains with vmcnt(0) before every LDS write -- nothing is drained early.
+//
+// The K loop is budgeted in VALU slots: 16 MFMAs of a 128x128x64 step keep the matrix pipe busy for 512 cycles, i.e.
+// 128 wave64 VALU issues; everything else has to fit under that.  Hence
+//   * buffer addressing: per-lane byte offsets are loop-invariant VGPRs, the K advance travels in the scalar offset,
+//     and padding (conv borders, K tail) is an out-of-range offset that the hardware turns into zeros -- no pointer
+//     arithmetic, selects or divisions in the loop;
+//   * MODE 1 (3x3/1x1 convs with cin % 64 == 0): one filter tap per K tile, tracked by a scalar cursor, border validity
+//     as one bit test against a per-row tap mask;
+//   * the fused input ReLU is one v_pk_max_i16 per fragment dword and compiled in only where it is used.
+// MODE 2 (any cin % 8 == 0, e.g. the 7x7 stem) keeps per-lane tap arithmetic.
 // The LDS image keeps gemm.hip's XOR swizzle: the DMA destination is lane-linear, so the permutation is applied
-// to the per-lane SOURCE address (cdna_hip_programming.md rule 21).  Zero padding (conv borders, K tail) points the
-// lane at a 16-byte zero page instead of branching.  Same tiles, MFMA layout and epilogue as gemm.hip.
+// to the per-lane SOURCE address (cdna_hip_programming.md rule 21).  Same tiles, MFMA layout and epilogue as gemm.hip.
 #include "common.h"
 #include "gemm_epilogue.h"
 
@@ -13,109 +22,158 @@ namespace siu3r_gemm_dma {
 
 constexpr int BM = 128, BK = 64, STAGES = 3;
 constexpr int A_TILE_BYTES = BM * BK * 2;
+constexpr unsigned OOB = 0xffffff00u;  // >= num_records of every resource below: the DMA writes zeros
+constexpr int RSRC_FLAGS = 0x00020000;
 
-__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) short i16x2;
 
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-__device__ __forceinline__ uint4 relu_bf16x8(uint4 v) {
-  uint32_t* w = (uint32_t*)&v;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint32_t neg = (w[j] >> 15) & 0x00010001u;  // sign bits -> bit 0 of each half
-    w[j] &= ~(neg * 0xffffu);
-  }
-  return v;
-}
-
-template <int NI, int CONV>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const siu3r_gemm_params p) {
+template <int NI, int MODE, bool RELU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_dma_kernel(const siu3r_gemm_params p) {
+#if __HIP_DEVICE_COMPILE__  // the buffer-resource type has no host representation; the host pass only needs the stub
   constexpr int BN = 64 * NI;
   constexpr int B_TILE_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
   constexpr int A_DMA = 4;        // 1-KiB DMA pieces per wave per K-tile for A (16 pieces / 4 waves)
   constexpr int W_DMA = 2 * NI;   // ... for W (BN/8 pieces / 4 waves)
   constexpr int LP = A_DMA + W_DMA;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * STAGE_BYTES];
+  __shared__ __attribute__((aligned(128))) unsigned char smem[STAGES * STAGE_BYTES];
 
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  const int tiles_m = (p.m + BM - 1) / BM, tiles_n = (p.n + BN - 1) / BN;
+  const int M = p.m, N = p.n, K = p.k, kpad = p.kpad;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
-  const int ry = xcd / p.map_gx, rx = xcd - ry * p.map_gx;
+#ifndef SIU3R_GEMM_DBG
+#define SIU3R_GEMM_DBG 0  // tuning builds only (tools/ab_build.sh): 1 no epilogue, 2 no in-loop DMA, 4 no MFMA, 8 no barrier, 16 no reads
+#endif
+  constexpr int dbg = SIU3R_GEMM_DBG;
+  const int map_gx = p.map_gx;
+  const int ry = xcd / map_gx, rx = xcd - ry * map_gx;
   const int lm = li / p.map_rn, ln = li - lm * p.map_rn;
   const int tile_m = ry * p.map_rm + lm, tile_n = rx * p.map_rn + ln;
   if (lm >= p.map_rm || tile_m >= tiles_m || tile_n >= tiles_n) return;
   const int z = blockIdx.z;
+  const int nkt = kpad / BK;
+  uint64_t* trace = p.trace ? p.trace + (size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8 : nullptr;
+  auto stamp = [&](int slot) {
+    if (trace && t == 0) trace[slot] = __builtin_readcyclecounter();
+  };
+  stamp(0);
 
   const u16* Ab = (const u16*)p.a + (int64_t)z * p.sa;
   const u16* Wb = (const u16*)p.w_hi + (int64_t)z * p.sw;
-  const u16* zero = (const u16*)g_zero_page;
 
   // ---- DMA geometry.  Piece g (8 rows x 128 B) of a tile; lane -> (row = 8 g + lane/8, physical chunk = lane%8);
   // the lane fetches the LOGICAL chunk that the swizzle stores there.
   const int prow = lane >> 3, pchunk = lane & 7;
-  int a_c[A_DMA];                 // logical 8-element k-chunk fetched by this lane for piece i
-  const u16* a_ptr[A_DMA];        // dense: row base pointer (+ chunk offset); conv: image base of the row's batch item
-  int a_iy0[A_DMA], a_ix0[A_DMA];
+  const int cin = p.cin, iw = p.iw, ih = p.ih, kw = p.kw, kh = p.kh;
+  const int pad_bias = (MODE == 1) ? (p.pad * iw + p.pad) * cin * 2 : 0;  // keeps every per-row offset non-negative
+  __amdgpu_buffer_rsrc_t rA, rW;
+  if (MODE == 0)
+    rA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, (short)0, (int)(((int64_t)(M - 1) * p.lda + K) * 2), RSRC_FLAGS);
+  else
+    rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Ab - pad_bias), (short)0, (int)OOB, RSRC_FLAGS);
+  rW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, (short)0, (int)((int64_t)N * kpad * 2), RSRC_FLAGS);
+
+  unsigned a_voff[A_DMA];          // MODE 0/1: byte offset of the lane's chunk at K-tile 0 / tap (0,0)
+  unsigned a_mask[A_DMA];          // MODE 1: bit (ky*kw+kx) set <=> that tap is inside the image for this row
+  int a_c[A_DMA];                  // logical 8-element k-chunk fetched by this lane for piece i
+  const u16* a_ptr[A_DMA];         // MODE 2: image base of the row's batch item
+  int a_iy0[A_DMA], a_ix0[A_DMA];  // MODE 2
 #pragma unroll
   for (int i = 0; i < A_DMA; ++i) {
     const int r = (wave * A_DMA + i) * 8 + prow;
     a_c[i] = pchunk ^ ((r >> 1) & 7);
     int m = tile_m * BM + r;
-    if (m > p.m - 1) m = p.m - 1;  // rows beyond M: clamped, never stored
+    if (m > M - 1) m = M - 1;  // rows beyond M: clamped, never stored
+    a_voff[i] = a_mask[i] = 0;
+    a_ptr[i] = nullptr;
     a_iy0[i] = a_ix0[i] = 0;
-    if (CONV) {
+    if (MODE == 0) {
+      a_voff[i] = (unsigned)(((int64_t)m * p.lda + a_c[i] * 8) * 2);
+    } else {
       const int ohw = p.oh * p.ow;
       const int b = m / ohw, rr = m - b * ohw;
       const int oy = rr / p.ow, ox = rr - oy * p.ow;
-      a_ptr[i] = Ab + (int64_t)b * p.ih * p.iw * p.cin;
-      a_iy0[i] = oy * p.stride - p.pad;
-      a_ix0[i] = ox * p.stride - p.pad;
-    } else {
-      a_ptr[i] = Ab + (int64_t)m * p.lda + a_c[i] * 8;
+      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+      if (MODE == 1) {
+        a_voff[i] = (unsigned)((((b * ih + iy0) * iw + ix0) * cin + a_c[i] * 8) * 2 + pad_bias);
+        unsigned mk = 0;
+        for (int ky = 0; ky < kh; ++ky)
+          for (int kx = 0; kx < kw; ++kx)
+            if (iy0 + ky >= 0 && iy0 + ky < ih && ix0 + kx >= 0 && ix0 + kx < iw) mk |= 1u << (ky * kw + kx);
+        a_mask[i] = mk;
+      } else {
+        a_ptr[i] = Ab + (int64_t)b * ih * iw * cin;
+        a_iy0[i] = iy0;
+        a_ix0[i] = ix0;
+      }
     }
   }
-  const u16* w_ptr[W_DMA];
+  unsigned w_voff[W_DMA];
 #pragma unroll
   for (int i = 0; i < W_DMA; ++i) {
     const int r = (wave * W_DMA + i) * 8 + prow;
     const int c = pchunk ^ ((r >> 1) & 7);
     int n = tile_n * BN + r;
-    if (n > p.n - 1) n = p.n - 1;
-    w_ptr[i] = Wb + (int64_t)n * p.kpad + c * 8;
+    if (n > N - 1) n = N - 1;
+    w_voff[i] = (unsigned)(((int64_t)n * kpad + c * 8) * 2);
   }
+  const bool ktail = (K & (BK - 1)) != 0;
+
+  // MODE 1 cursor of the next K tile to be issued (tiles are issued strictly in order): wave-uniform scalars
+  int cur_c0 = 0, cur_kx = 0, cur_toff = 0, cur_row = 0;  // cur_row = byte offset of tap row ky
+  unsigned cur_bit = 1u;
+  auto cursor_advance = [&]() {
+    cur_c0 += BK;
+    cur_toff += BK * 2;
+    if (cur_c0 == cin) {
+      cur_c0 = 0;
+      cur_bit <<= 1;
+      if (++cur_kx == kw) {
+        cur_kx = 0;
+        cur_row += iw * cin * 2;
+      }
+      cur_toff = cur_row + cur_kx * cin * 2;
+    }
+  };
 
   // one A piece (index i) and/or W pieces of K-tile kt into ring stage `stage`
   auto issue_a = [&](int kt, int stage, int i) {
-    unsigned char* sA = smem + stage * STAGE_BYTES;
-    const u16* src;
-    const int k0 = kt * BK + a_c[i] * 8;
-    if (CONV) {
-      const int tap = k0 / p.cin, c0 = k0 - tap * p.cin;
-      const int ky = tap / p.kw, kx = tap - ky * p.kw;
-      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-      const bool ok = k0 < p.k && iy >= 0 && iy < p.ih && ix >= 0 && ix < p.iw;
-      src = ok ? a_ptr[i] + ((int64_t)iy * p.iw + ix) * p.cin + c0 : zero;
+    unsigned char* dst = smem + stage * STAGE_BYTES + (wave * A_DMA + i) * 1024;
+    if (MODE == 0) {
+      unsigned voff = a_voff[i];
+      if (ktail && kt == nkt - 1) voff = (kt * BK + a_c[i] * 8 < K) ? voff : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, voff, kt * (BK * 2), 0, 0);
+    } else if (MODE == 1) {
+      const unsigned voff = (a_mask[i] & cur_bit) ? a_voff[i] : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, voff, cur_toff, 0, 0);
     } else {
-      src = k0 < p.k ? a_ptr[i] + kt * BK : zero;
+      const int k0 = kt * BK + a_c[i] * 8;
+      const int tap = k0 / cin, c0 = k0 - tap * cin;
+      const int ky = tap / kw, kx = tap - ky * kw;
+      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+      const bool ok = k0 < K && iy >= 0 && iy < ih && ix >= 0 && ix < iw;
+      const unsigned voff = ok ? (unsigned)(((a_ptr[i] - Ab) + ((int64_t)iy * iw + ix) * cin + c0) * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, voff, 0, 0, 0);
     }
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(sA + (wave * A_DMA + i) * 1024), 16, 0, 0);
   };
   auto issue_w = [&](int kt, int stage, int i) {
-    unsigned char* sB = smem + stage * STAGE_BYTES + A_TILE_BYTES;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[i] + kt * BK),
-                                     (__attribute__((address_space(3))) void*)(sB + (wave * W_DMA + i) * 1024), 16, 0, 0);
+    unsigned char* dst = smem + stage * STAGE_BYTES + A_TILE_BYTES + (wave * W_DMA + i) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr)dst, 16, w_voff[i], kt * (BK * 2), 0, 0);
   };
   auto issue = [&](int kt, int stage) {
 #pragma unroll
     for (int i = 0; i < A_DMA; ++i) issue_a(kt, stage, i);
 #pragma unroll
     for (int i = 0; i < W_DMA; ++i) issue_w(kt, stage, i);
+    if (MODE == 1) cursor_advance();
   };
 
   f32x16 acc[2][NI];
@@ -127,58 +185,120 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const siu3r_gemm_params p
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // Fragment reads are inline asm: hipcc treats every LDS-DMA as a pending LDS store and would put
-  // s_waitcnt vmcnt(0) in front of any ds_read it can see, draining the ring each K-step.  The reads are issued in
-  // two halves of (2 + NI) * 2 so that the second half's latency hides under the first half's MFMAs; each wait
-  // statement names its fragments "+v" so no MFMA can be scheduled above it (cdna_hip_programming.md 5.7 (ii)).
-  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  // s_waitcnt vmcnt(0) in front of any ds_read it can see, draining the ring each K-step.  Each wait statement names
+  // its fragments "+v" so no MFMA can be scheduled above it (cdna_hip_programming.md 5.7 (ii)).
+  // Address of (row, k-substep ks): row*128 + (((2 ks + lh) ^ swz) << 4) = (row*128 | ((lh ^ swz) << 4)) ^ (ks << 5).
   const unsigned int lds_base = (unsigned int)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  unsigned int offA[2], offB[NI];  // per-lane row offsets; the k-substep enters through the XOR term
+  unsigned int offA[2], offB[NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) offA[i] = (wm * 64 + i * 32 + l31) * 128;
+  for (int i = 0; i < 2; ++i) {
+    const int row = wm * 64 + i * 32 + l31;
+    offA[i] = row * 128 + ((lh ^ ((row >> 1) & 7)) << 4);
+  }
 #pragma unroll
-  for (int j = 0; j < NI; ++j) offB[j] = (wn * (32 * NI) + j * 32 + l31) * 128;
-  const int swzA0 = ((wm * 64 + l31) >> 1) & 7;          // rows i*32 apart share (row>>1)&7
-  const int swzB0 = ((wn * (32 * NI) + l31) >> 1) & 7;
-  const unsigned int relu_mask = p.relu_in ? 0xffffffffu : 0u;
+  for (int j = 0; j < NI; ++j) {
+    const int row = wn * (32 * NI) + j * 32 + l31;
+    offB[j] = A_TILE_BYTES + row * 128 + ((lh ^ ((row >> 1) & 7)) << 4);
+  }
 
-  // K-tile body: fragment reads of k-substep ks+1 are issued before the MFMAs of ks, and the DMA pieces of the
-  // K-tile two ahead are spread over the four MFMA groups so that their issue cost hides under the matrix pipe.
-  // Only lgkmcnt(0) is used for the reads (a counted wait could be satisfied by an unrelated scalar load).
-  auto read_frags = [&](unsigned int sA, unsigned int sB, int ks, u32x4 (&fa)[2], u32x4 (&fb)[NI]) {
-    const int c = ks * 2 + lh;
+  auto read_frags = [&](const unsigned int (&adA)[2], const unsigned int (&adB)[NI], int ks, u32x4 (&fa)[2], u32x4 (&fb)[NI]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const unsigned int ad = sA + offA[i] + ((c ^ swzA0) << 4);
+      const unsigned int ad = adA[i] ^ (ks << 5);
       asm volatile("ds_read_b128 %0, %1" : "=v"(fa[i]) : "v"(ad) : "memory");
     }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const unsigned int ad = sB + offB[j] + ((c ^ swzB0) << 4);
+      const unsigned int ad = adB[j] ^ (ks << 5);
       asm volatile("ds_read_b128 %0, %1" : "=v"(fb[j]) : "v"(ad) : "memory");
     }
   };
-  auto compute = [&](int stage, int kt_next, int stage_next) {
-    const unsigned int sA = lds_base + stage * STAGE_BYTES;
-    const unsigned int sB = sA + A_TILE_BYTES;
-    u32x4 fa[4][2], fb[4][NI];
-    read_frags(sA, sB, 0, fa[0], fb[0]);
+  // K-tile body.  All 4 x (2 + NI) fragment reads of a K tile are issued back to back, one MFMA group BEFORE the
+  // tile is consumed: inside the last k-substep of the previous tile, right after the barrier that publishes it.
+  // A ds_read_b128 round trip is ~180 cycles with four waves reading; a k-substep's MFMAs last 64 (NI=1) / 128 cycles,
+  // so reading one substep ahead left most of that latency exposed four times per K tile.  The waits are counted
+  // (LDS returns in order; an interleaved scalar load can only make a counted wait more conservative).
+  // The DMA pieces of the K tile two ahead are spread over the four MFMA groups.
+  auto issue_tile_reads = [&](int stage, u32x4 (&fa)[4][2], u32x4 (&fb)[4][NI]) {
+    const unsigned int sbase = lds_base + stage * STAGE_BYTES;  // 128-byte aligned: the XOR stays inside the row
+    unsigned int adA[2], adB[NI];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) adA[i] = sbase + offA[i];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) adB[j] = sbase + offB[j];
+#ifdef SIU3R_GEMM_RDLINEAR  // tuning build: conflict-free lane-linear addresses (wrong data) = the LDS read floor
+#pragma unroll
+    for (int i = 0; i < 2; ++i) adA[i] = sbase + (wave * 2 + i) * 4096 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) adB[j] = sbase + (wave * NI + j) * 4096 + lane * 16 + 128;
+#endif
+    // lgkmcnt is a 4-bit counter: never more than 15 reads in flight.  NI = 2 (16 reads per tile) issues its last
+    // k-substep from tile_body, after the first wait
+#pragma unroll
+    for (int ks = 0; ks < (NI == 2 ? 3 : 4); ++ks) read_frags(adA, adB, ks, fa[ks], fb[ks]);
+  };
+  auto issue_last_reads = [&](int stage, u32x4 (&fa)[4][2], u32x4 (&fb)[4][NI]) {
+    const unsigned int sbase = lds_base + stage * STAGE_BYTES;
+    unsigned int adA[2], adB[NI];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) adA[i] = sbase + offA[i];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) adB[j] = sbase + offB[j];
+    read_frags(adA, adB, 3, fa[3], fb[3]);
+  };
+#define SIU3R_WAIT_FRAGS(CNT)                                                                                              \
+  do {                                                                                                                     \
+    if (NI == 2)                                                                                                           \
+      asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa[ks][0]), "+v"(fa[ks][1]), "+v"(fb[ks][0]), "+v"(fb[ks][NI - 1])::"memory"); \
+    else                                                                                                                   \
+      asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa[ks][0]), "+v"(fa[ks][1]), "+v"(fb[ks][0])::"memory");          \
+  } while (0)
+  auto tile_body = [&](int kt, int st, u32x4 (&fa)[4][2], u32x4 (&fb)[4][NI], u32x4 (&na)[4][2], u32x4 (&nb)[4][NI]) {
+    const int kt_next = (kt + 2 < nkt && !(dbg & 2)) ? kt + 2 : -1;  // wave-uniform
+    int stage_next = st + 2;
+    if (stage_next >= STAGES) stage_next -= STAGES;
+    int stage_read = st + 1;
+    if (stage_read >= STAGES) stage_read -= STAGES;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (NI == 2)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[ks][0]), "+v"(fa[ks][1]), "+v"(fb[ks][0]), "+v"(fb[ks][NI - 1])::"memory");
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[ks][0]), "+v"(fa[ks][1]), "+v"(fb[ks][0])::"memory");
-      if (ks < 3) read_frags(sA, sB, ks + 1, fa[ks + 1], fb[ks + 1]);
+      // fragments of k-substep ks: (3 - ks) * (2 + NI) younger reads may still be in flight
+      if (ks == 0) {
+        if (NI == 2) {
+          SIU3R_WAIT_FRAGS(8);
+          issue_last_reads(st, fa, fb);
+        } else {
+          SIU3R_WAIT_FRAGS(9);
+        }
+      }
+      else if (ks == 1) { if (NI == 2) SIU3R_WAIT_FRAGS(8); else SIU3R_WAIT_FRAGS(6); }
+      else if (ks == 2) { if (NI == 2) SIU3R_WAIT_FRAGS(4); else SIU3R_WAIT_FRAGS(3); }
+      else SIU3R_WAIT_FRAGS(0);
+      if (ks == 3 && kt + 1 < nkt) {
+        // this wave has finished reading tile kt.  Tile kt+1 must have landed: only the pieces of tile kt+2 issued in
+        // k-substeps 0..2 of this tile (3 A + 3 or 2 W) may remain in flight
+        if (kt_next >= 0) {
+          if (NI == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (!(dbg & 8)) __builtin_amdgcn_s_barrier();  // tile kt+1 is visible to every wave; stage st is free for tile kt+3
+        asm volatile("" ::: "memory");
+        if (!(dbg & 16)) issue_tile_reads(stage_read, na, nb);
+      }
       __builtin_amdgcn_sched_barrier(0);
       bf16x8 a[2], bq[NI];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         u32x4 v = fa[ks][i];
-        // fused input ReLU (ResidualConvUnit): clear negative bf16 halves, branch-free
+        if (RELU) {  // fused input ReLU (ResidualConvUnit): a negative bf16 is a negative int16
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const unsigned int neg = (v[e] >> 15) & 0x00010001u;
-          v[e] &= ~((neg * 0xffffu) & relu_mask);
+          for (int e = 0; e < 4; ++e) {
+            union { unsigned int u; i16x2 h; } x;
+            x.u = v[e];
+            x.h = __builtin_elementwise_max(x.h, (i16x2){0, 0});
+            v[e] = x.u;
+          }
         }
         union { u32x4 u; bf16x8 h; } cv;
         cv.u = v;
@@ -193,63 +313,97 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const siu3r_gemm_params p
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
-      if (kt_next >= 0) {  // wave-uniform
+        for (int j = 0; j < NI; ++j) if (!(dbg & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
+      if (kt_next >= 0) {
         issue_a(kt_next, stage_next, ks);
         if (NI == 2) issue_w(kt_next, stage_next, ks);
-        else if (ks < 2) issue_w(kt_next, stage_next, ks);
+        else if (ks < 2) issue_w(kt_next, stage_next, ks);  // NI = 1: two W pieces, in k-substeps 0 and 1
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (MODE == 1 && kt_next >= 0) cursor_advance();
   };
 
   // ---- 3-stage ring, prefetch distance 2, one raw barrier per K-tile, counted vmcnt
-  const int nkt = p.kpad / BK;
+  stamp(1);
   issue(0, 0);
   if (nkt > 1) issue(1, 1);
-  int st = 0;
-  for (int kt = 0; kt < nkt; ++kt) {
-    // tile kt must have landed; only tile kt+1 (the LP newest DMAs of this wave) may still be in flight
-    if (kt + 1 < nkt) {
-      if (LP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();  // every wave's pieces of tile kt are in LDS; stage (kt+2)%3 is no longer read
-    asm volatile("" ::: "memory");
-    int s2 = st + 2;
-    if (s2 >= STAGES) s2 -= STAGES;
-    compute(st, kt + 2 < nkt ? kt + 2 : -1, s2);
-    st = (st + 1 == STAGES) ? 0 : st + 1;
+  stamp(2);
+  if (nkt > 1) {
+    if (LP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  __builtin_amdgcn_s_barrier();  // tile 0 is in LDS
+  asm volatile("" ::: "memory");
+  stamp(3);
+  u32x4 fA0[4][2], fB0[4][NI], fA1[4][2], fB1[4][NI];
+  issue_tile_reads(0, fA0, fB0);
+  int st = 0;
+  for (int kt = 0; kt < nkt; kt += 2) {
+    tile_body(kt, st, fA0, fB0, fA1, fB1);
+    st = (st + 1 == STAGES) ? 0 : st + 1;
+    if (kt + 1 < nkt) {
+      tile_body(kt + 1, st, fA1, fB1, fA0, fB0);
+      st = (st + 1 == STAGES) ? 0 : st + 1;
+    }
+  }
+#undef SIU3R_WAIT_FRAGS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp(4);
 
   // ---- epilogue: LDS-staged, row-wise vectorised (gemm_epilogue.h)
+  if (dbg & 1) { if (acc[0][0][0] == 123.456f) ((float*)p.c)[0] = 1.f; return; }
   siu3r_epi::run<NI>(p, acc, smem, tile_m, tile_n, z, t);
+  if (trace && t == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    trace[5] = __builtin_readcyclecounter();
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    trace[6] = ((uint64_t)xcc << 32) | hwid;
+  }
+#endif
 }
 
 }  // namespace siu3r_gemm_dma
 
-// called by siu3r_gemm() (gemm.hip) for bf16 activations without the bf16x3 split, dense or conv gather
+// Called by siu3r_gemm() (gemm.hip) for bf16 activations without the bf16x3 split, dense or conv gather.
+// Returns 1 when the problem is outside what the buffer-addressed kernels cover (the caller then uses the
+// register-staged kernel): operands of 4 GiB or more, or a fused input ReLU outside MODE 1.
 int siu3r_gemm_dma_launch(const siu3r_gemm_params& p, int ni, void* stream) {
   using namespace siu3r_gemm_dma;
-  const int BN = 64 * ni;
-  const int tiles = 8 * p.map_rm * p.map_rn;
-  (void)BN;
-  dim3 grid(tiles, 1, p.batch > 0 ? p.batch : 1), block(256);
-  hipStream_t s = (hipStream_t)stream;
-  if (ni == 1) {
-    if (p.a_mode == 1)
-      hipLaunchKernelGGL((gemm_dma_kernel<1, 1>), grid, block, 0, s, p);
-    else
-      hipLaunchKernelGGL((gemm_dma_kernel<1, 0>), grid, block, 0, s, p);
+  const int64_t lim = 0xfffff000ll;
+  int mode;
+  if ((int64_t)p.n * p.kpad * 2 >= lim) return 1;
+  if (p.a_mode == 0) {
+    mode = 0;
+    if (((int64_t)(p.m - 1) * p.lda + p.k) * 2 >= lim || p.relu_in) return 1;
   } else {
-    if (p.a_mode == 1)
-      hipLaunchKernelGGL((gemm_dma_kernel<2, 1>), grid, block, 0, s, p);
-    else
-      hipLaunchKernelGGL((gemm_dma_kernel<2, 0>), grid, block, 0, s, p);
+    const int64_t img = (int64_t)(p.m / (p.oh * p.ow)) * p.ih * p.iw * p.cin * 2 + (int64_t)(p.pad * p.iw + p.pad) * p.cin * 2;
+    if (img >= lim) return 1;
+    mode = (p.cin % 64 == 0 && p.kh * p.kw <= 32 && p.kpad == p.k) ? 1 : 2;
+    if (mode == 2 && p.relu_in) return 1;
   }
+  const int tiles = 8 * p.map_rm * p.map_rn;
+  dim3 grid(tiles, 1, p.batch > 0 ? p.batch : 1);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 block(256);
+#define SIU3R_DMA_LAUNCH(NI_, MODE_, RELU_) hipLaunchKernelGGL((gemm_dma_kernel<NI_, MODE_, RELU_>), grid, block, 0, s, p)
+  if (ni == 1) {
+    if (mode == 0) SIU3R_DMA_LAUNCH(1, 0, false);
+    else if (mode == 1 && p.relu_in) SIU3R_DMA_LAUNCH(1, 1, true);
+    else if (mode == 1) SIU3R_DMA_LAUNCH(1, 1, false);
+    else SIU3R_DMA_LAUNCH(1, 2, false);
+  } else {
+    if (mode == 0) SIU3R_DMA_LAUNCH(2, 0, false);
+    else if (mode == 1 && p.relu_in) SIU3R_DMA_LAUNCH(2, 1, true);
+    else if (mode == 1) SIU3R_DMA_LAUNCH(2, 1, false);
+    else SIU3R_DMA_LAUNCH(2, 2, false);
+  }
+#undef SIU3R_DMA_LAUNCH
   SIU3R_LAUNCH_CHECK("siu3r_gemm(dma)");
   return 0;
 }

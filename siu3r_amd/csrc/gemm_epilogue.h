@@ -1,7 +1,7 @@
 // Shared GEMM epilogue for gemm.hip / gemm_dma.hip.
 //
-// The MFMA accumulators (lane = one output column, 16 rows per 32x32 tile) are staged through LDS in two
-// 64-row halves and written back row-wise: every lane owns 8 consecutive columns of one row, so bias / residual /
+// The MFMA accumulators (lane = one output column, 16 rows per 32x32 tile) are staged through LDS (whole tile)
+// and written back row-wise: every lane owns 8 consecutive columns of one row, so bias / residual /
 // output move as 16-byte (bf16) or 2x16-byte (fp32) vectors and a row of the tile is one contiguous burst,
 // instead of 2-4 byte scalar stores per lane (which made the old epilogue cost more than a K=1024 main loop).
 // Fused here: bias, exact-erf GELU / ReLU, residual add, RoPE2D on q|k columns, conv-transpose pixel shuffle,
@@ -11,23 +11,44 @@
 
 namespace siu3r_epi {
 
-// erf with |error| <= 1.5e-7 (Abramowitz-Stegun 7.1.26): fp32-epsilon class, an order cheaper than erff()
-__device__ __forceinline__ float erf_as(float x) {
+// GELU(x) = x Phi(x) = 0.5 (x + |x| erf(|x| / sqrt 2)) with erf(u) = 1 - (1 + a1 u + ... + a6 u^6)^-16
+// (Abramowitz-Stegun 7.1.28, |error| <= 3e-7: fp32-epsilon class).  One quarter-rate op (the reciprocal) per element
+// instead of erff()'s or 7.1.26's two (reciprocal + exponential); the 1/sqrt 2 is folded into the coefficients.
+// (1 + ...)^16 overflows to +inf beyond |x| ~ 25, where 1/inf = 0 gives erf = 1 exactly.
+__device__ __forceinline__ float gelu_fast(float x) {
   const float ax = fabsf(x);
-  const float t = 1.0f / (1.0f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float y = 1.0f - poly * __expf(-ax * ax);
-  return x < 0.f ? -y : y;
+  float q = 4.30638e-5f * 0.125f;                        // a6 / 2^3
+  q = q * ax + 2.765672e-4f * 0.17677669529663687f;      // a5 / 2^2.5
+  q = q * ax + 1.520143e-4f * 0.25f;                     // a4 / 2^2
+  q = q * ax + 9.2705272e-3f * 0.35355339059327373f;     // a3 / 2^1.5
+  q = q * ax + 4.22820123e-2f * 0.5f;                    // a2 / 2
+  q = q * ax + 7.05230784e-2f * 0.70710678118654752f;    // a1 / 2^0.5
+  q = q * ax + 1.0f;
+  q *= q;
+  q *= q;
+  q *= q;
+  q *= q;
+  const float e = 1.0f - __builtin_amdgcn_rcpf(q);
+  return 0.5f * (ax * e + x);
 }
-__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 
+template <int NI>
+constexpr int staging_bytes() { return 128 * (64 * NI + 4) * 4; }
+
+// The whole 128 x BN accumulator tile is staged once (two raw barriers); every thread then owns ONE 8-column chunk
+// (t % CHUNKS, so its bias / RoPE axis are loop invariants) of NTASK rows.  All global reads of a group of 4 rows --
+// residual, RoPE positions, then the cos/sin rows -- are issued before any of them is used, and the first group's are
+// issued before the staging barriers, so the tile pays one memory latency instead of one per row (the per-row
+// dependent loads of the previous version cost as much as a K = 1024 main loop).
 template <int NI>
 __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2][NI], unsigned char* smem, int tile_m,
                                     int tile_n, int z, int t) {
   constexpr int BN = 64 * NI, BM = 128;
-  constexpr int LDC = BN + 4;          // floats per staged row (16-B aligned rows, spreads banks)
-  constexpr int CHUNKS = BN / 8;       // 8-column chunks per row
-  constexpr int TASKS = 64 * CHUNKS;   // per half
+  constexpr int LDC = BN + 4;            // floats per staged row (16-B aligned rows, spreads banks)
+  constexpr int CHUNKS = BN / 8;         // 8-column chunks per row
+  constexpr int RPP = 256 / CHUNKS;      // rows per pass of the 256 threads
+  constexpr int NTASK = BM / RPP;        // rows per thread (4 or 8)
+  constexpr int G = 4, NG = NTASK / G;
   float* cs = (float*)smem;
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -36,59 +57,124 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
   const unsigned char* Rb = (const unsigned char*)p.residual;
   const int64_t c_boff = (int64_t)z * p.sc, r_boff = (int64_t)z * p.sr;
   const int c_esz = p.c_dtype == SIU3R_F32 ? 4 : 2;
+  const int r_esz = p.r_dtype == SIU3R_F32 ? 4 : 2;
+  const int M = p.m, N = p.n;
 
-  for (int half = 0; half < 2; ++half) {
-    __syncthreads();  // main loop (or previous half) no longer reads the staging area
+  const int chunk = t % CHUNKS, row0 = t / CHUNKS;
+  const int n0 = tile_n * BN + chunk * 8;
+  const bool col_ok = n0 < N;
+  const int nv = col_ok ? min(8, N - n0) : 0;
+  int co0 = n0, kidx = 0;
+  if (p.out_mode == 1) {
+    kidx = n0 / p.cout;
+    co0 = n0 - kidx * p.cout;
+  }
+  const bool full = nv == 8 && (p.out_mode == 0 || co0 + 8 <= p.cout);
+  const bool rope = p.rope_cos != nullptr && n0 < p.rope_ncols && col_ok;
+  const int pc = chunk ^ 2;  // RoPE partner chunk: 16 columns away inside the 64-wide head
+  const int d0 = n0 & 63, axis = d0 >> 5;
+  const bool upper = (d0 & 16) != 0;
+
+  // ---- loop invariants: bias of this chunk (and of the RoPE partner chunk)
+  float bias[8], pbias[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias[e] = pbias[e] = 0.f;
+  if (p.bias && col_ok) {
+    if (nv == 8 && (((uintptr_t)(p.bias + co0)) & 15) == 0) {
+      const float4 a = *(const float4*)(p.bias + co0), b = *(const float4*)(p.bias + co0 + 4);
+      bias[0] = a.x; bias[1] = a.y; bias[2] = a.z; bias[3] = a.w; bias[4] = b.x; bias[5] = b.y; bias[6] = b.z; bias[7] = b.w;
+    } else {
+      _Pragma("unroll") for (int e = 0; e < 8; ++e)
+        if (e < nv) bias[e] = p.bias[co0 + e];
+    }
+    if (rope) {
+      const int pn0 = tile_n * BN + pc * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pbias[e] = p.bias[pn0 + e];
+    }
+  }
+
+  f32x8 res[G];
+  int64_t pos[G];
+  auto issue_loads = [&](int g) {
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const int lr = row0 + (g * G + k) * RPP;
+      const int m = tile_m * BM + lr;
+      const bool ok = col_ok && m < M;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) res[k].v[e] = 0.f;
+      pos[k] = 0;
+      if (!ok) continue;
+      if (Rb && p.out_mode == 0) {
+        const int64_t ridx = r_boff + (int64_t)m * p.ldr + n0;
+        if (full && (((uintptr_t)Rb + ridx * r_esz) & 15) == 0) {
+          res[k] = load8_as_f32(Rb, p.r_dtype, ridx);
+        } else {
+          _Pragma("unroll") for (int e = 0; e < 8; ++e)
+            if (e < nv) res[k].v[e] = load_as_f32(Rb, p.r_dtype, ridx + e);
+        }
+      }
+      if (rope) pos[k] = p.rope_pos[((int64_t)z * M + m) * 2 + axis];
+    }
+  };
+
+  issue_loads(0);
+  // ---- stage the tile.  Raw barriers: the loads above stay in flight across them
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // main loop no longer reads the ring
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int col = wn * (32 * NI) + j * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int lr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        cs[lr * LDC + col] = half == 0 ? acc[0][j][r] : acc[1][j][r];
+        const int lr = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        cs[lr * LDC + col] = acc[i][j][r];
       }
     }
-    __syncthreads();
-    for (int task = t; task < TASKS; task += 256) {
-      const int chunk = task % CHUNKS, lr = task / CHUNKS;
-      const int n0 = tile_n * BN + chunk * 8;
-      const int m = tile_m * BM + (lr >> 5) * 64 + half * 32 + (lr & 31);
-      if (n0 >= p.n || m >= p.m) continue;
-      const int nv = min(8, p.n - n0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g > 0) issue_loads(g);
+    float4 rc[G][2], rs[G][2];
+    if (rope) {
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        const float* cs_ = p.rope_cos + pos[k] * 16 + (d0 & 8);
+        const float* sn_ = p.rope_sin + pos[k] * 16 + (d0 & 8);
+        rc[k][0] = *(const float4*)cs_; rc[k][1] = *(const float4*)(cs_ + 4);
+        rs[k][0] = *(const float4*)sn_; rs[k][1] = *(const float4*)(sn_ + 4);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const int lr = row0 + (g * G + k) * RPP;
+      const int m = tile_m * BM + lr;
+      if (!col_ok || m >= M) continue;
       float v[8];
       {
         const float4 a = *(const float4*)(cs + lr * LDC + chunk * 8);
         const float4 b = *(const float4*)(cs + lr * LDC + chunk * 8 + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
       }
-      // ---- bias (indexed by output channel; conv-transpose: n = (ky*up+kx)*cout + co)
-      int co0 = n0, kidx = 0;
-      if (p.out_mode == 1) {
-        kidx = n0 / p.cout;
-        co0 = n0 - kidx * p.cout;
-      }
-      if (p.bias) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (e < nv) v[e] += p.bias[co0 + e];
-      }
-      // ---- RoPE2D on q|k columns: partner chunk is 16 columns away (chunk ^ 2 inside the 64-wide head)
-      if (p.rope_cos != nullptr && n0 < p.rope_ncols) {
-        const int pc = chunk ^ 2;
+      for (int e = 0; e < 8; ++e) v[e] += bias[e];
+      // ---- RoPE2D on q|k columns
+      if (rope) {
         const float4 a = *(const float4*)(cs + lr * LDC + pc * 8);
         const float4 b = *(const float4*)(cs + lr * LDC + pc * 8 + 4);
-        float pv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        const int pn0 = tile_n * BN + pc * 8;
-        const int d0 = n0 & 63, axis = d0 >> 5;
-        const bool upper = (d0 & 16) != 0;
-        const int64_t pos = p.rope_pos[((int64_t)z * p.m + m) * 2 + axis];
-        const float* cs_ = p.rope_cos + pos * 16 + (d0 & 8);
-        const float* sn_ = p.rope_sin + pos * 16 + (d0 & 8);
+        const float pv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const float cc[8] = {rc[k][0].x, rc[k][0].y, rc[k][0].z, rc[k][0].w, rc[k][1].x, rc[k][1].y, rc[k][1].z, rc[k][1].w};
+        const float ss[8] = {rs[k][0].x, rs[k][0].y, rs[k][0].z, rs[k][0].w, rs[k][1].x, rs[k][1].y, rs[k][1].z, rs[k][1].w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float pb = p.bias ? p.bias[pn0 + e] : 0.f;
-          const float c = cs_[e], s = sn_[e], o = pv[e] + pb;
-          v[e] = upper ? (v[e] * c + o * s) : (v[e] * c - o * s);
+          const float o = pv[e] + pbias[e];
+          v[e] = upper ? (v[e] * cc[e] + o * ss[e]) : (v[e] * cc[e] - o * ss[e]);
         }
       }
       // ---- activation
@@ -110,7 +196,6 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
         const int ky = kidx / p.up, kx = kidx - ky * p.up;
         oidx = (((int64_t)b * (p.ih * p.up) + iy * p.up + ky) * (p.iw * p.up) + ix * p.up + kx) * p.cout + co0;
       }
-      const bool full = nv == 8 && (p.out_mode == 0 || co0 + 8 <= p.cout);
       // ---- fused bilinear x2 (align_corners=True) upsample-add of a low-res NHWC map with n channels
       if (p.up_src) {
         const int ohw = p.oh * p.ow;
@@ -123,30 +208,28 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
         const int y1 = y0 + (y0 < sh - 1 ? 1 : 0), x1 = x0 + (x0 < sw - 1 ? 1 : 0);
         const float ly = fy - y0, lx = fx - x0;
         const int64_t sb = (int64_t)b * sh * sw;
-        const int64_t i00 = (sb + (int64_t)y0 * sw + x0) * p.n + n0, i01 = (sb + (int64_t)y0 * sw + x1) * p.n + n0;
-        const int64_t i10 = (sb + (int64_t)y1 * sw + x0) * p.n + n0, i11 = (sb + (int64_t)y1 * sw + x1) * p.n + n0;
-        if (full && (p.n & 7) == 0) {
+        const int64_t i00 = (sb + (int64_t)y0 * sw + x0) * N + n0, i01 = (sb + (int64_t)y0 * sw + x1) * N + n0;
+        const int64_t i10 = (sb + (int64_t)y1 * sw + x0) * N + n0, i11 = (sb + (int64_t)y1 * sw + x1) * N + n0;
+        if (full && (N & 7) == 0) {
           const f32x8 a = load8_as_f32(p.up_src, p.up_dtype, i00), b_ = load8_as_f32(p.up_src, p.up_dtype, i01);
           const f32x8 c = load8_as_f32(p.up_src, p.up_dtype, i10), d = load8_as_f32(p.up_src, p.up_dtype, i11);
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             v[e] += (1.f - ly) * ((1.f - lx) * a.v[e] + lx * b_.v[e]) + ly * ((1.f - lx) * c.v[e] + lx * d.v[e]);
         } else {
-          for (int e = 0; e < nv; ++e)
-            v[e] += (1.f - ly) * ((1.f - lx) * load_as_f32(p.up_src, p.up_dtype, i00 + e) + lx * load_as_f32(p.up_src, p.up_dtype, i01 + e)) +
+          _Pragma("unroll") for (int e = 0; e < 8; ++e)
+            if (e < nv) v[e] += (1.f - ly) * ((1.f - lx) * load_as_f32(p.up_src, p.up_dtype, i00 + e) + lx * load_as_f32(p.up_src, p.up_dtype, i01 + e)) +
                     ly * ((1.f - lx) * load_as_f32(p.up_src, p.up_dtype, i10 + e) + lx * load_as_f32(p.up_src, p.up_dtype, i11 + e));
         }
       }
-      // ---- residual
+      // ---- residual (conv-transpose scatter: read at the scattered position, not prefetched)
       if (Rb) {
-        const int64_t ridx = r_boff + ((p.out_mode == 0) ? (int64_t)m * p.ldr + n0 : oidx);
-        const int r_esz = p.r_dtype == SIU3R_F32 ? 4 : 2;
-        if (full && (((uintptr_t)Rb + ridx * r_esz) & 15) == 0) {
-          const f32x8 r = load8_as_f32(Rb, p.r_dtype, ridx);
+        if (p.out_mode == 0) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += r.v[e];
+          for (int e = 0; e < 8; ++e) v[e] += res[k].v[e];
         } else {
-          for (int e = 0; e < nv; ++e) v[e] += load_as_f32(Rb, p.r_dtype, ridx + e);
+          _Pragma("unroll") for (int e = 0; e < 8; ++e)
+            if (e < nv) v[e] += load_as_f32(Rb, p.r_dtype, r_boff + oidx + e);
         }
       }
       // ---- store
@@ -157,7 +240,8 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
         for (int e = 0; e < 8; ++e) o.v[e] = v[e];
         store8_from_f32(Cb, p.c_dtype, cidx, o);
       } else {
-        for (int e = 0; e < nv; ++e) store_from_f32(Cb, p.c_dtype, cidx + e, v[e]);  // cout % 8 == 0: no straddling
+        _Pragma("unroll") for (int e = 0; e < 8; ++e)
+          if (e < nv) store_from_f32(Cb, p.c_dtype, cidx + e, v[e]);  // cout % 8 == 0: no straddling
       }
     }
   }

@@ -16,6 +16,8 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional, Sequence
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -98,6 +100,16 @@ class _Ctx:
         self.act = torch.float32 if self.split else torch.bfloat16
         self.dev = w.dev
         self.cache: Dict = {}
+        self._streams: List = []
+        self.concurrent = os.environ.get("SIU3R_NO_STREAMS", "0") != "1"
+
+    def side_stream(self, i):
+        """i-th auxiliary HIP stream: the independent chains of the network (two decoder sides, the four DPT heads,
+        the ViT-Adapter/Mask2Former branch) are enqueued on separate streams so that at batch 1, where most launches
+        are far smaller than the 256 CUs, they fill the chip together.  Forks and joins are wait_stream() edges."""
+        while len(self._streams) <= i:
+            self._streams.append(torch.cuda.Stream(device=self.dev))
+        return self._streams[i]
 
     def ln(self, name, x, eps, out_dtype=None):
         return ops.layernorm(x, self.w.v(name + ".weight"), self.w.v(name + ".bias"), eps, out_dtype or self.act)
@@ -146,10 +158,10 @@ class AsymmetricCroCo:
         return ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], heads=heads, head_dim=Cc // heads,
                              scale=(Cc // heads) ** -0.5, split3=ctx.split)
 
-    def _mlp(self, p, x, ln_name):
+    def _mlp(self, p, x, ln_name, out=None):
         ctx = self.ctx
         h = ops.linear(ctx.ln(ln_name, x, 1e-6), ctx.w.linear(p + ".fc1"), out_dtype=ctx.act, act=ACT_GELU)
-        return ops.linear(h, ctx.w.linear(p + ".fc2"), out_dtype=torch.float32, residual=x)
+        return ops.linear(h, ctx.w.linear(p + ".fc2"), out_dtype=torch.float32, residual=x, out=out)
 
     def _enc_block(self, p, x, pos, rope):
         ctx = self.ctx
@@ -157,7 +169,7 @@ class AsymmetricCroCo:
         x = ops.linear(a, ctx.w.linear(p + ".attn.proj"), out_dtype=torch.float32, residual=x)
         return self._mlp(p + ".mlp", x, p + ".norm2")
 
-    def _dec_block(self, p, x, y, xpos, ypos, rope):
+    def _dec_block(self, p, x, y, xpos, ypos, rope, out=None):
         """DecoderBlock.forward (blocks.py:186-191); x, y are [B, N, C] fp32 strided views."""
         ctx = self.ctx
         B, N, Cc = x.shape
@@ -171,10 +183,10 @@ class AsymmetricCroCo:
                         out_dtype=ctx.act, rope=(rope[0], rope[1], ypos, Cc)).view(B, N, 2, DEC_HEADS, d)
         a = ops.attention(q, kv[:, :, 0], kv[:, :, 1], heads=DEC_HEADS, head_dim=d, scale=d ** -0.5, split3=ctx.split)
         x = ops.linear(a, ctx.w.linear(p + ".cross_attn.proj"), out_dtype=torch.float32, residual=x)
-        return self._mlp(p + ".mlp", x, p + ".norm3")
+        return self._mlp(p + ".mlp", x, p + ".norm3", out=out)
 
-    def forward(self, context: dict, symmetrize_batch=False, return_views=False):
-        """reference signature backbone_croco.py:263-268; context = {"image": [B,2,3,H,W], "intrinsics": [B,2,3,3]}."""
+    def forward(self, context: dict, symmetrize_batch=False, return_views=False, after_encoder=None):
+        """reference signature backbone_croco.py:263-268 (+ after_encoder hook); context = {"image": [B,2,3,H,W], "intrinsics": [B,2,3,3]}."""
         assert not symmetrize_batch, "symmetrize_batch is a training-time option"
         ctx = self.ctx
         images, K = context["image"], context["intrinsics"]
@@ -202,28 +214,42 @@ class AsymmetricCroCo:
         for i in range(self.enc_depth):
             x = self._enc_block(f"backbone.enc_blocks.{i}", x, pos, rope)
             all_feat.append(x)
+        av = [t.view(B, V, N + 1, -1) for t in all_feat]
+        self._all_feat_bv = [t[..., :-1, :] for t in av]  # [B, V, N, C] views for the (b,v)-batched adapter
+        if after_encoder is not None:
+            after_encoder()  # lets the caller fork the encoder-only consumers (ViT-Adapter branch) before the decoder
         f = ctx.ln("backbone.enc_norm", x, 1e-6, out_dtype=torch.float32)
         g = ops.linear(f, ctx.w.linear("backbone.decoder_embed"), out_dtype=torch.float32)
         fv = f.view(B, V, N + 1, -1)
         pv = pos.view(B, V, N + 1, 2)
         pos1, pos2 = pv[:, 0].contiguous(), pv[:, 1].contiguous()
         outs1, outs2 = [fv[:, 0]], [fv[:, 1]]
+        # the two decoder sides of a layer are independent (each reads the other's PREVIOUS layer output): side 1 on
+        # the current stream, side 2 on a side stream, joined after every layer; both write straight into the next
+        # (b, v)-major buffer
+        main = torch.cuda.current_stream()
+        side = ctx.side_stream(0) if ctx.concurrent else main
+        if side is not main:
+            side.wait_stream(main)
         for i in range(self.dec_depth):
             gv = g.view(B, V, N + 1, -1)
-            n1 = self._dec_block(f"backbone.dec_blocks.{i}", gv[:, 0], gv[:, 1], pos1, pos2, rope)
-            n2 = self._dec_block(f"backbone.dec_blocks2.{i}", gv[:, 1], gv[:, 0], pos2, pos1, rope)
-            g = torch.stack((n1, n2), dim=1)  # layout plumbing: keep (b, v)-major for the next layer
-            outs1.append(n1)
-            outs2.append(n2)
+            g_next = torch.empty_like(gv)
+            self._dec_block(f"backbone.dec_blocks.{i}", gv[:, 0], gv[:, 1], pos1, pos2, rope, out=g_next[:, 0])
+            with torch.cuda.stream(side):
+                self._dec_block(f"backbone.dec_blocks2.{i}", gv[:, 1], gv[:, 0], pos2, pos1, rope, out=g_next[:, 1])
+            if side is not main:
+                main.wait_stream(side)
+                side.wait_stream(main)
+            g = g_next
+            outs1.append(g_next[:, 0])
+            outs2.append(g_next[:, 1])
         outs1[-1] = ctx.ln("backbone.dec_norm", outs1[-1], 1e-6, out_dtype=torch.float32)
         outs2[-1] = ctx.ln("backbone.dec_norm", outs2[-1], 1e-6, out_dtype=torch.float32)
         strip = lambda t: t[..., :-1, :]
-        av = [t.view(B, V, N + 1, -1) for t in all_feat]
         feat1, feat2 = strip(fv[:, 0]), strip(fv[:, 1])
         all_feat1, all_feat2 = [strip(t[:, 0]) for t in av], [strip(t[:, 1]) for t in av]
         dec1, dec2 = [strip(t) for t in outs1], [strip(t) for t in outs2]
         shape = torch.tensor([[H, W]] * B)
-        self._all_feat_bv = [strip(t) for t in av]  # [B, V, N, C] views for the (b,v)-batched adapter
         res = (feat1, feat2, all_feat1, all_feat2, dec1, dec2, shape, shape.clone())
         if return_views:
             res = res + ({"img": images[:, 0]}, {"img": images[:, 1]})
@@ -635,6 +661,8 @@ class SIU3RModel:
         self.gaussian_adapter = UnifiedGaussianAdapter(sh_degree=sh_degree)
         self.processor = pp.VideoMask2FormerImageProcessor()
         self.raw_gs_dim = (sh_degree + 1) ** 2 * 3 + 3 + 4 + 1
+        self.use_graph = os.environ.get("SIU3R_NO_GRAPH", "0") != "1"
+        self._graphs: Dict = {}
 
     def eval(self):
         return self
@@ -645,36 +673,100 @@ class SIU3RModel:
 
     def forward(self, context_views_images, context_views_intrinsics, mask_labels=None, class_labels=None,
                 enable_query_class_logit_lift=False, return_intermediates=False):
-        """reference signature model.py:314-321."""
+        """reference signature model.py:314-321.
+
+        The network body (everything up to the class/mask logits and the Gaussian parameters) is a fixed launch
+        sequence for a given input shape: the first call of a shape runs it eagerly (packing the weights), the second
+        captures it -- all seven streams of it -- into a HIP graph, later calls replay the graph on fresh copies of the
+        inputs.  At batch 1 the ~1200 launches of one pass cost more host time than GPU time otherwise.  The panoptic
+        post-process (host-visible segment table) always runs eagerly after it.  SIU3R_NO_GRAPH=1 disables capture."""
         assert mask_labels is None and class_labels is None, "inference path only (training losses are out of scope)"
         ctx = self._ctx
         images = context_views_images.to(ctx.dev)
+        K = context_views_intrinsics.to(ctx.dev)
         B, V, _, H, W = images.shape
-        (feat1, feat2, all_feat1, all_feat2, dec1, dec2, shape1, shape2, view1, view2) = self.backbone(
-            {"image": images, "intrinsics": context_views_intrinsics.to(ctx.dev), "near": 0.1, "far": 100}, return_views=True)
-        Z = B * V
-        img_bv = images.reshape(Z, 3, H, W).contiguous().float()
-        img8 = ops.pack_image_nhwc8(img_bv, ctx.act)
-        # the adapter is shared by both views (model.py:342-345): one (b,v)-batched pass
-        allf = [t.reshape(Z, t.shape[2], t.shape[3]) if t.is_contiguous() else t.flatten(0, 1) for t in self.backbone._all_feat_bv]
-        ms_nhwc = self.adapter.forward_nhwc(img_bv, img8, allf)
-        img8_bv = img8.view(B, V, H, W, 8)
-        res1 = self.downstream_head1.forward_pts3d(dec1, H, W)
-        res2 = self.downstream_head2.forward_pts3d(dec2, H, W)
-        gs1 = self.gaussian_param_head1.forward_gs(dec1, img8_bv[:, 0].contiguous(), H, W)
-        gs2 = self.gaussian_param_head2.forward_gs(dec2, img8_bv[:, 1].contiguous(), H, W)
-        means = torch.stack((res1["pts3d"].view(B, H * W, 3), res2["pts3d"].view(B, H * W, 3)), dim=1)
-        raw = torch.stack((gs1.view(B, H * W, -1), gs2.view(B, H * W, -1)), dim=1)
-        gaussians = self.gaussian_adapter.forward(means, raw)
-        seg_out = self.mask2former.forward_nhwc(ms_nhwc, B, V)
+        key = (B, V, H, W, images.dtype, K.dtype)
+        eager = (not self.use_graph) or return_intermediates or ops.kernel_timer_active() or torch.cuda.is_current_stream_capturing()
+        if eager:
+            gaussians, seg_out, inter = self._network(images, K)
+        else:
+            ent = self._graphs.get(key)
+            if ent is None:  # first call of this shape: eager (packs weights, fills the constant caches)
+                self._graphs[key] = {"graph": None}
+                gaussians, seg_out, inter = self._network(images, K)
+            else:
+                if ent["graph"] is None:
+                    ent["images"], ent["K"] = images.clone(), K.clone()
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        ent["out"] = self._network(ent["images"], ent["K"])
+                    ent["graph"] = g
+                ent["images"].copy_(images, non_blocking=True)
+                ent["K"].copy_(K, non_blocking=True)
+                ent["graph"].replay()
+                g_static, seg_out, inter = ent["out"]
+                # results leave the graph's private memory: the next replay overwrites it
+                gaussians = Gaussians(**{f: getattr(g_static, f).clone() for f in Gaussians.FIELDS})
+                seg_out = VideoMask2FormerForVideoSegmentationOutput(seg_out)
+                for k_ in ("class_queries_logits", "masks_queries_logits"):
+                    seg_out[k_] = seg_out[k_].clone()
         results = self.processor.post_process_panoptic_segmentation(
             seg_out, threshold=self.seg_threshold, target_sizes=[(H, W)] * B, label_ids_to_fuse=self.label_ids_to_fuse)
         gaussians, masks, infos, qcl, qscores = pp.post_process_gaussians(gaussians, results, B, V, H, W, enable_query_class_logit_lift)
         if return_intermediates:
-            self._last = dict(dec1=dec1, dec2=dec2, all_feat1=all_feat1, all_feat2=all_feat2, ms=ms_nhwc, pts1=res1["pts3d"],
-                              pts2=res2["pts3d"], gs_raw1=gs1, gs_raw2=gs2, seg_out=seg_out)
+            self._last = inter
         if enable_query_class_logit_lift:
             return gaussians, seg_out, masks, infos, qscores
         return gaussians, seg_out, masks, infos
+
+    def _network(self, images, context_views_intrinsics):
+        """Images + intrinsics (on the GPU) -> Gaussian parameters, segmentation logits.  No host synchronisation."""
+        ctx = self._ctx
+        B, V, _, H, W = images.shape
+        Z = B * V
+        img_bv = images.reshape(Z, 3, H, W).contiguous().float()
+        img8 = ops.pack_image_nhwc8(img_bv, ctx.act)
+        img8_bv = img8.view(B, V, H, W, 8)
+        img8_v = [img8_bv[:, 0].contiguous(), img8_bv[:, 1].contiguous()]
+        main = torch.cuda.current_stream()
+        par = ctx.concurrent
+        seg_stream = ctx.side_stream(1) if par else main
+        box = {}
+
+        def seg_branch():
+            # ViT-Adapter + Mask2Former need only the encoder's features: forked before the decoder starts.
+            # The adapter is shared by both views (model.py:342-345): one (b,v)-batched pass
+            seg_stream.wait_stream(main)
+            with torch.cuda.stream(seg_stream):
+                allf = [t.reshape(Z, t.shape[2], t.shape[3]) if t.is_contiguous() else t.flatten(0, 1) for t in self.backbone._all_feat_bv]
+                box["ms"] = self.adapter.forward_nhwc(img_bv, img8, allf)
+                box["seg"] = self.mask2former.forward_nhwc(box["ms"], B, V)
+
+        (feat1, feat2, all_feat1, all_feat2, dec1, dec2, shape1, shape2, view1, view2) = self.backbone(
+            {"image": images, "intrinsics": context_views_intrinsics, "near": 0.1, "far": 100}, return_views=True,
+            after_encoder=seg_branch)
+        # four independent DPT heads, one stream each
+        hs = [ctx.side_stream(2 + i) if par else main for i in range(3)] + [main]
+        for st in hs[:3]:
+            if st is not main:
+                st.wait_stream(main)
+        with torch.cuda.stream(hs[0]):
+            gs1 = self.gaussian_param_head1.forward_gs(dec1, img8_v[0], H, W)
+        with torch.cuda.stream(hs[1]):
+            gs2 = self.gaussian_param_head2.forward_gs(dec2, img8_v[1], H, W)
+        with torch.cuda.stream(hs[2]):
+            res1 = self.downstream_head1.forward_pts3d(dec1, H, W)
+        res2 = self.downstream_head2.forward_pts3d(dec2, H, W)
+        for st in hs[:3] + [seg_stream]:
+            if st is not main:
+                main.wait_stream(st)
+        ms_nhwc, seg_out = box["ms"], box["seg"]
+        means = torch.stack((res1["pts3d"].view(B, H * W, 3), res2["pts3d"].view(B, H * W, 3)), dim=1)
+        raw = torch.stack((gs1.view(B, H * W, -1), gs2.view(B, H * W, -1)), dim=1)
+        gaussians = self.gaussian_adapter.forward(means, raw)
+        inter = dict(dec1=dec1, dec2=dec2, all_feat1=all_feat1, all_feat2=all_feat2, ms=ms_nhwc, pts1=res1["pts3d"],
+                     pts2=res2["pts3d"], gs_raw1=gs1, gs_raw2=gs2, seg_out=seg_out)
+        return gaussians, seg_out, inter
 
     __call__ = forward

@@ -104,13 +104,23 @@ class KernelTimer:
     Events are recorded on the stream the kernel is launched on (torch's current stream)."""
 
     def __init__(self):
-        self.records = []  # (variant, flops, ev0, ev1)
+        self.records = []  # (variant, flops, ev0, ev1, shape)
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for variant, fl, e0, e1 in self.records:
+        for variant, fl, e0, e1, _ in self.records:
             d = out.setdefault(variant, dict(launches=0, flops=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += fl
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+    def by_shape(self):
+        torch.cuda.synchronize()
+        out = {}
+        for variant, fl, e0, e1, shape in self.records:
+            d = out.setdefault((variant,) + shape, dict(launches=0, flops=0.0, ms=0.0))
             d["launches"] += 1
             d["flops"] += fl
             d["ms"] += e0.elapsed_time(e1)
@@ -125,6 +135,10 @@ def set_kernel_timer(t: Optional[KernelTimer]):
     _timer = t
 
 
+def kernel_timer_active() -> bool:
+    return _timer is not None
+
+
 def _gemm_launch(p: GemmParams):
     if _timer is None:
         check(_lib.lib().siu3r_gemm(C.byref(p), _stream()))
@@ -135,11 +149,20 @@ def _gemm_launch(p: GemmParams):
     e0.record()
     check(_lib.lib().siu3r_gemm(C.byref(p), _stream()))
     e1.record()
-    _timer.records.append((variant, flops, e0, e1))
+    _timer.records.append((variant, flops, e0, e1, (p.m, p.n, p.k, max(1, p.batch), p.a_mode, p.out_mode, p.kh)))
+
+
+_trace_buf: Optional[torch.Tensor] = None  # tools/gemm_trace.py: int64 [workgroups, 8] stamp buffer (tuning only)
+
+
+def set_gemm_trace(buf: Optional[torch.Tensor]):
+    global _trace_buf
+    _trace_buf = buf
 
 
 def _fill_common(p: GemmParams, a, pw: PackedWeight, out, act, residual, relu_in):
     p.a, p.w_hi, p.w_lo, p.c = _p(a), _p(pw.hi), _p(pw.lo), _p(out)
+    p.trace = _p(_trace_buf)
     p.bias = _p(pw.bias)
     p.residual = _p(residual)
     p.n, p.k, p.kpad = pw.n, pw.k, pw.kpad

@@ -399,3 +399,36 @@ def test_split_bf16_exact():
     h = x.bfloat16()
     assert torch.equal(hi[:, :100].cpu(), h)
     assert torch.equal(lo[:, :100].cpu(), (x - h.float()).bfloat16())
+
+
+def test_gemm_wide_tiles_subprocess():
+    """The 128x128-tile variants (A/B option SIU3R_GEMM_NARROW_MAX=0, read at library load) against torch:
+    dense with a K tail, 3x3 conv (uniform-tap mode) with fused input ReLU, 7x7 stem conv (per-lane tap mode)."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import torch, torch.nn.functional as F
+from siu3r_amd import ops
+g = torch.Generator().manual_seed(3)
+r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1)
+a, w, b = r(300, 1096).cuda(), r(200, 1096).cuda() * 0.05, r(200).cuda()
+for adt in (torch.bfloat16, torch.float32):
+    y = ops.linear(a.to(adt), ops.pack_linear(w, b, False), out_dtype=torch.float32)
+    ref = a.to(adt).float() @ w.to(torch.bfloat16).float().t() + b
+    assert (y - ref).abs().max() / ref.abs().max() < 1e-2, "dense"
+x, cw = r(2, 24, 20, 128).cuda(), r(96, 128, 3, 3).cuda() * 0.05
+y = ops.conv2d(x.to(torch.bfloat16), ops.pack_conv(cw, None, False), pad=1, out_dtype=torch.float32, relu_in=True)
+ref = F.conv2d(F.relu(x.to(torch.bfloat16).float()).permute(0, 3, 1, 2), cw.to(torch.bfloat16).float(), padding=1).permute(0, 2, 3, 1)
+assert (y - ref).abs().max() / ref.abs().max() < 1e-2, "conv3x3"
+x, cw = r(1, 40, 36, 8).cuda(), r(80, 8, 7, 7).cuda() * 0.05
+y = ops.conv2d(x.to(torch.bfloat16), ops.pack_conv(cw, None, False), pad=3, out_dtype=torch.float32)
+ref = F.conv2d(x.to(torch.bfloat16).float().permute(0, 3, 1, 2), cw.to(torch.bfloat16).float(), padding=3).permute(0, 2, 3, 1)
+assert (y - ref).abs().max() / ref.abs().max() < 1e-2, "conv7x7"
+print("WIDE_OK")
+'''
+    env = dict(os.environ, SIU3R_GEMM_NARROW_MAX="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert "WIDE_OK" in out.stdout, out.stdout + out.stderr
