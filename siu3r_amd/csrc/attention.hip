@@ -10,6 +10,8 @@
 // of O^T = V^T P^T using a "virtual k" ordering (key(h,j) = 16*sb + (j&3) + 8*(j>>2) + 4*h); V^T is built in
 // LDS with that same ordering in mind, so no cross-lane shuffle is needed between the two GEMMs.
 // SPLIT = bf16x3 mode: Q,K,P,V are split hi+lo and every product uses three MFMAs (~fp32 accuracy).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -310,20 +312,26 @@ __global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
   load_tile(0, r0);
   load_mask(0, mA);
   if (nkt > 1) load_tile(1, r1);
+  // raw barriers: __syncthreads() would drain the two KV tiles in flight (hipcc puts s_waitcnt vmcnt(0) in front of it)
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
   store_tile(0, r0);
-  __syncthreads();
+  lds_barrier();
   for (int kt = 0; kt < nkt; kt += 2) {
     if (kt + 2 < nkt) load_tile(kt + 2, r0);
     if (kt + 1 < nkt) load_mask(kt + 1, mB);
     process(kt, 0, mA);
     if (kt + 1 < nkt) store_tile(1, r1);
-    __syncthreads();
+    lds_barrier();
     if (kt + 1 >= nkt) break;
     if (kt + 3 < nkt) load_tile(kt + 3, r1);
     if (kt + 2 < nkt) load_mask(kt + 2, mA);
     process(kt + 1, 1, mB);
     if (kt + 2 < nkt) store_tile(0, r0);
-    __syncthreads();
+    lds_barrier();
   }
 
   // ---------------- epilogue: O[q, h*D + d] = O^T[d][q] / l ----------------
@@ -348,6 +356,247 @@ __global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
         }
       }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 fast path (no RoPE here -- it is fused into the projection GEMM's epilogue --, no bf16x3 split): the path every
+// attention of the bf16 forward takes.  Same work split and S^T / virtual-k structure as attn_kernel above, but
+//   * K and V tiles go global -> registers -> LDS as raw 16-byte chunks: no unpack/repack, V stays ROW-major
+//     ([key][D], 64-byte halves swapped by key bit 1 for D = 64) and its transpose happens in the LDS read
+//     (ds_read_b64_tr_b16: a 16-lane group fetches a [4 keys][16 d] block and receives it d-major);
+//   * scale * log2(e) rides in the fma that feeds v_exp_f32 (the running maximum stays in raw-score units, so Q is
+//     used as stored: pre-scaling Q would add a bf16 rounding to every logit); the key-validity compare runs
+//     only on a ragged last tile; the O rescale is skipped while no lane's running maximum grows;
+//   * P is packed with v_cvt_pk_bf16_f32; the cross-half maximum / sum use v_permlane32_swap.
+// Per 64-key tile and wave: 16 MFMAs (512 cycles) against ~32 v_exp_f32 (quarter rate, 512 cycles) + ~110 VALU.
+template <int D, int MASK>
+__global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params p) {
+  constexpr int K_BYTES = KT * D * 2;
+  constexpr int V_BYTES = KT * D * 2;
+  constexpr int STAGE = K_BYTES + V_BYTES;
+  constexpr int CH = D / 32;  // 16-byte chunks per thread per tile and tensor
+  constexpr int KS = D / 16;
+  constexpr int DT = D / 32;
+  constexpr int RS = D * 2;   // V row stride in LDS
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4v;  // native vector: stays in registers (HIP's uint4 struct did not)
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q_row = blockIdx.x * 128 + wave * 32 + l31;
+  const bool q_ok = q_row < p.Nq;
+  const float sl2 = p.scale * 1.4426950408889634f;
+
+  // Q fragments (B operand: lane = query, 8 consecutive d per k-substep), raw bf16
+  bf16x8 qf[KS];
+  {
+    const u16* qp = (const u16*)p.q + (int64_t)b * p.q_sb + (int64_t)(q_ok ? q_row : p.Nq - 1) * p.q_sn + (int64_t)h * p.q_sh;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[ks] = as_bf16x8(*(const uint4*)(qp + ks * 16 + 8 * lh));
+    }
+  }
+
+  // staging: thread -> (key = t>>2, chunks ld_c0 + 2c)
+  const int ld_key = t >> 2;
+  const int ld_c0 = (D == 64) ? ((t & 1) + 4 * ((t >> 1) & 1)) : (t & 3);
+  struct KVRegs { u32x4v kb[CH], vb[CH]; };
+  const u16* kbase = (const u16*)p.k + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
+  const u16* vbase = (const u16*)p.v + (int64_t)b * p.v_sb + (int64_t)h * p.v_sh;
+  auto load_tile = [&](int kt, KVRegs& rg) {
+    int key = kt * KT + ld_key;
+    if (key > p.Nk - 1) key = p.Nk - 1;  // clamped: finite garbage, its scores are masked and its P is 0
+    const u16* kp = kbase + (int64_t)key * p.k_sn;
+    const u16* vp = vbase + (int64_t)key * p.v_sn;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      rg.kb[c] = *(const u32x4v*)(kp + (ld_c0 + 2 * c) * 8);
+      rg.vb[c] = *(const u32x4v*)(vp + (ld_c0 + 2 * c) * 8);
+    }
+  };
+  auto store_tile = [&](int stage, const KVRegs& rg) {
+    unsigned char* sK = smem + stage * STAGE;
+    unsigned char* sV = sK + K_BYTES;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = ld_c0 + 2 * c;
+      *(u32x4v*)(sK + k_off<D>(ld_key, ch)) = rg.kb[c];
+      const int pc = (D == 64) ? ((((ch >> 2) ^ ((ld_key >> 1) & 1)) << 2) | (ch & 3)) : ch;
+      *(u32x4v*)(sV + ld_key * RS + pc * 16) = rg.vb[c];
+    }
+  };
+
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+  const int nkt = (p.Nk + KT - 1) / KT;
+  const bool ragged = (p.Nk & (KT - 1)) != 0;
+
+  const uint8_t* mrow = nullptr;
+  if constexpr (MASK) mrow = p.mask + ((int64_t)b * p.Nq + (q_ok ? q_row : p.Nq - 1)) * p.mask_ld;
+  auto load_mask = [&](int kt, uint4 (&mk)[4]) {
+    if constexpr (MASK) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mk[i] = *(const uint4*)(mrow + (int64_t)kt * KT + 16 * i);
+    }
+  };
+
+  // per-lane byte offset of the transposed V reads inside a stage: row (lane&15)>>2 of a 4-key group, 16-d block
+  // (lane>>4)&1, 4-d piece lane&3; the 64-byte half of the row is chosen per read
+  const int i2 = (lane & 15) >> 2;
+  const int v_lane = (4 * lh + i2) * RS + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+  const int v_hswz = (D == 64) ? ((i2 >> 1) & 1) : 0;
+
+  // value held by lane ^ 32.  v_permlane32_swap exchanges the upper half of its first operand with the lower half of
+  // its second: with distinct registers the results are (low half, high half) broadcasts, but when the register
+  // allocator gives both operands the SAME register (it does, inside this kernel) both results are the half-swapped
+  // input.  Selecting r1 in the lower lanes and r0 in the upper ones is the other half's value in either case.
+  auto other_half = [&](float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, lh ? sw[0] : sw[1]);
+  };
+  auto process = [&](int kt, int cur, const uint4 (&mk)[4]) {
+    const unsigned char* sK = smem + cur * STAGE;
+    const unsigned char* sV = sK + K_BYTES;
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = as_bf16x8(*(const uint4*)(sK + k_off<D>(kb * 32 + l31, ks * 2 + lh)));
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
+      }
+    }
+    // lane holds keys key(kb,r) = kt*64 + kb*32 + (r&3) + 8*(r>>2) + 4*lh of query l31
+    if (ragged && kt == nkt - 1) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= p.Nk) sacc[kb][r] = NEG_BIG;
+    }
+    if constexpr (MASK) {
+      const uint32_t* w = (const uint32_t*)&mk[0];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const uint32_t ws = lh ? w[2 * (kb * 4 + g) + 1] : w[2 * (kb * 4 + g)];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if ((ws >> (8 * e)) & 0xffu) sacc[kb][4 * g + e] = NEG_BIG;
+        }
+    }
+    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);  // v_max3_f32
+    mx = fmaxf(mx, other_half(mx));
+    const float m_new = fmaxf(m_run, mx);
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {  // wave-uniform: rescale only when some maximum grew
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+      m_run = m_new;
+    }
+    float psum = 0.f;
+    const float nm = -m_run * sl2;  // exp2((s - m) * sl2) as one fma + v_exp_f32 per score; m tracks the RAW maximum
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][r], sl2, nm));
+        sacc[kb][r] = pv;
+        psum += pv;
+      }
+    l_run += psum;
+
+    // O^T += V^T P^T : B operand = P registers as they are (virtual-k order), A operand = transposed LDS reads
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        float pf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = sacc[kb][8 * sb + j];
+        const bf16x8 ph = as_bf16x8(pack_bf16x8(pf));
+        const int rbase = (kb * 32 + 16 * sb) * RS + v_lane;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int ho = (D == 64) ? ((dt ^ v_hswz) * 64) : 0;
+          auto p0 = (__attribute__((address_space(3))) s16x4*)(sV + rbase + ho);
+          auto p1 = (__attribute__((address_space(3))) s16x4*)(sV + rbase + 8 * RS + ho);
+          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0);
+          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p1);
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, ph, oacc[dt], 0, 0, 0);
+        }
+      }
+  };
+
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  KVRegs r0, r1;
+  uint4 mA[4], mB[4];
+  load_tile(0, r0);
+  load_mask(0, mA);
+  if (nkt > 1) load_tile(1, r1);
+  store_tile(0, r0);
+  lds_barrier();
+  for (int kt = 0; kt < nkt; kt += 2) {
+    if (kt + 2 < nkt) load_tile(kt + 2, r0);
+    if (kt + 1 < nkt) load_mask(kt + 1, mB);
+    process(kt, 0, mA);
+    if (kt + 1 < nkt) store_tile(1, r1);
+    lds_barrier();
+    if (kt + 1 >= nkt) break;
+    if (kt + 3 < nkt) load_tile(kt + 3, r1);
+    if (kt + 2 < nkt) load_mask(kt + 2, mA);
+    process(kt + 1, 1, mB);
+    if (kt + 2 < nkt) store_tile(0, r0);
+    lds_barrier();
+  }
+
+  // epilogue: O[q, h*D + d] = O^T[d][q] / l
+  const float l_tot = l_run + other_half(l_run);
+  const float inv = 1.f / l_tot;
+  if (q_ok) {
+    u16* op = (u16*)p.out + ((int64_t)b * p.Nq + q_row) * ((int64_t)p.H * D) + (int64_t)h * D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + 8 * g + 4 * lh;
+        uint2 w;
+        w.x = pack_bf16x2(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv);
+        w.y = pack_bf16x2(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+        *(uint2*)(op + d) = w;
+      }
+  }
+}
+
+template <int D>
+int launch_fast(const siu3r_attn_params& p, hipStream_t s) {
+  dim3 grid((p.Nq + 127) / 128, p.H, p.B), block(256);
+  if (p.mask)
+    hipLaunchKernelGGL((attn_fast_kernel<D, 1>), grid, block, 0, s, p);
+  else
+    hipLaunchKernelGGL((attn_fast_kernel<D, 0>), grid, block, 0, s, p);
+  SIU3R_LAUNCH_CHECK("siu3r_attention(fast)");
+  return 0;
 }
 
 template <int D, int IN_F32, int SPLIT>
@@ -379,6 +628,8 @@ extern "C" int siu3r_attention(const siu3r_attn_params* pp, void* stream) {
                   p.k_sb % al == 0 && p.v_sn % al == 0 && p.v_sh % al == 0 && p.v_sb % al == 0,
               "siu3r_attention: q/k/v strides must keep 16-byte alignment");
   hipStream_t s = (hipStream_t)stream;
+  static const bool no_fast = getenv("SIU3R_ATTN_NO_FAST") != nullptr;  // A/B switch
+  if (p.dtype == SIU3R_BF16 && !p.split3 && !p.rope_cos && !no_fast) return p.D == 64 ? launch_fast<64>(p, s) : launch_fast<32>(p, s);
   if (p.D == 64) {
     if (p.split3) return launch<64, 1, 1>(p, s);
     if (p.dtype == SIU3R_F32) return launch<64, 1, 0>(p, s);

@@ -33,7 +33,27 @@ void siu3r_set_error(const char* fmt, ...);
   } while (0)
 
 // ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two floats -> packed bf16 pair (x in the low half): one v_cvt_pk_bf16_f32 on gfx950 (round-to-nearest-even)
+__device__ __host__ inline uint32_t pack_bf16x2(float x, float y) {
+#if __HIP_DEVICE_COMPILE__
+  f32x2_t v = {x, y};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+#else
+  auto rne = [](float f) -> uint32_t {
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    if ((v.u & 0x7fffffffu) > 0x7f800000u) return (v.u >> 16) | 0x40;
+    return (v.u + 0x7fffu + ((v.u >> 16) & 1u)) >> 16;
+  };
+  return (rne(x) & 0xffffu) | (rne(y) << 16);
+#endif
+}
 __device__ __host__ inline u16 f32_to_bf16_bits(float f) {
+#if __HIP_DEVICE_COMPILE__
+  return (u16)(pack_bf16x2(f, 0.f) & 0xffffu);
+#endif
   union { float f; uint32_t u; } v;
   v.f = f;
   uint32_t u = v.u;
@@ -89,7 +109,7 @@ __device__ inline void store8_from_f32(void* p, int dtype, int64_t i, const f32x
     uint32_t w[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      w[j] = (uint32_t)f32_to_bf16_bits(r.v[2 * j]) | ((uint32_t)f32_to_bf16_bits(r.v[2 * j + 1]) << 16);
+      w[j] = pack_bf16x2(r.v[2 * j], r.v[2 * j + 1]);
     *(uint4*)((u16*)p + i) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
@@ -99,7 +119,7 @@ __device__ inline uint4 pack_bf16x8(const float* f) {
   uint32_t w[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    w[j] = (uint32_t)f32_to_bf16_bits(f[2 * j]) | ((uint32_t)f32_to_bf16_bits(f[2 * j + 1]) << 16);
+    w[j] = pack_bf16x2(f[2 * j], f[2 * j + 1]);
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 __device__ inline void split_bf16x8(const float* f, uint4& hi, uint4& lo) {
@@ -107,10 +127,9 @@ __device__ inline void split_bf16x8(const float* f, uint4& hi, uint4& lo) {
   uint32_t h[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    u16 a = f32_to_bf16_bits(f[2 * j]), b = f32_to_bf16_bits(f[2 * j + 1]);
-    r[2 * j] = f[2 * j] - bf16_bits_to_f32(a);
-    r[2 * j + 1] = f[2 * j + 1] - bf16_bits_to_f32(b);
-    h[j] = (uint32_t)a | ((uint32_t)b << 16);
+    h[j] = pack_bf16x2(f[2 * j], f[2 * j + 1]);
+    r[2 * j] = f[2 * j] - bf16_bits_to_f32((u16)(h[j] & 0xffffu));
+    r[2 * j + 1] = f[2 * j + 1] - bf16_bits_to_f32((u16)(h[j] >> 16));
   }
   hi = make_uint4(h[0], h[1], h[2], h[3]);
   lo = pack_bf16x8(r);

@@ -180,18 +180,16 @@ class AsymmetricCroCo:
         q = ops.linear(ctx.ln(p + ".norm2", x, 1e-6), ctx.w.linear(p + ".cross_attn.projq"), out_dtype=ctx.act,
                        rope=(rope[0], rope[1], xpos, Cc)).view(B, N, DEC_HEADS, d)
         kv = ops.linear(y_, ctx.w.merged(p + ".cross_attn.projkv", [p + ".cross_attn.projk", p + ".cross_attn.projv"]),
-                        out_dtype=ctx.act, rope=(rope[0], rope[1], ypos, Cc)).view(B, N, 2, DEC_HEADS, d)
+                        out_dtype=ctx.act, rope=(rope[0], rope[1], ypos, Cc)).view(B, y.shape[1], 2, DEC_HEADS, d)
         a = ops.attention(q, kv[:, :, 0], kv[:, :, 1], heads=DEC_HEADS, head_dim=d, scale=d ** -0.5, split3=ctx.split)
         x = ops.linear(a, ctx.w.linear(p + ".cross_attn.proj"), out_dtype=torch.float32, residual=x)
         return self._mlp(p + ".mlp", x, p + ".norm3", out=out)
 
-    def forward(self, context: dict, symmetrize_batch=False, return_views=False, after_encoder=None):
-        """reference signature backbone_croco.py:263-268 (+ after_encoder hook); context = {"image": [B,2,3,H,W], "intrinsics": [B,2,3,3]}."""
-        assert not symmetrize_batch, "symmetrize_batch is a training-time option"
+    # ---- encoder: all B*V views as one batch (backbone_croco.py:270-300)
+    def encode(self, images, K):
         ctx = self.ctx
-        images, K = context["image"], context["intrinsics"]
         B, V, _, H, W = images.shape
-        assert V == 2
+        assert V >= 2
         assert H % 16 == 0, f"Input image height ({H}) is not a multiple of patch size (16)."
         assert W % 16 == 0, f"Input image width ({W}) is not a multiple of patch size (16)."
         h, w = H // 16, W // 16
@@ -216,41 +214,89 @@ class AsymmetricCroCo:
             all_feat.append(x)
         av = [t.view(B, V, N + 1, -1) for t in all_feat]
         self._all_feat_bv = [t[..., :-1, :] for t in av]  # [B, V, N, C] views for the (b,v)-batched adapter
-        if after_encoder is not None:
-            after_encoder()  # lets the caller fork the encoder-only consumers (ViT-Adapter branch) before the decoder
+        return dict(x=x, av=av, pos=pos, rope=rope, dims=(B, V, H, W, N))
+
+    def _ctx_positions(self, B, V, h, w):
+        """positions of the memory tokens of views 1..V-1: the other views in ascending order (generate_ctx_views,
+        backbone_croco.py:528-539).  Constant per shape."""
+        key = ("ctxpos", B, V, h, w)
+        c = self.ctx.cache
+        if key not in c:
+            pv = self._positions(B * V, h, w).view(B, V, h * w + 1, 2)
+            c[key] = torch.stack([torch.cat([pv[:, j] for j in range(V) if j != i], dim=1) for i in range(1, V)], dim=1).flatten(0, 1).contiguous()
+        return c[key]
+
+    # ---- decoder (backbone_croco.py:302-347 for the pair, :541-584 for V views): view 0 runs dec_blocks with the
+    # tokens of all other views as memory; views 1..V-1 run dec_blocks2 (batched), each with the other views' tokens
+    # (ascending view order) as memory.  Every layer reads the PREVIOUS layer's tokens of all views.
+    def decode(self, enc):
+        ctx = self.ctx
+        B, V, H, W, N = enc["dims"]
+        h, w = H // 16, W // 16
+        x, pos, rope = enc["x"], enc["pos"], enc["rope"]
         f = ctx.ln("backbone.enc_norm", x, 1e-6, out_dtype=torch.float32)
-        g = ops.linear(f, ctx.w.linear("backbone.decoder_embed"), out_dtype=torch.float32)
+        g = ops.linear(f, ctx.w.linear("backbone.decoder_embed"), out_dtype=torch.float32).view(B, V, N + 1, -1)
         fv = f.view(B, V, N + 1, -1)
         pv = pos.view(B, V, N + 1, 2)
-        pos1, pos2 = pv[:, 0].contiguous(), pv[:, 1].contiguous()
-        outs1, outs2 = [fv[:, 0]], [fv[:, 1]]
-        # the two decoder sides of a layer are independent (each reads the other's PREVIOUS layer output): side 1 on
-        # the current stream, side 2 on a side stream, joined after every layer; both write straight into the next
-        # (b, v)-major buffer
+        pos0 = pv[:, 0].contiguous()
+        if V == 2:
+            pos_rest, mem0_pos, memr_pos = pv[:, 1].contiguous(), pv[:, 1].contiguous(), pos0
+        else:
+            pos_rest = pv[:, 1:].reshape(B * (V - 1), N + 1, 2).contiguous()
+            mem0_pos = pv[:, 1:].reshape(B, (V - 1) * (N + 1), 2).contiguous()
+            memr_pos = self._ctx_positions(B, V, h, w)
+        layers = [fv]
+        # the two sides of a layer are independent: view 0 on the current stream, the other views on a side stream,
+        # joined after every layer; both write straight into the next (b, v)-major buffer
         main = torch.cuda.current_stream()
         side = ctx.side_stream(0) if ctx.concurrent else main
         if side is not main:
             side.wait_stream(main)
+        direct = V == 2 or B == 1  # views 1.. of g_next form one strided batch
         for i in range(self.dec_depth):
-            gv = g.view(B, V, N + 1, -1)
-            g_next = torch.empty_like(gv)
-            self._dec_block(f"backbone.dec_blocks.{i}", gv[:, 0], gv[:, 1], pos1, pos2, rope, out=g_next[:, 0])
+            g_next = torch.empty_like(g)
+            mem0 = g[:, 1] if V == 2 else g[:, 1:].reshape(B, (V - 1) * (N + 1), -1)
+            self._dec_block(f"backbone.dec_blocks.{i}", g[:, 0], mem0, pos0, mem0_pos, rope, out=g_next[:, 0])
             with torch.cuda.stream(side):
-                self._dec_block(f"backbone.dec_blocks2.{i}", gv[:, 1], gv[:, 0], pos2, pos1, rope, out=g_next[:, 1])
+                if V == 2:
+                    xr, memr, outr = g[:, 1], g[:, 0], g_next[:, 1]
+                else:
+                    xr = g[:, 1:].reshape(B * (V - 1), N + 1, -1)
+                    memr = torch.stack([torch.cat([g[:, j] for j in range(V) if j != v], dim=1) for v in range(1, V)], dim=1).flatten(0, 1)
+                    outr = g_next[0, 1:] if B == 1 else None
+                r = self._dec_block(f"backbone.dec_blocks2.{i}", xr, memr, pos_rest, memr_pos, rope, out=outr)
+                if not direct:
+                    g_next[:, 1:].copy_(r.view(B, V - 1, N + 1, -1))
             if side is not main:
                 main.wait_stream(side)
                 side.wait_stream(main)
             g = g_next
-            outs1.append(g_next[:, 0])
-            outs2.append(g_next[:, 1])
-        outs1[-1] = ctx.ln("backbone.dec_norm", outs1[-1], 1e-6, out_dtype=torch.float32)
-        outs2[-1] = ctx.ln("backbone.dec_norm", outs2[-1], 1e-6, out_dtype=torch.float32)
+            layers.append(g_next)
+        last = ctx.ln("backbone.dec_norm", layers[-1].reshape(B * V, N + 1, -1), 1e-6, out_dtype=torch.float32)
+        layers[-1] = last.view(B, V, N + 1, -1)
+        return dict(layers=layers, fv=fv)
+
+    def _assemble(self, enc, dec):
         strip = lambda t: t[..., :-1, :]
-        feat1, feat2 = strip(fv[:, 0]), strip(fv[:, 1])
-        all_feat1, all_feat2 = [strip(t[:, 0]) for t in av], [strip(t[:, 1]) for t in av]
-        dec1, dec2 = [strip(t) for t in outs1], [strip(t) for t in outs2]
+        B, V, H, W, N = enc["dims"]
+        feats = [strip(dec["fv"][:, v]) for v in range(V)]
+        all_feats = [[strip(t[:, v]) for t in enc["av"]] for v in range(V)]
+        decs = [[strip(t[:, v]) for t in dec["layers"]] for v in range(V)]
+        return feats, all_feats, decs
+
+    def forward(self, context: dict, symmetrize_batch=False, return_views=False, after_encoder=None):
+        """reference signature backbone_croco.py:263-268 (+ after_encoder hook); context = {"image": [B,2,3,H,W], "intrinsics": [B,2,3,3]}."""
+        assert not symmetrize_batch, "symmetrize_batch is a training-time option"
+        images, K = context["image"], context["intrinsics"]
+        B, V, _, H, W = images.shape
+        assert V == 2, "AsymmetricCroCo is the two-view backbone; use AsymmetricCroCoMulti for more views"
+        enc = self.encode(images, K)
+        if after_encoder is not None:
+            after_encoder()  # lets the caller fork the encoder-only consumers (ViT-Adapter branch) before the decoder
+        dec = self.decode(enc)
+        feats, all_feats, decs = self._assemble(enc, dec)
         shape = torch.tensor([[H, W]] * B)
-        res = (feat1, feat2, all_feat1, all_feat2, dec1, dec2, shape, shape.clone())
+        res = (feats[0], feats[1], all_feats[0], all_feats[1], decs[0], decs[1], shape, shape.clone())
         if return_views:
             res = res + ({"img": images[:, 0]}, {"img": images[:, 1]})
         return res
@@ -264,6 +310,26 @@ class AsymmetricCroCo:
     @property
     def d_out(self):
         return 1024
+
+
+class AsymmetricCroCoMulti(AsymmetricCroCo):
+    """V >= 2 context views (reference backbone_croco.py:350-590): same weights and blocks as AsymmetricCroCo; view 0
+    decodes with dec_blocks, views 1..V-1 with dec_blocks2."""
+
+    def forward(self, context: dict, symmetrize_batch=False, return_views=False):
+        assert not symmetrize_batch, "symmetrize_batch is a training-time option"
+        images, K = context["image"], context["intrinsics"]
+        B, V, _, H, W = images.shape
+        enc = self.encode(images, K)
+        dec = self.decode(enc)
+        feats, all_feats, decs = self._assemble(enc, dec)
+        shapes = [torch.tensor([[H, W]] * B) for _ in range(V)]
+        res = (feats, all_feats, decs, shapes)
+        if return_views:
+            res = res + ([{"img": images[:, v]} for v in range(V)],)
+        return res
+
+    __call__ = forward
 
 
 # ==================================================================================================
@@ -640,6 +706,15 @@ class VideoMask2FormerForVideoSegmentation:
 # ==================================================================================================
 # whole model (model.py:31-389)
 # ==================================================================================================
+class _Run:
+    """State of one pass through the network body (the static buffers of a captured shape, in graph mode)."""
+
+    def __init__(self, images, K):
+        self.images, self.K = images, K
+        self.img_bv = self.img8 = self.enc = self.dec = self.ms = self.seg = self.gaussians = None
+        self.gs, self.pts = [None, None], [None, None]
+
+
 class SIU3RModel:
     def __init__(self, state_dict: Dict[str, torch.Tensor], image_size=(512, 512), precision="bf16", device="cuda",
                  num_queries=100, seg_threshold=0.5, label_ids_to_fuse=(0, 1), sh_degree=4):
@@ -673,13 +748,15 @@ class SIU3RModel:
 
     def forward(self, context_views_images, context_views_intrinsics, mask_labels=None, class_labels=None,
                 enable_query_class_logit_lift=False, return_intermediates=False):
-        """reference signature model.py:314-321.
+        """reference signature model.py:314-321 (V = 2) / model_multi.py (V >= 2 context views).
 
-        The network body (everything up to the class/mask logits and the Gaussian parameters) is a fixed launch
-        sequence for a given input shape: the first call of a shape runs it eagerly (packing the weights), the second
-        captures it -- all seven streams of it -- into a HIP graph, later calls replay the graph on fresh copies of the
-        inputs.  At batch 1 the ~1200 launches of one pass cost more host time than GPU time otherwise.  The panoptic
-        post-process (host-visible segment table) always runs eagerly after it.  SIU3R_NO_GRAPH=1 disables capture."""
+        The network body is a fixed launch sequence per input shape, made of independent chains: encoder ->
+        {ViT-Adapter + Mask2Former | decoder -> four DPT heads} -> Gaussian adapter.  Eager mode enqueues the chains
+        on separate HIP streams.  From the third call of a shape on, every chain is replayed from its own HIP graph
+        (captured at the second call; the first packs the weights), the graphs launched on those same streams: at
+        batch 1 the ~1100 launches of a pass otherwise cost more host time than GPU time, and ONE graph for the
+        whole body serialises its branches on this runtime.  The panoptic post-process (host-visible segment table)
+        always runs eagerly afterwards.  SIU3R_NO_GRAPH=1 / SIU3R_NO_STREAMS=1 disable the two mechanisms."""
         assert mask_labels is None and class_labels is None, "inference path only (training losses are out of scope)"
         ctx = self._ctx
         images = context_views_images.to(ctx.dev)
@@ -687,86 +764,137 @@ class SIU3RModel:
         B, V, _, H, W = images.shape
         key = (B, V, H, W, images.dtype, K.dtype)
         eager = (not self.use_graph) or return_intermediates or ops.kernel_timer_active() or torch.cuda.is_current_stream_capturing()
-        if eager:
-            gaussians, seg_out, inter = self._network(images, K)
+        ent = None if eager else self._graphs.get(key)
+        if eager or ent is None:
+            if not eager:
+                self._graphs[key] = {"graphs": None}  # first call of this shape: eager (packs weights, fills caches)
+            st = _Run(images, K)
+            self._run_stages(st, lambda name, fn: fn())
+            gaussians, seg_out = st.gaussians, st.seg
         else:
-            ent = self._graphs.get(key)
-            if ent is None:  # first call of this shape: eager (packs weights, fills the constant caches)
-                self._graphs[key] = {"graph": None}
-                gaussians, seg_out, inter = self._network(images, K)
-            else:
-                if ent["graph"] is None:
-                    ent["images"], ent["K"] = images.clone(), K.clone()
-                    torch.cuda.synchronize()
+            if ent["graphs"] is None:
+                st = ent["st"] = _Run(images.clone(), K.clone())
+                ent["graphs"] = {}
+                torch.cuda.synchronize()
+                conc, ctx.concurrent = ctx.concurrent, False  # a captured chain is serial by construction
+
+                def capture(name, fn):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
-                        ent["out"] = self._network(ent["images"], ent["K"])
-                    ent["graph"] = g
-                ent["images"].copy_(images, non_blocking=True)
-                ent["K"].copy_(K, non_blocking=True)
-                ent["graph"].replay()
-                g_static, seg_out, inter = ent["out"]
-                # results leave the graph's private memory: the next replay overwrites it
-                gaussians = Gaussians(**{f: getattr(g_static, f).clone() for f in Gaussians.FIELDS})
-                seg_out = VideoMask2FormerForVideoSegmentationOutput(seg_out)
-                for k_ in ("class_queries_logits", "masks_queries_logits"):
-                    seg_out[k_] = seg_out[k_].clone()
+                        fn()
+                    ent["graphs"][name] = g
+
+                try:
+                    for name, fn in self._stages(st):
+                        capture(name, fn)
+                finally:
+                    ctx.concurrent = conc
+                torch.cuda.synchronize()
+            st = ent["st"]
+            st.images.copy_(images, non_blocking=True)
+            st.K.copy_(K, non_blocking=True)
+            self._run_stages(st, lambda name, fn: ent["graphs"][name].replay())
+            # results leave the graphs' private memory: the next replay overwrites it
+            gaussians = Gaussians(**{f: getattr(st.gaussians, f).clone() for f in Gaussians.FIELDS})
+            seg_out = VideoMask2FormerForVideoSegmentationOutput(st.seg)
+            for k_ in ("class_queries_logits", "masks_queries_logits"):
+                seg_out[k_] = seg_out[k_].clone()
         results = self.processor.post_process_panoptic_segmentation(
             seg_out, threshold=self.seg_threshold, target_sizes=[(H, W)] * B, label_ids_to_fuse=self.label_ids_to_fuse)
         gaussians, masks, infos, qcl, qscores = pp.post_process_gaussians(gaussians, results, B, V, H, W, enable_query_class_logit_lift)
         if return_intermediates:
-            self._last = inter
+            _, _, decs = self.backbone._assemble(st.enc, st.dec)
+            all1 = [t[:, 0, :-1] for t in st.enc["av"]]
+            all2 = [t[:, 1, :-1] for t in st.enc["av"]]
+            self._last = dict(dec1=decs[0], dec2=decs[1], decs=decs, all_feat1=all1, all_feat2=all2, ms=st.ms, pts1=st.pts[0],
+                              pts2=st.pts[1], gs_raw1=st.gs[0], gs_raw2=st.gs[1], seg_out=st.seg)
         if enable_query_class_logit_lift:
             return gaussians, seg_out, masks, infos, qscores
         return gaussians, seg_out, masks, infos
 
-    def _network(self, images, context_views_intrinsics):
-        """Images + intrinsics (on the GPU) -> Gaussian parameters, segmentation logits.  No host synchronisation."""
+    # ---- the chains of the network body.  Each stage only reads what earlier stages left in the _Run
+    def _stages(self, st):
+        return [("encode", lambda: self._s_encode(st)), ("seg", lambda: self._s_seg(st)), ("decode", lambda: self._s_decode(st)),
+                ("gs0", lambda: self._s_head(st, 0)), ("gsr", lambda: self._s_head(st, 1)), ("pts0", lambda: self._s_head(st, 2)),
+                ("ptsr", lambda: self._s_head(st, 3)), ("tail", lambda: self._s_tail(st))]
+
+    def _run_stages(self, st, run):
+        """Enqueue the stages with their fork/join edges.  run(name, fn) either calls fn (eager) or replays its graph."""
         ctx = self._ctx
-        B, V, _, H, W = images.shape
-        Z = B * V
-        img_bv = images.reshape(Z, 3, H, W).contiguous().float()
-        img8 = ops.pack_image_nhwc8(img_bv, ctx.act)
-        img8_bv = img8.view(B, V, H, W, 8)
-        img8_v = [img8_bv[:, 0].contiguous(), img8_bv[:, 1].contiguous()]
+        stages = dict(self._stages(st))
         main = torch.cuda.current_stream()
         par = ctx.concurrent
+        run("encode", stages["encode"])
         seg_stream = ctx.side_stream(1) if par else main
-        box = {}
-
-        def seg_branch():
-            # ViT-Adapter + Mask2Former need only the encoder's features: forked before the decoder starts.
-            # The adapter is shared by both views (model.py:342-345): one (b,v)-batched pass
+        if par:
             seg_stream.wait_stream(main)
-            with torch.cuda.stream(seg_stream):
-                allf = [t.reshape(Z, t.shape[2], t.shape[3]) if t.is_contiguous() else t.flatten(0, 1) for t in self.backbone._all_feat_bv]
-                box["ms"] = self.adapter.forward_nhwc(img_bv, img8, allf)
-                box["seg"] = self.mask2former.forward_nhwc(box["ms"], B, V)
-
-        (feat1, feat2, all_feat1, all_feat2, dec1, dec2, shape1, shape2, view1, view2) = self.backbone(
-            {"image": images, "intrinsics": context_views_intrinsics, "near": 0.1, "far": 100}, return_views=True,
-            after_encoder=seg_branch)
-        # four independent DPT heads, one stream each
+        with torch.cuda.stream(seg_stream):  # needs only the encoder's features: overlaps the decoder and the heads
+            run("seg", stages["seg"])
+        run("decode", stages["decode"])
         hs = [ctx.side_stream(2 + i) if par else main for i in range(3)] + [main]
-        for st in hs[:3]:
-            if st is not main:
-                st.wait_stream(main)
-        with torch.cuda.stream(hs[0]):
-            gs1 = self.gaussian_param_head1.forward_gs(dec1, img8_v[0], H, W)
-        with torch.cuda.stream(hs[1]):
-            gs2 = self.gaussian_param_head2.forward_gs(dec2, img8_v[1], H, W)
-        with torch.cuda.stream(hs[2]):
-            res1 = self.downstream_head1.forward_pts3d(dec1, H, W)
-        res2 = self.downstream_head2.forward_pts3d(dec2, H, W)
-        for st in hs[:3] + [seg_stream]:
-            if st is not main:
-                main.wait_stream(st)
-        ms_nhwc, seg_out = box["ms"], box["seg"]
-        means = torch.stack((res1["pts3d"].view(B, H * W, 3), res2["pts3d"].view(B, H * W, 3)), dim=1)
-        raw = torch.stack((gs1.view(B, H * W, -1), gs2.view(B, H * W, -1)), dim=1)
-        gaussians = self.gaussian_adapter.forward(means, raw)
-        inter = dict(dec1=dec1, dec2=dec2, all_feat1=all_feat1, all_feat2=all_feat2, ms=ms_nhwc, pts1=res1["pts3d"],
-                     pts2=res2["pts3d"], gs_raw1=gs1, gs_raw2=gs2, seg_out=seg_out)
-        return gaussians, seg_out, inter
+        for s_ in hs[:3]:
+            if s_ is not main:
+                s_.wait_stream(main)
+        for name, s_ in zip(("gs0", "gsr", "pts0", "ptsr"), hs):
+            with torch.cuda.stream(s_):
+                run(name, stages[name])
+        for s_ in hs[:3] + [seg_stream]:
+            if s_ is not main:
+                main.wait_stream(s_)
+        run("tail", stages["tail"])
+
+    def _s_encode(self, st):
+        ctx = self._ctx
+        B, V, _, H, W = st.images.shape
+        st.img_bv = st.images.reshape(B * V, 3, H, W).contiguous().float()
+        st.img8 = ops.pack_image_nhwc8(st.img_bv, ctx.act)
+        st.enc = self.backbone.encode(st.images, st.K)
+
+    def _s_seg(self, st):
+        # the adapter is shared by all views (model.py:342-345): one (b,v)-batched pass; Mask2Former sees T = V frames
+        B, V, _, H, W = st.images.shape
+        Z = B * V
+        allf = [t[..., :-1, :] for t in st.enc["av"]]
+        allf = [t.reshape(Z, t.shape[2], t.shape[3]) if t.is_contiguous() else t.flatten(0, 1) for t in allf]
+        st.ms = self.adapter.forward_nhwc(st.img_bv, st.img8, allf)
+        st.seg = self.mask2former.forward_nhwc(st.ms, B, V)
+
+    def _s_decode(self, st):
+        st.dec = self.backbone.decode(st.enc)
+
+    @staticmethod
+    def _rest_views(t):
+        """[B, V, ...] -> views 1..V-1 as one batch [B*(V-1), ...] (a view when possible, else a copy)."""
+        r = t[:, 1:]
+        return r[0] if t.shape[0] == 1 else (r[:, 0] if t.shape[1] == 2 else r.reshape(-1, *t.shape[2:]))
+
+    def _s_head(self, st, i):
+        """i = 0: GS head of view 0 (gaussian_param_head1), 1: GS head of views 1.. (head2), 2 / 3: the pts3d heads."""
+        B, V, _, H, W = st.images.shape
+        first = i in (0, 2)
+        toks = [(t[:, 0] if first else self._rest_views(t))[..., :-1, :] for t in st.dec["layers"]]
+        if i < 2:
+            img8 = st.img8.view(B, V, H, W, 8)
+            img = (img8[:, 0] if first else self._rest_views(img8)).contiguous()
+            head = self.gaussian_param_head1 if first else self.gaussian_param_head2
+            st.gs[0 if first else 1] = head.forward_gs(toks, img, H, W)
+        else:
+            head = self.downstream_head1 if first else self.downstream_head2
+            st.pts[0 if first else 1] = head.forward_pts3d(toks, H, W)["pts3d"]
+
+    def _s_tail(self, st):
+        B, V, _, H, W = st.images.shape
+        cat = lambda a, b_: torch.cat((a.reshape(B, 1, H * W, -1), b_.reshape(B, V - 1, H * W, -1)), dim=1)
+        st.gaussians = self.gaussian_adapter.forward(cat(st.pts[0], st.pts[1]), cat(st.gs[0], st.gs[1]))
 
     __call__ = forward
+
+
+class SIU3RMultiViewModel(SIU3RModel):
+    """V >= 2 context views (reference src/models/model_multi.py): view 0 is decoded by dec_blocks / *_head1, every
+    other view by dec_blocks2 / *_head2 (batched here); ViT-Adapter per view, Mask2Former over T = V frames.
+    The forward signature and the returned tuple are SIU3RModel's; with V = 2 the two classes compute the same thing."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.backbone = AsymmetricCroCoMulti(self._ctx)

@@ -432,3 +432,41 @@ print("WIDE_OK")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert "WIDE_OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
+@pytest.mark.parametrize("case", [(2, 3, 257, 300, 64, False), (2, 8, 100, 520, 32, True), (1, 2, 128, 64, 64, True)], ids=["d64", "d32mask", "d64mask1tile"])
+def test_attention_peaky(mode, case):
+    """Concentrated softmax (|logit| up to ~40): with near-uniform weights a wrong key<->value pairing, a wrong row
+    maximum or a wrong normaliser hides inside the bf16 tolerance; here every one of them is an O(1) error.
+    Also covers a structured one-hot case whose answer is exact (weights one-hot, values = key index)."""
+    ops = _ops()
+    name, adt, split, tol = mode
+    B, H, Nq, Nk, D, use_mask = case
+    q, k, v = gen(B, Nq, H, D, seed=40, scale=6.0), gen(B, Nk, H, D, seed=41, scale=6.0), gen(B, Nk, H, D, seed=42)
+    mask = mpad = None
+    if use_mask:
+        mask = torch.rand(B, Nq, Nk, generator=torch.Generator().manual_seed(5)) < 0.7
+        mask[:, :, 0] = False
+        ld = (Nk + 63) // 64 * 64
+        mpad = torch.ones(B, Nq, ld, dtype=torch.uint8)
+        mpad[:, :, :Nk] = mask.to(torch.uint8)
+        mpad = mpad.cuda()
+    dev = lambda t: t.cuda().to(adt)
+    out = ops.attention(dev(q), dev(k), dev(v), heads=H, head_dim=D, scale=D ** -0.5, mask=mpad, split3=split)
+    # without the bf16x3 split the kernel rounds its operands to bf16: the reference sees the same rounded inputs
+    rdt = adt if split else torch.bfloat16
+    ref = _attn_ref(q.to(rdt).float(), k.to(rdt).float(), v.to(rdt).float(), D ** -0.5, mask=mask)
+    check(f"attention_peaky[{name},{case}]", out, ref, tol)
+    # one-hot weights: query i selects key i % Nk exactly; value column 0 = key index, column 1 = 1
+    q1, k1, v1 = torch.zeros(1, Nq, 1, D), torch.zeros(1, min(Nk, D), 1, D), torch.zeros(1, min(Nk, D), 1, D)
+    n1 = k1.shape[1]
+    for i in range(Nq):
+        q1[0, i, 0, i % n1] = 8.0
+    for j in range(n1):
+        k1[0, j, 0, j] = 8.0
+    v1[0, :, 0, 0] = torch.arange(n1).float()
+    v1[0, :, 0, 1] = 1.0
+    o1 = ops.attention(dev(q1), dev(k1), dev(v1), heads=1, head_dim=D, scale=1.0, split3=split).float().cpu()[0]
+    assert torch.equal(o1[:, 0].round().long(), torch.arange(Nq) % n1), "one-hot attention selected the wrong keys"
+    assert float((o1[:, 1] - 1).abs().max()) < 1e-2

@@ -23,8 +23,13 @@ for mode in (True, False):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): m(imgs[0], K, enable_query_class_logit_lift=True)
     torch.cuda.synchronize(); print("graph" if mode else "eager", (time.perf_counter() - t0) * 100, "ms/step")
-os.environ["X"]="1"
 m._ctx.concurrent = False
+m.use_graph = True
+m._graphs.clear()
+for _ in range(3): m(imgs[0], K, enable_query_class_logit_lift=True)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10): m(imgs[0], K, enable_query_class_logit_lift=True)
+torch.cuda.synchronize(); print("graph single-stream", (time.perf_counter() - t0) * 100, "ms/step")
 m.use_graph = False
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): m(imgs[0], K, enable_query_class_logit_lift=True)
