@@ -184,6 +184,60 @@ def backbone(w: W, images: T, intrinsics: T, enc_heads=16, dec_heads=12):
     )
 
 
+def backbone_multi(w: W, images: T, intrinsics: T, enc_heads=16, dec_heads=12):
+    """AsymmetricCroCoMulti.forward (backbone_croco.py:541-590) for V >= 2 context views.
+
+    Same weights as the pair model.  Decoder (_decoder, :486-539): view 0 runs dec_blocks with the tokens of all
+    other views as memory; views 1..V-1 run dec_blocks2, each with the other views' tokens in ascending view order
+    (generate_ctx_views, :500-506).  Returns per-view lists: feats[v], all_feats[v][24], decs[v][13], token stripped."""
+    B, V, _, H, Wd = images.shape
+    assert V >= 2 and H % 16 == 0 and Wd % 16 == 0
+    emb = _lin(w, "backbone.intrinsic_encoder", intrinsics.flatten(2))  # [B,V,1024]
+    img = images.flatten(0, 1)                                           # (b v) major (:552)
+    itok = emb.flatten(0, 1).unsqueeze(1)
+    x = _conv(w, "backbone.patch_embed.proj", img, stride=16)
+    h, w_ = x.shape[2], x.shape[3]
+    x = x.flatten(2).transpose(1, 2)
+    pos = patch_positions(B * V, h, w_)
+    x = torch.cat((x, itok), dim=1)
+    add_pos = pos[:, 0:1, :].clone()
+    add_pos[:, :, 0] += pos[:, -1, 0].unsqueeze(-1) + 1
+    pos = torch.cat((pos, add_pos), dim=1)
+    n_enc = len({k.split(".")[2] for k in w if k.startswith("backbone.enc_blocks.")})
+    all_feat = []
+    for i in range(n_enc):
+        x = enc_block(w, f"backbone.enc_blocks.{i}", x, pos, enc_heads)
+        all_feat.append(x)
+    x = _ln(w, "backbone.enc_norm", x, 1e-6)
+    L = x.shape[1]
+    feat = x.view(B, V, L, -1)
+    pose = pos.view(B, V, L, 2)
+
+    def ctx_views(t):  # [B,V,L,C] -> [B,V,(V-1)L,C]: for view i the other views, ascending
+        return torch.stack([torch.cat([t[:, j] for j in range(V) if j != i], dim=1) for i in range(V)], dim=1)
+
+    pos_ctx = ctx_views(pose)
+    outs = [feat]
+    g = _lin(w, "backbone.decoder_embed", x).view(B, V, L, -1)
+    n_dec = len({k.split(".")[2] for k in w if k.startswith("backbone.dec_blocks.")})
+    for i in range(n_dec):
+        gc = ctx_views(g)
+        f1 = dec_block(w, f"backbone.dec_blocks.{i}", g[:, 0], gc[:, 0], pose[:, 0], pos_ctx[:, 0], dec_heads)
+        f2 = dec_block(w, f"backbone.dec_blocks2.{i}", g[:, 1:].flatten(0, 1), gc[:, 1:].flatten(0, 1),
+                       pose[:, 1:].flatten(0, 1), pos_ctx[:, 1:].flatten(0, 1), dec_heads)
+        g = torch.cat((f1.unsqueeze(1), f2.view(B, V - 1, L, -1)), dim=1)
+        outs.append(g)
+    outs[-1] = _ln(w, "backbone.dec_norm", outs[-1].flatten(0, 1), 1e-6).view(B, V, L, -1)
+    strip = lambda t: t[..., :-1, :]
+    af = [t.view(B, V, L, -1) for t in all_feat]
+    return dict(
+        feats=[strip(feat[:, v]) for v in range(V)],
+        all_feats=[[strip(t[:, v]) for t in af] for v in range(V)],
+        decs=[[strip(t[:, v]) for t in outs] for v in range(V)],
+        hw=(h, w_),
+    )
+
+
 # ----------------------------------------------------------------------------------------
 # DPT heads (heads/dpt_block.py, dpt_head.py:36-79, dpt_gs_head.py:121-171, postprocess.py:22-63)
 # ----------------------------------------------------------------------------------------
@@ -707,4 +761,35 @@ def model_forward(w: W, images: T, intrinsics: T, keep_intermediates: bool = Tru
     if keep_intermediates:
         out.update(bb=bb, ms1=ms1, ms2=ms2, pts1=pts1, pts2=pts2, gs_raw1=gs1, gs_raw2=gs2,
                    mask_features=mask_features, ms=ms, m2f_extra=extra)
+    return out
+
+
+def model_forward_multi(w: W, images: T, intrinsics: T, keep_intermediates: bool = True) -> Dict[str, object]:
+    """SIU3RMultiViewModel.forward (model_multi.py:314-389): view 0 -> *_head1, every other view -> *_head2;
+    the adapter runs per view, Mask2Former over T = V frames."""
+    B, V, _, H, Wd = images.shape
+    bb = backbone_multi(w, images, intrinsics)
+    ms_v = [adapter(w, images[:, v], bb["all_feats"][v]) for v in range(V)]
+    pts = [pts3d_head(w, "downstream_head1" if v == 0 else "downstream_head2", bb["decs"][v], H, Wd) for v in range(V)]
+    gs = [gs_head(w, "gaussian_param_head1" if v == 0 else "gaussian_param_head2", bb["decs"][v], images[:, v], H, Wd) for v in range(V)]
+    means = torch.stack([p.reshape(B, H * Wd, 3) for p in pts], dim=1)
+    raw = torch.stack(gs, dim=1)
+    g = gaussian_adapter(means, raw)
+    feats = [torch.stack([ms_v[v][l] for v in range(V)], dim=1).flatten(0, 1) for l in range(len(ms_v[0]))]
+    mask_features, ms = pixel_decoder(w, feats)
+    class_logits, mask_logits, extra = m2f_decoder(w, ms, mask_features, B, V)
+    results = panoptic_postprocess(class_logits, mask_logits, (H, Wd))
+    sem, ins = scatter_labels(results, B, V, H, Wd)
+    out = dict(
+        means=g["means"].flatten(1, 2), covariances=g["covariances"].flatten(1, 2),
+        harmonics=g["harmonics"].flatten(1, 2), opacities=g["opacities"].flatten(1, 2),
+        scales=g["scales"].flatten(1, 2), rotations=g["rotations"].flatten(1, 2),
+        semantic_labels=sem, instance_labels=ins,
+        class_queries_logits=class_logits, masks_queries_logits=mask_logits,
+        seg_masks=[r["segmentation"] for r in results], seg_infos=[r["segments_info"] for r in results],
+        query_class_logits=[r["query_class_logits"] for r in results],
+        query_scores=[r["query_scores"] for r in results],
+    )
+    if keep_intermediates:
+        out.update(bb=bb, ms_v=ms_v, pts=pts, gs_raw=gs, mask_features=mask_features, ms=ms)
     return out

@@ -76,6 +76,32 @@ def model_fixture(size, sd):
     print("model fixture", size, "done")
 
 
+def multi_fixture(sd, size=128, V=3):
+    """SIU3RMultiViewModel (src/models/model_multi.py) on V = 3 views: the asset pair + the first image mirrored."""
+    model = R.build_reference_model((size, size), multi=True)
+    model.load_state_dict(sd, strict=False)  # backbone.mask_token (unused at inference) is not in the key spec
+    pair = load_pair(size)[0]
+    img = torch.stack((pair[0], pair[1], pair[0].flip(-1)))[None]
+    K = torch.tensor([[318 / 256, 0, 0.5], [0, 318 / 256, 0.5], [0, 0, 1]])[None, None].repeat(1, V, 1, 1)
+    with torch.no_grad():
+        g, seg, masks, infos, qs = model(img, K, enable_query_class_logit_lift=True)
+    out = {}
+    for f in ("means", "covariances", "harmonics", "opacities", "scales", "rotations"):
+        for k, v in summarize(getattr(g, f)).items():
+            out[f"{f}.{k}"] = np.asarray(v)
+    for name, t in (("class_queries_logits", seg.class_queries_logits), ("masks_queries_logits", seg.masks_queries_logits)):
+        for k, v in summarize(t).items():
+            out[f"{name}.{k}"] = np.asarray(v)
+    out["class_queries_logits.full"] = seg.class_queries_logits.numpy()
+    out["semantic_labels.sum"] = np.asarray(int(g.semantic_labels.sum()))
+    out["instance_labels.sum"] = np.asarray(int(g.instance_labels.sum()))
+    np.savez_compressed(os.path.join(HERE, f"model_multi_v{V}_{size}.npz"), **out)
+    with open(os.path.join(HERE, f"model_multi_v{V}_{size}.json"), "w") as fh:
+        json.dump(dict(seg_infos=infos, query_scores=qs, input="asset pair + image1 mirrored, /255, bilinear to size", views=V,
+                       intrinsics="fx=fy=318/256, c=0.5", weights="oracle.weights.make_weights(0)", stride=STRIDE), fh)
+    print("multi-view fixture done")
+
+
 def panoptic_fixture():
     from src.models.mask2former.image_processing_video_mask2former import VideoMask2FormerImageProcessor
     from src.models.mask2former.video_seg_decoder import VideoMask2FormerForVideoSegmentationOutput as Out
@@ -158,5 +184,6 @@ if __name__ == "__main__":
     panoptic_fixture()
     lifting_fixture()
     sd = OW.make_weights(0)
+    multi_fixture(sd)
     for size in (256, 512):
         model_fixture(size, sd)

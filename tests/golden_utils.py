@@ -24,8 +24,19 @@ def fixture_images(size):
     return a[None]
 
 
-def default_K(B=1):
-    return torch.tensor([[318 / 256, 0, 0.5], [0, 318 / 256, 0.5], [0, 0, 1]])[None, None].repeat(B, 2, 1, 1)
+def default_K(B=1, V=2):
+    return torch.tensor([[318 / 256, 0, 0.5], [0, 318 / 256, 0.5], [0, 0, 1]])[None, None].repeat(B, V, 1, 1)
+
+
+def fixture_images_multi(size=128):
+    """V = 3 fixture input: the asset pair and the first image mirrored (tests/golden/make_golden.py::multi_fixture)."""
+    pair = fixture_images(size)[0]
+    return torch.stack((pair[0], pair[1], pair[0].flip(-1)))[None]
+
+
+def load_multi_fixture(V=3, size=128):
+    z = np.load(os.path.join(GOLDEN, f"model_multi_v{V}_{size}.npz"), allow_pickle=False)
+    return z, json.load(open(os.path.join(GOLDEN, f"model_multi_v{V}_{size}.json")))
 
 
 def compare_summary(name, t: torch.Tensor, z, tol):

@@ -135,3 +135,50 @@ def test_forward_against_reference_golden(precision, tol, size):
     assert str(masks[0].dtype) == str(z["seg_mask.dtype"])
     del model
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-3), ("bf16", 6e-2)])
+def test_multiview_forward(precision, tol):
+    """SIU3RMultiViewModel (V = 3, 128^2): against the golden vectors of the reference's model_multi.py forward, and
+    per-view against oracle.model_forward_multi; then the same model replayed through its HIP graphs, and B = 2."""
+    from golden_utils import FIELDS, compare_summary, default_K, fixture_images_multi, load_multi_fixture
+    from oracle import siu3r_oracle as O
+    from oracle import weights as OW
+    from siu3r_amd.model import SIU3RMultiViewModel
+
+    if "sd" not in _STATE:
+        _STATE["sd"] = OW.make_weights(0)
+    sd = _STATE["sd"]
+    z, meta = load_multi_fixture()
+    img, K = fixture_images_multi(128), default_K(1, 3)
+    model = SIU3RMultiViewModel(sd, image_size=(128, 128), precision=precision)
+    ctol = lambda f: tol * (3.4 if (f == "covariances" and precision == "bf16") else 1)
+    with torch.no_grad():
+        g, seg, masks, infos, qs = model(img.cuda(), K.cuda(), enable_query_class_logit_lift=True, return_intermediates=True)
+        ref = O.model_forward_multi(sd, img, K)
+    for f in FIELDS:
+        compare_summary(f, getattr(g, f), z, ctol(f))
+    compare_summary("class_queries_logits", seg.class_queries_logits, z, tol)
+    compare_summary("masks_queries_logits", seg.masks_queries_logits, z, tol)
+    assert int(g.semantic_labels.sum()) == int(z["semantic_labels.sum"]) and int(g.instance_labels.sum()) == int(z["instance_labels.sum"])
+    assert infos == meta["seg_infos"]
+    fails = []
+    for v in range(3):
+        for i in (1, 6, 12):
+            _report(f"multi.dec[v{v}][{i}]", model._last["decs"][v][i], ref["bb"]["decs"][v][i], tol, tol, fails)
+    _report("multi.means", g.means, ref["means"], tol, tol, fails)
+    _report("multi.harmonics", g.harmonics, ref["harmonics"], tol, tol, fails)
+    assert torch.equal(g.semantic_labels.cpu(), ref["semantic_labels"]) and torch.equal(g.instance_labels.cpu(), ref["instance_labels"])
+    assert not fails, fails
+    # graph replay (third call of the shape) reproduces the eager result bit for bit
+    with torch.no_grad():
+        outs = [model(img.cuda(), K.cuda(), enable_query_class_logit_lift=True) for _ in range(3)]
+    for o in outs:
+        assert torch.equal(o[0].means, g.means) and torch.equal(o[0].harmonics, g.harmonics) and torch.equal(o[1].class_queries_logits, seg.class_queries_logits)
+    # B = 2 (views 1.. do not form one strided batch: the copy path): item 0 = the fixture, item 1 = its views permuted
+    img2 = torch.cat((img, img[:, [1, 2, 0]]), 0)
+    with torch.no_grad():
+        g2 = model(img2.cuda(), default_K(2, 3).cuda())[0]
+    assert float((g2.means[0] - g.means[0]).abs().max()) <= 1e-5 * float(g.means.abs().max())
+    del model
+    torch.cuda.empty_cache()

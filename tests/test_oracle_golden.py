@@ -8,7 +8,8 @@ import pytest
 import torch
 
 from crafted import crafted_panoptic_inputs, permuted
-from golden_utils import FIELDS, GOLDEN, compare_summary, default_K, fixture_images, load_model_fixture
+from golden_utils import (FIELDS, GOLDEN, compare_summary, default_K, fixture_images, fixture_images_multi, load_model_fixture,
+                          load_multi_fixture)
 from oracle import siu3r_oracle as O
 from oracle import weights as OW
 
@@ -83,3 +84,14 @@ def test_model_forward_against_reference_vectors(size):
     assert out["seg_infos"] == meta["seg_infos"] and out["query_scores"] == meta["query_scores"]
     assert str(out["seg_masks"][0].dtype) == str(z["seg_mask.dtype"])
     assert np.array_equal(out["seg_masks"][0].unique().numpy(), z["seg_mask.unique"])
+
+
+def test_multiview_forward_against_reference_vectors():
+    """SIU3RMultiViewModel.forward of the reference (V = 3, 128^2) vs oracle.model_forward_multi."""
+    z, meta = load_multi_fixture()
+    with torch.no_grad():
+        out = O.model_forward_multi(_weights(), fixture_images_multi(128), default_K(1, 3), keep_intermediates=False)
+    for f in FIELDS + ("class_queries_logits", "masks_queries_logits"):
+        compare_summary(f, out[f], z, 2e-4)
+    assert int(out["semantic_labels"].sum()) == int(z["semantic_labels.sum"]) and int(out["instance_labels"].sum()) == int(z["instance_labels.sum"])
+    assert out["seg_infos"] == meta["seg_infos"] and out["query_scores"] == meta["query_scores"]
