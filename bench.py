@@ -97,23 +97,36 @@ def main():
         "data": "synthetic (seeded uniform images, seeded synthetic weights of the reference architecture)",
         "config": {"workload": f"configs[1]: single pair 2x{H}x{W} per step" if B == 1 else f"{B} pairs 2x{H}x{W} per step",
                    "pairs_per_step_per_gpu": B, "image_size": [H, W], "precision": args.precision,
-                   "parallelism": f"dp{world} (independent pairs, one all-gather of metric statistics)"},
+                   "parallelism": f"dp{world} (independent pairs, one all-gather of metric statistics)",
+                   "launch": "per-chain HIP graphs on 6 streams" if (model.use_graph and model._ctx.concurrent) else "eager"},
         "network_tflops_algorithmic": value * FLOPS_PER_PAIR_512 * (H * W / (512 * 512)) / 1e12,
     }
 
     if not args.no_roofline:
         timer = ops.KernelTimer()
         ops.set_kernel_timer(timer)
-        step()
+        conc, model._ctx.concurrent = model._ctx.concurrent, False  # one stream: every launch between its own two events
+        torch.cuda._sleep(int(2.0e8))  # ~0.1 s: the whole step is enqueued before it runs, so the event pairs time the
+        step()                         # kernels back to back instead of the host's launch pace
+        model._ctx.concurrent = conc
         ops.set_kernel_timer(None)
         summ = timer.summary()
         dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
         name, d = dom
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_pass.sh: separate
+        # FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md, both in KiB)
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc_path) and args.precision == "bf16" and B == 1 and (H, W) == (512, 512):
+            pmc = json.load(open(pmc_path)).get("siu3r_gemm_dma::gemm_dma_kernel<1, 0, false>") if name == "gemm_dma_kernel<1,0,false>" else None
+            if pmc:
+                traffic = (2.0 * pmc["fetch_size_per_launch"] + pmc["write_size_per_launch"]) * 1024.0
+                traffic_src = "profiles/r01_pmc_summary.json (gemm_dma_kernel<1,0,false>, mean per launch)"
         result["roofline"] = {
-            "kernel": f"gemm_kernel ({name}; all Linear/Conv launches of one instrumented step after the timed region)",
+            "kernel": f"siu3r_gemm_dma::{name} (dense Linear launches; HIP events around every launch of one eager single-stream step, queued behind a sleep kernel, after the timed region)",
             "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+            "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
             "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
             "algorithmic_flops_per_launch_avg": d["flops"] / d["launches"],
             "gemm_time_ms_per_step": d["ms"],

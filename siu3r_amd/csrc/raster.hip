@@ -178,7 +178,25 @@ __global__ void project_kernel(Cam c, int64_t G, const float* means, const float
     const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
     const float x = dx * inv, y = dy * inv, z = dz * inv;
     const int deg = c.sh_degree;
-    const float* sh = colors + (size_t)g * channels * 3;
+    // the Gaussian's coefficient block ([coef][rgb], 12 B per coefficient, 4-byte aligned) as 16-byte loads: a lane's
+    // block is contiguous, so 12 (19 with band 4) wide loads replace 48 (75) scalar ones that each touched 64 cache lines
+    struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
+    const float* shp = colors + (size_t)g * channels * 3;
+    float sh[76];
+    const int nf = ((deg > 3 && c.sh_band4) ? 25 : (deg > 2 ? 16 : (deg > 1 ? 9 : (deg > 0 ? 4 : 1)))) * 3;
+#pragma unroll
+    for (int q = 0; q < 19; ++q) {
+      if (4 * q < nf) {
+        if (4 * q + 4 <= channels * 3) {
+          const f4u t4 = *(const f4u*)(shp + 4 * q);
+          sh[4 * q] = t4.v[0]; sh[4 * q + 1] = t4.v[1]; sh[4 * q + 2] = t4.v[2]; sh[4 * q + 3] = t4.v[3];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sh[4 * q + e] = (4 * q + e < channels * 3) ? shp[4 * q + e] : 0.f;
+        }
+      }
+    }
+#pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
 #define S(i) sh[(i) * 3 + ch]
       float r = SH_C0 * S(0);
@@ -254,38 +272,72 @@ __global__ void fill_kernel(int64_t G, const int32_t* rect, const float* depth, 
     }
 }
 
-// one workgroup per tile: bitonic sort of the tile's keys in LDS (up to SORT_CAP), global-memory bitonic beyond
+// One workgroup per tile: bitonic sort of the tile's (depth bits << 32 | id) keys in LDS.  Three instantiations by
+// capacity (a tile is handled by the smallest one that holds its padded length): small tiles get small LDS footprints
+// and therefore many resident workgroups.  Every thread is busy in every pass, and two butterfly stages (strides j and
+// j/2) are done per LDS round trip on four keys held in registers: half the LDS traffic and barriers of the textbook
+// loop.  Tiles beyond 8192 keys fall back to an in-place global-memory bitonic (rare).
 constexpr int SORT_CAP = 8192;  // 64 KiB of LDS
+__device__ __forceinline__ void cmpx(uint64_t& a, uint64_t& b, bool up) {
+  if ((a > b) == up) {
+    const uint64_t t = a;
+    a = b;
+    b = t;
+  }
+}
+template <int CAP, int CAP_PREV>
 __global__ __launch_bounds__(256) void sort_kernel(const int32_t* tile_start, uint64_t* keys, int32_t* ids) {
-  __shared__ uint64_t s[SORT_CAP];
+  __shared__ uint64_t s[CAP];
   const int tile = blockIdx.x;
   const int beg = tile_start[tile], n = tile_start[tile + 1] - beg;
   if (n <= 0) return;
-  int np = 1;
-  while (np < n) np <<= 1;
-  if (np <= SORT_CAP) {
+  int np = 1, lg = 0;
+  while (np < n) {
+    np <<= 1;
+    ++lg;
+  }
+  if (np <= CAP_PREV) return;  // a smaller instantiation owns this tile
+  if (np <= CAP) {
     for (int i = threadIdx.x; i < np; i += 256) s[i] = i < n ? keys[beg + i] : ~0ull;
     __syncthreads();
-    for (int k = 2; k <= np; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = threadIdx.x; i < np; i += 256) {
-          const int l = i ^ j;
-          if (l > i) {
-            const uint64_t a = s[i], b = s[l];
-            const bool up = (i & k) == 0;
-            if ((a > b) == up) {
-              s[i] = b;
-              s[l] = a;
-            }
-          }
+    for (int lk = 1; lk <= lg; ++lk) {       // merge width k = 1 << lk
+      const int k = 1 << lk;
+      int lj = lk - 1;                        // stride j = 1 << lj
+      for (; lj >= 1; lj -= 2) {              // two stages per pass: strides j and h = j / 2
+        const int j = 1 << lj, h = j >> 1;
+        for (int q = threadIdx.x; q < (np >> 2); q += 256) {
+          const int low = q & (h - 1);
+          const int i0 = ((q >> (lj - 1)) << (lj + 1)) | low;
+          const bool up = (i0 & k) == 0;
+          uint64_t a = s[i0], b = s[i0 + h], c = s[i0 + j], d = s[i0 + j + h];
+          cmpx(a, c, up);
+          cmpx(b, d, up);
+          cmpx(a, b, up);
+          cmpx(c, d, up);
+          s[i0] = a;
+          s[i0 + h] = b;
+          s[i0 + j] = c;
+          s[i0 + j + h] = d;
         }
         __syncthreads();
       }
+      if (lj == 0) {                          // odd number of stages: the stride-1 stage alone
+        for (int q = threadIdx.x; q < (np >> 1); q += 256) {
+          const int i0 = q << 1;
+          const bool up = (i0 & k) == 0;
+          uint64_t a = s[i0], b = s[i0 + 1];
+          cmpx(a, b, up);
+          s[i0] = a;
+          s[i0 + 1] = b;
+        }
+        __syncthreads();
+      }
+    }
     for (int i = threadIdx.x; i < n; i += 256) {
       keys[beg + i] = s[i];
       ids[beg + i] = (int32_t)(s[i] & 0xffffffffu);
     }
-  } else {
+  } else if (CAP == SORT_CAP) {
     // oversized tile: in-place bitonic on the (virtually padded) global segment; slow path, rare
     uint64_t* k_ = keys + beg;
     for (int k = 2; k <= np; k <<= 1)
@@ -483,7 +535,9 @@ extern "C" int siu3r_raster_sort(const siu3r_raster_cam* cam, int64_t G, const i
   hipStream_t s = (hipStream_t)stream;
   const int gw = (cam->width + TILE - 1) / TILE, T = gw * ((cam->height + TILE - 1) / TILE);
   if (G > 0) hipLaunchKernelGGL(fill_kernel, g1(G), dim3(256), 0, s, G, rect, depth, cursor, keys, gw);
-  hipLaunchKernelGGL(sort_kernel, dim3(T), dim3(256), 0, s, tile_start, keys, ids);
+  hipLaunchKernelGGL((sort_kernel<1024, 0>), dim3(T), dim3(256), 0, s, tile_start, keys, ids);
+  hipLaunchKernelGGL((sort_kernel<4096, 1024>), dim3(T), dim3(256), 0, s, tile_start, keys, ids);
+  hipLaunchKernelGGL((sort_kernel<SORT_CAP, 4096>), dim3(T), dim3(256), 0, s, tile_start, keys, ids);
   SIU3R_LAUNCH_CHECK("siu3r_raster_sort");
   return 0;
 }

@@ -143,7 +143,18 @@ def _gemm_launch(p: GemmParams):
     if _timer is None:
         check(_lib.lib().siu3r_gemm(C.byref(p), _stream()))
         return
-    variant = "gemm_bf16x3" if p.w_lo else ("gemm_f32a" if p.a_dtype == F32 else "gemm_bf16")
+    # label with the kernel the launcher will pick (mirrors gemm.hip / gemm_dma.hip dispatch) so that the event
+    # averages line up with rocprofv3's per-kernel rows
+    if p.w_lo:
+        variant = "gemm_kernel<1,1,1> (bf16x3)"
+    elif p.a_dtype == F32 or p.a_mode == 2:
+        variant = "gemm_kernel<1,0,1> (fp32 A)"
+    elif p.a_mode == 0:
+        variant = "gemm_dma_kernel<1,0,false>" if not p.relu_in else "gemm_kernel<0,0,1>"
+    elif p.cin % 64 == 0 and p.kh * p.kw <= 32 and p.kpad == p.k:
+        variant = "gemm_dma_kernel<1,1,true>" if p.relu_in else "gemm_dma_kernel<1,1,false>"
+    else:
+        variant = "gemm_dma_kernel<1,2,false>" if not p.relu_in else "gemm_kernel<0,0,1>"
     flops = 2.0 * p.m * p.n * p.k * max(1, p.batch)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
