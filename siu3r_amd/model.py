@@ -229,11 +229,13 @@ class AsymmetricCroCo:
     # ---- decoder (backbone_croco.py:302-347 for the pair, :541-584 for V views): view 0 runs dec_blocks with the
     # tokens of all other views as memory; views 1..V-1 run dec_blocks2 (batched), each with the other views' tokens
     # (ascending view order) as memory.  Every layer reads the PREVIOUS layer's tokens of all views.
-    def decode(self, enc):
+    def decode_begin(self, enc):
+        """enc_norm + decoder_embed, positions, and ALL layer buffers (so that the per-layer, per-side steps -- which the
+        model captures as separate HIP graphs -- only write into memory that outlives them)."""
         ctx = self.ctx
         B, V, H, W, N = enc["dims"]
         h, w = H // 16, W // 16
-        x, pos, rope = enc["x"], enc["pos"], enc["rope"]
+        x, pos = enc["x"], enc["pos"]
         f = ctx.ln("backbone.enc_norm", x, 1e-6, out_dtype=torch.float32)
         g = ops.linear(f, ctx.w.linear("backbone.decoder_embed"), out_dtype=torch.float32).view(B, V, N + 1, -1)
         fv = f.view(B, V, N + 1, -1)
@@ -245,36 +247,51 @@ class AsymmetricCroCo:
             pos_rest = pv[:, 1:].reshape(B * (V - 1), N + 1, 2).contiguous()
             mem0_pos = pv[:, 1:].reshape(B, (V - 1) * (N + 1), 2).contiguous()
             memr_pos = self._ctx_positions(B, V, h, w)
-        layers = [fv]
-        # the two sides of a layer are independent: view 0 on the current stream, the other views on a side stream,
-        # joined after every layer; both write straight into the next (b, v)-major buffer
+        gs = [g] + [torch.empty_like(g) for _ in range(self.dec_depth)]
+        return dict(enc=enc, fv=fv, g=gs, pos0=pos0, pos_rest=pos_rest, mem0_pos=mem0_pos, memr_pos=memr_pos, rope=enc["rope"])
+
+    def decode_side(self, d, i, side):
+        """Layer i, side 0 = view 0 (dec_blocks), side 1 = views 1..V-1 batched (dec_blocks2); reads layer i's input
+        buffer g[i] (all views), writes its own views of g[i+1]."""
+        B, V, H, W, N = d["enc"]["dims"]
+        g, g_next, rope = d["g"][i], d["g"][i + 1], d["rope"]
+        if side == 0:
+            mem0 = g[:, 1] if V == 2 else g[:, 1:].reshape(B, (V - 1) * (N + 1), -1)
+            self._dec_block(f"backbone.dec_blocks.{i}", g[:, 0], mem0, d["pos0"], d["mem0_pos"], rope, out=g_next[:, 0])
+            return
+        if V == 2:
+            xr, memr, outr = g[:, 1], g[:, 0], g_next[:, 1]
+        else:
+            xr = g[:, 1:].reshape(B * (V - 1), N + 1, -1)
+            memr = torch.stack([torch.cat([g[:, j] for j in range(V) if j != v], dim=1) for v in range(1, V)], dim=1).flatten(0, 1)
+            outr = g_next[0, 1:] if B == 1 else None  # views 1.. of g_next form one strided batch only then
+        r = self._dec_block(f"backbone.dec_blocks2.{i}", xr, memr, d["pos_rest"], d["memr_pos"], rope, out=outr)
+        if outr is None:
+            g_next[:, 1:].copy_(r.view(B, V - 1, N + 1, -1))
+
+    def decode_end(self, d):
+        B, V, H, W, N = d["enc"]["dims"]
+        layers = [d["fv"]] + d["g"][1:]
+        last = self.ctx.ln("backbone.dec_norm", layers[-1].reshape(B * V, N + 1, -1), 1e-6, out_dtype=torch.float32)
+        layers[-1] = last.view(B, V, N + 1, -1)
+        return dict(layers=layers, fv=d["fv"])
+
+    def decode(self, enc):
+        """The two sides of a layer are independent (each reads the other's PREVIOUS layer output): view 0 on the
+        current stream, the other views on a side stream, joined after every layer."""
+        ctx = self.ctx
+        d = self.decode_begin(enc)
         main = torch.cuda.current_stream()
         side = ctx.side_stream(0) if ctx.concurrent else main
-        if side is not main:
-            side.wait_stream(main)
-        direct = V == 2 or B == 1  # views 1.. of g_next form one strided batch
         for i in range(self.dec_depth):
-            g_next = torch.empty_like(g)
-            mem0 = g[:, 1] if V == 2 else g[:, 1:].reshape(B, (V - 1) * (N + 1), -1)
-            self._dec_block(f"backbone.dec_blocks.{i}", g[:, 0], mem0, pos0, mem0_pos, rope, out=g_next[:, 0])
+            if side is not main:
+                side.wait_stream(main)
+            self.decode_side(d, i, 0)
             with torch.cuda.stream(side):
-                if V == 2:
-                    xr, memr, outr = g[:, 1], g[:, 0], g_next[:, 1]
-                else:
-                    xr = g[:, 1:].reshape(B * (V - 1), N + 1, -1)
-                    memr = torch.stack([torch.cat([g[:, j] for j in range(V) if j != v], dim=1) for v in range(1, V)], dim=1).flatten(0, 1)
-                    outr = g_next[0, 1:] if B == 1 else None
-                r = self._dec_block(f"backbone.dec_blocks2.{i}", xr, memr, pos_rest, memr_pos, rope, out=outr)
-                if not direct:
-                    g_next[:, 1:].copy_(r.view(B, V - 1, N + 1, -1))
+                self.decode_side(d, i, 1)
             if side is not main:
                 main.wait_stream(side)
-                side.wait_stream(main)
-            g = g_next
-            layers.append(g_next)
-        last = ctx.ln("backbone.dec_norm", layers[-1].reshape(B * V, N + 1, -1), 1e-6, out_dtype=torch.float32)
-        layers[-1] = last.view(B, V, N + 1, -1)
-        return dict(layers=layers, fv=fv)
+        return self.decode_end(d)
 
     def _assemble(self, enc, dec):
         strip = lambda t: t[..., :-1, :]
@@ -711,7 +728,7 @@ class _Run:
 
     def __init__(self, images, K):
         self.images, self.K = images, K
-        self.img_bv = self.img8 = self.enc = self.dec = self.ms = self.seg = self.gaussians = None
+        self.img_bv = self.img8 = self.enc = self.dstate = self.dec = self.ms = self.seg = self.gaussians = None
         self.gs, self.pts = [None, None], [None, None]
 
 
@@ -814,9 +831,21 @@ class SIU3RModel:
 
     # ---- the chains of the network body.  Each stage only reads what earlier stages left in the _Run
     def _stages(self, st):
-        return [("encode", lambda: self._s_encode(st)), ("seg", lambda: self._s_seg(st)), ("decode", lambda: self._s_decode(st)),
-                ("gs0", lambda: self._s_head(st, 0)), ("gsr", lambda: self._s_head(st, 1)), ("pts0", lambda: self._s_head(st, 2)),
-                ("ptsr", lambda: self._s_head(st, 3)), ("tail", lambda: self._s_tail(st))]
+        bb = self.backbone
+
+        def dec_pre():
+            st.dstate = bb.decode_begin(st.enc)
+
+        def dec_post():
+            st.dec = bb.decode_end(st.dstate)
+
+        dec = [("dec_pre", dec_pre)]
+        for i in range(bb.dec_depth):
+            dec += [(f"decA{i}", lambda i=i: bb.decode_side(st.dstate, i, 0)), (f"decB{i}", lambda i=i: bb.decode_side(st.dstate, i, 1))]
+        dec += [("dec_post", dec_post)]
+        return [("encode", lambda: self._s_encode(st)), ("seg", lambda: self._s_seg(st))] + dec + [
+            ("gs0", lambda: self._s_head(st, 0)), ("gsr", lambda: self._s_head(st, 1)), ("pts0", lambda: self._s_head(st, 2)),
+            ("ptsr", lambda: self._s_head(st, 3)), ("tail", lambda: self._s_tail(st))]
 
     def _run_stages(self, st, run):
         """Enqueue the stages with their fork/join edges.  run(name, fn) either calls fn (eager) or replays its graph."""
@@ -830,7 +859,18 @@ class SIU3RModel:
             seg_stream.wait_stream(main)
         with torch.cuda.stream(seg_stream):  # needs only the encoder's features: overlaps the decoder and the heads
             run("seg", stages["seg"])
-        run("decode", stages["decode"])
+        # decoder: per layer, view 0 and the other views are independent chains (joined after every layer)
+        run("dec_pre", stages["dec_pre"])
+        dside = ctx.side_stream(0) if par else main
+        for i in range(self.backbone.dec_depth):
+            if par:
+                dside.wait_stream(main)
+            run(f"decA{i}", stages[f"decA{i}"])
+            with torch.cuda.stream(dside):
+                run(f"decB{i}", stages[f"decB{i}"])
+            if par:
+                main.wait_stream(dside)
+        run("dec_post", stages["dec_post"])
         hs = [ctx.side_stream(2 + i) if par else main for i in range(3)] + [main]
         for s_ in hs[:3]:
             if s_ is not main:
@@ -858,9 +898,6 @@ class SIU3RModel:
         allf = [t.reshape(Z, t.shape[2], t.shape[3]) if t.is_contiguous() else t.flatten(0, 1) for t in allf]
         st.ms = self.adapter.forward_nhwc(st.img_bv, st.img8, allf)
         st.seg = self.mask2former.forward_nhwc(st.ms, B, V)
-
-    def _s_decode(self, st):
-        st.dec = self.backbone.decode(st.enc)
 
     @staticmethod
     def _rest_views(t):
