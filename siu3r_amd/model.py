@@ -185,8 +185,8 @@ class AsymmetricCroCo:
         x = ops.linear(a, ctx.w.linear(p + ".cross_attn.proj"), out_dtype=torch.float32, residual=x)
         return self._mlp(p + ".mlp", x, p + ".norm3", out=out)
 
-    # ---- encoder: all B*V views as one batch (backbone_croco.py:270-300)
-    def encode(self, images, K):
+    def encode_begin(self, images, K):
+        """patch embedding + intrinsics token (backbone_croco.py:270-281)."""
         ctx = self.ctx
         B, V, _, H, W = images.shape
         assert V >= 2
@@ -206,15 +206,25 @@ class AsymmetricCroCo:
         kin = torch.zeros((Z, 16), dtype=torch.float32, device=ctx.dev)
         kin[:, :9] = K.reshape(Z, 9).float()
         ops.linear(kin, ctx.w.lin["backbone.intrinsic_encoder"], out=x[:, N])
-        pos = self._positions(Z, h, w)
-        rope = self._rope(max(h, w) + 1)
-        all_feat = []
-        for i in range(self.enc_depth):
-            x = self._enc_block(f"backbone.enc_blocks.{i}", x, pos, rope)
-            all_feat.append(x)
-        av = [t.view(B, V, N + 1, -1) for t in all_feat]
-        self._all_feat_bv = [t[..., :-1, :] for t in av]  # [B, V, N, C] views for the (b,v)-batched adapter
-        return dict(x=x, av=av, pos=pos, rope=rope, dims=(B, V, H, W, N))
+        return dict(x=x, all_feat=[], pos=self._positions(Z, h, w), rope=self._rope(max(h, w) + 1), dims=(B, V, H, W, N))
+
+    def encode_blocks(self, e, lo, hi):
+        """encoder blocks lo..hi-1; every block's output is kept (the ViT-Adapter taps blocks 5/11/17/23)."""
+        for i in range(lo, hi):
+            e["x"] = self._enc_block(f"backbone.enc_blocks.{i}", e["x"], e["pos"], e["rope"])
+            e["all_feat"].append(e["x"])
+
+    def encode_end(self, e):
+        B, V, H, W, N = e["dims"]
+        e["av"] = [t.view(B, V, N + 1, -1) for t in e["all_feat"]]
+        self._all_feat_bv = [t[..., :-1, :] for t in e["av"]]  # [B, V, N, C] views for the (b,v)-batched adapter
+        return e
+
+    # ---- encoder: all B*V views as one batch (backbone_croco.py:270-300)
+    def encode(self, images, K):
+        e = self.encode_begin(images, K)
+        self.encode_blocks(e, 0, self.enc_depth)
+        return self.encode_end(e)
 
     def _ctx_positions(self, B, V, h, w):
         """positions of the memory tokens of views 1..V-1: the other views in ascending order (generate_ctx_views,
@@ -469,12 +479,11 @@ class CroCoViTAdapter:
         f2 = ops.dwconv3x3_gelu(f1, ctx.w.vec[wk + "#w9c"], ctx.w.v(wk + ".bias"), h, w)
         return ops.linear(f2, ctx.w.linear(p + ".ffn.fc2"), out_dtype=torch.float32, residual=c)
 
-    def forward_nhwc(self, img: torch.Tensor, img8: torch.Tensor, all_feat: Sequence[torch.Tensor]):
-        """img [Z,3,Hi,Wi]; all_feat: 24 x [Z, N, 1024] fp32 (strided views).  Returns 4 NHWC maps [Z,h_l,w_l,1024]."""
+    def spm(self, img8: torch.Tensor):
+        """SpatialPriorModule + level embeddings (vit_adapter.py:380-391): needs only the image."""
         ctx = self.ctx
-        Z, _, Hi, Wi = img.shape
+        Z, Hi, Wi, _ = img8.shape
         h, w = Hi // 16, Wi // 16
-        ref = self._ref(Hi, Wi)
         sp = "adapter.spm"
         c = ops.conv2d(img8, ctx.w.conv(sp + ".stem.0", cin_pad=8, bn=sp + ".stem.1"), stride=2, pad=1, out_dtype=ctx.act, act=ACT_RELU)
         c = ops.conv2d(c, ctx.w.conv(sp + ".stem.3", bn=sp + ".stem.4"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
@@ -491,19 +500,26 @@ class CroCoViTAdapter:
         ops.linear(c2.view(Z, n2, -1), ctx.w.linear(sp + ".fc2", key=sp + ".fc2+le", extra_bias=le[0]), out=cc[:, :n2])
         ops.linear(c3.view(Z, n3, -1), ctx.w.linear(sp + ".fc3", key=sp + ".fc3+le", extra_bias=le[1]), out=cc[:, n2:n2 + n3])
         ops.linear(c4.view(Z, n4, -1), ctx.w.linear(sp + ".fc4", key=sp + ".fc4+le", extra_bias=le[2]), out=cc[:, n2 + n3:])
-        outs = []
-        for i, idx in enumerate(ADAPTER_IDX):
-            x = all_feat[idx]
-            cc = self._extractor(f"adapter.interactions.{i}.extractor", cc, ref, x, h, w)
-            if i == 3:
-                for j in range(2):
-                    cc = self._extractor(f"adapter.interactions.3.extra_extractors.{j}", cc, ref, x, h, w)
-            outs.append(x.contiguous().view(Z, h, w, -1))  # layout plumbing: strip-view -> dense NHWC
+        return dict(c1=c1, cc=cc, outs=[], dims=(Z, Hi, Wi, h, w, n2, n3, n4), ref=self._ref(Hi, Wi))
+
+    def interact(self, a, i, x):
+        """interaction i (vit_adapter.py:393-418): the extractor(s) that read encoder block ADAPTER_IDX[i]'s tokens x."""
+        Z, Hi, Wi, h, w, n2, n3, n4 = a["dims"]
+        a["cc"] = self._extractor(f"adapter.interactions.{i}.extractor", a["cc"], a["ref"], x, h, w)
+        if i == 3:
+            for j in range(2):
+                a["cc"] = self._extractor(f"adapter.interactions.3.extra_extractors.{j}", a["cc"], a["ref"], x, h, w)
+        a["outs"].append(x.contiguous().view(Z, h, w, -1))  # layout plumbing: strip-view -> dense NHWC
+
+    def finish(self, a):
+        ctx = self.ctx
+        Z, Hi, Wi, h, w, n2, n3, n4 = a["dims"]
+        cc, c1 = a["cc"], a["c1"]
         c2 = cc[:, :n2].contiguous().view(Z, 2 * h, 2 * w, -1)
         c3 = cc[:, n2:n2 + n3].contiguous().view(Z, h, w, -1)
         c4 = cc[:, n2 + n3:].contiguous().view(Z, h // 2, w // 2, -1)
         c1 = ops.conv_transpose2d(c2, ctx.w.convT("adapter.up"), out_dtype=torch.float32, residual=c1)
-        x1, x2, x3, x4 = outs
+        x1, x2, x3, x4 = a["outs"]
         s1, b1 = ctx.w.bn_affine("adapter.norm1")
         s2, b2 = ctx.w.bn_affine("adapter.norm2")
         s3, b3 = ctx.w.bn_affine("adapter.norm3")
@@ -513,6 +529,13 @@ class CroCoViTAdapter:
         f3 = ops.affine_add(x3, c3, s3, b3, out_dtype=ctx.act)
         f4 = ops.resize_bilinear(x4, (h // 2, w // 2), False, addend=c4, ch_scale=s4, ch_shift=b4, out_dtype=ctx.act)
         return [f1, f2, f3, f4]
+
+    def forward_nhwc(self, img: torch.Tensor, img8: torch.Tensor, all_feat: Sequence[torch.Tensor]):
+        """img [Z,3,Hi,Wi]; all_feat: 24 x [Z, N, 1024] fp32 (strided views).  Returns 4 NHWC maps [Z,h_l,w_l,1024]."""
+        a = self.spm(img8)
+        for i, idx in enumerate(ADAPTER_IDX):
+            self.interact(a, i, all_feat[idx])
+        return self.finish(a)
 
     def forward(self, x, all_feat):
         """reference signature (vit_adapter.py:393): returns [f1..f4] as NCHW-shaped (channels-last) tensors."""
@@ -728,7 +751,7 @@ class _Run:
 
     def __init__(self, images, K):
         self.images, self.K = images, K
-        self.img_bv = self.img8 = self.enc = self.dstate = self.dec = self.ms = self.seg = self.gaussians = None
+        self.img_bv = self.img8 = self.enc = self.adapter = self.dstate = self.dec = self.ms = self.seg = self.gaussians = None
         self.gs, self.pts = [None, None], [None, None]
 
 
@@ -843,7 +866,25 @@ class SIU3RModel:
         for i in range(bb.dec_depth):
             dec += [(f"decA{i}", lambda i=i: bb.decode_side(st.dstate, i, 0)), (f"decB{i}", lambda i=i: bb.decode_side(st.dstate, i, 1))]
         dec += [("dec_post", dec_post)]
-        return [("encode", lambda: self._s_encode(st)), ("seg", lambda: self._s_seg(st))] + dec + [
+        ad = self.adapter
+        bounds = [0] + [i + 1 for i in ADAPTER_IDX]  # encoder segments end at the blocks the adapter taps
+
+        def enc_seg(k):
+            bb.encode_blocks(st.enc, bounds[k], bounds[k + 1])
+            if k == len(ADAPTER_IDX) - 1:
+                if bounds[-1] < bb.enc_depth:
+                    bb.encode_blocks(st.enc, bounds[-1], bb.enc_depth)
+                bb.encode_end(st.enc)
+
+        def interact(k):
+            B, V, _, H, W = st.images.shape
+            t = st.enc["all_feat"][ADAPTER_IDX[k]].view(B * V, -1, bb.enc_embed_dim)[:, :-1]
+            ad.interact(st.adapter, k, t)
+
+        enc = [("enc_begin", lambda: self._s_encode_begin(st)), ("spm", lambda: setattr(st, "adapter", ad.spm(st.img8)))]
+        for k in range(len(ADAPTER_IDX)):
+            enc += [(f"enc{k}", lambda k=k: enc_seg(k)), (f"int{k}", lambda k=k: interact(k))]
+        return enc + [("seg", lambda: self._s_seg(st))] + dec + [
             ("gs0", lambda: self._s_head(st, 0)), ("gsr", lambda: self._s_head(st, 1)), ("pts0", lambda: self._s_head(st, 2)),
             ("ptsr", lambda: self._s_head(st, 3)), ("tail", lambda: self._s_tail(st))]
 
@@ -853,11 +894,22 @@ class SIU3RModel:
         stages = dict(self._stages(st))
         main = torch.cuda.current_stream()
         par = ctx.concurrent
-        run("encode", stages["encode"])
+        # encoder on the current stream; the ViT-Adapter rides beside it on its own stream: the spatial prior module needs
+        # only the image, interaction k only the tokens of encoder block ADAPTER_IDX[k].  The rest of the segmentation
+        # branch (adapter output maps, Mask2Former) then overlaps the decoder and the heads
+        run("enc_begin", stages["enc_begin"])
         seg_stream = ctx.side_stream(1) if par else main
         if par:
             seg_stream.wait_stream(main)
-        with torch.cuda.stream(seg_stream):  # needs only the encoder's features: overlaps the decoder and the heads
+        with torch.cuda.stream(seg_stream):
+            run("spm", stages["spm"])
+        for k in range(len(ADAPTER_IDX)):
+            run(f"enc{k}", stages[f"enc{k}"])
+            if par:
+                seg_stream.wait_stream(main)
+            with torch.cuda.stream(seg_stream):
+                run(f"int{k}", stages[f"int{k}"])
+        with torch.cuda.stream(seg_stream):
             run("seg", stages["seg"])
         # decoder: per layer, view 0 and the other views are independent chains (joined after every layer)
         run("dec_pre", stages["dec_pre"])
@@ -883,20 +935,17 @@ class SIU3RModel:
                 main.wait_stream(s_)
         run("tail", stages["tail"])
 
-    def _s_encode(self, st):
+    def _s_encode_begin(self, st):
         ctx = self._ctx
         B, V, _, H, W = st.images.shape
         st.img_bv = st.images.reshape(B * V, 3, H, W).contiguous().float()
         st.img8 = ops.pack_image_nhwc8(st.img_bv, ctx.act)
-        st.enc = self.backbone.encode(st.images, st.K)
+        st.enc = self.backbone.encode_begin(st.images, st.K)
 
     def _s_seg(self, st):
         # the adapter is shared by all views (model.py:342-345): one (b,v)-batched pass; Mask2Former sees T = V frames
         B, V, _, H, W = st.images.shape
-        Z = B * V
-        allf = [t[..., :-1, :] for t in st.enc["av"]]
-        allf = [t.reshape(Z, t.shape[2], t.shape[3]) if t.is_contiguous() else t.flatten(0, 1) for t in allf]
-        st.ms = self.adapter.forward_nhwc(st.img_bv, st.img8, allf)
+        st.ms = self.adapter.finish(st.adapter)
         st.seg = self.mask2former.forward_nhwc(st.ms, B, V)
 
     @staticmethod
