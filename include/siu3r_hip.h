@@ -219,6 +219,15 @@ int siu3r_panoptic_stage1(const float* class_logits, const float* mask_logits_cl
 int siu3r_panoptic_qcl(const float* p256, const float* probs, const int32_t* kept_idx, const int32_t* acc_list, int nq,
                        float* out, int b, int T, int H, int W, int mask_size, int Q, int C, void* stream);
 
+/* ---- viewer-semantics render helpers (reference viewer.py:301-336: gsplat.rasterization(means, quats, exp(scales), sigmoid(opacities),
+ * colors = cat(sh0, shN), sh_degree, backgrounds = 1); gsplat is un-vendored: published algorithm, see oracle/raster_ref.c) ------------ */
+/* quats (w,x,y,z, normalised here) + scales -> the 6 upper-triangular covariance entries consumed by siu3r_raster_bin */
+int siu3r_quat_scale_to_cov6(const float* quats_wxyz, const float* scales, float* cov6, int64_t G, void* stream);
+/* view-dependent colour: rgb[G,3] = max(SH_degree(normalise(mean - campos)) . sh[G,ncoef,3] + 0.5, 0); campos3_host is a HOST pointer */
+int siu3r_sh_eval(const float* means, const float* campos3_host, const float* sh, int ncoef, int degree, float* rgb, int64_t G, void* stream);
+/* colors[pixels, channels] += (1 - alpha[pixels]) * bg[channels]; bg_host is a HOST pointer, channels <= 3 */
+int siu3r_blend_background(float* colors, const float* alpha, const float* bg_host, int channels, int64_t pixels, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,3 +53,27 @@ def forward(cam, means, cov6, opacities, colors, want_lists=True):
                              p(nt), p(image), p(depth), p(alpha), p(tile_start), p(ids) if want_lists else None, C.c_int64(cap))
     assert D >= 0, "oracle id buffer too small"
     return dict(radii=radii, tiles_touched=tt, n_touched=nt, image=image, depth=depth, alpha=alpha, tile_start=tile_start, ids=ids[:D], D=int(D))
+
+
+def quat_scale_to_cov6(quats, scales):
+    quats, scales = np.ascontiguousarray(quats, np.float32), np.ascontiguousarray(scales, np.float32)
+    out = np.zeros((quats.shape[0], 6), np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib().raster_ref_quat_scale_to_cov6(C.c_int64(quats.shape[0]), p(quats), p(scales), p(out))
+    return out
+
+
+def sh_eval(degree, means, campos, sh):
+    means, campos, sh = (np.ascontiguousarray(a, np.float32) for a in (means, campos, sh))
+    out = np.zeros((means.shape[0], 3), np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib().raster_ref_sh_eval(C.c_int64(means.shape[0]), C.c_int(degree), C.c_int(sh.shape[1]), p(means), p(campos), p(sh), p(out))
+    return out
+
+
+def blend_background(colors, alpha, bg):
+    colors = np.ascontiguousarray(colors, np.float32).copy()
+    alpha, bg = np.ascontiguousarray(alpha, np.float32), np.ascontiguousarray(bg, np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib().raster_ref_blend_background(C.c_int64(alpha.size), C.c_int(colors.shape[-1]), p(colors), p(alpha), p(bg))
+    return colors

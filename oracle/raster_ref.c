@@ -64,7 +64,7 @@ static const float SH_C0 = 0.28209479177387814f;
 static const float SH_C1 = 0.4886025119029199f;
 static const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
 static const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
-static const float SH_C4[9] = {2.5033429417967046f, 1.7701307697799304f, 0.9461746957575601f, 0.6690465435572892f, 0.10578554691520431f, 0.6690465435572892f, 0.47308734787878004f, 1.7701307697799304f, 0.6258357354491761f};
+static const float SH_C4[9] = {2.5033429417967046f, -1.7701307697799304f, 0.9461746957575601f, -0.6690465435572892f, 0.10578554691520431f, -0.6690465435572892f, 0.47308734787878004f, -1.7701307697799304f, 0.6258357354491761f};
 
 /* SH -> RGB for one Gaussian; sh is [n_coef][3] (the reference rearranges to 'g n xyz', cuda_splatting.py:65) */
 static void sh_to_rgb(const raster_cam* c, const float* mean, const float* sh, float* rgb) {
@@ -347,3 +347,74 @@ int64_t raster_ref_forward(const raster_cam* c, int64_t G, const float* means, c
 }
 
 int raster_ref_struct_size(void) { return (int)sizeof(raster_cam); }
+
+/* exported for the SH-basis consistency test */
+void raster_ref_sh_to_rgb(const raster_cam* c, const float* mean, const float* sh, float* rgb) { sh_to_rgb(c, mean, sh, rgb); }
+
+/* ---- viewer-semantics helpers (reference viewer.py:301-336 -> gsplat.rasterization with quats/scales/SH colours; gsplat@961678f4 is not
+ * in /root/reference: published algorithm restated, PARITY UNPINNED like the rest of this file) ------------------------------------- */
+
+/* gsplat quat_scale_to_covar: q = (w,x,y,z) normalised, M = R diag(s), Sigma = M M^T, returned as the 6 upper-triangular entries */
+void raster_ref_quat_scale_to_cov6(int64_t G, const float* quats, const float* scales, float* cov6) {
+  for (int64_t g = 0; g < G; ++g) {
+    float w = quats[4 * g], x = quats[4 * g + 1], y = quats[4 * g + 2], z = quats[4 * g + 3];
+    const float inv = 1.0f / sqrtf(w * w + x * x + y * y + z * z);
+    w *= inv; x *= inv; y *= inv; z *= inv;
+    const float x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+    const float R[9] = {1.0f - 2.0f * (y2 + z2), 2.0f * (xy - wz), 2.0f * (xz + wy), 2.0f * (xy + wz), 1.0f - 2.0f * (x2 + z2), 2.0f * (yz - wx),
+                        2.0f * (xz - wy), 2.0f * (yz + wx), 1.0f - 2.0f * (x2 + y2)};
+    const float s0 = scales[3 * g], s1 = scales[3 * g + 1], s2 = scales[3 * g + 2];
+    float M[9];
+    for (int r = 0; r < 3; ++r) { M[3 * r] = R[3 * r] * s0; M[3 * r + 1] = R[3 * r + 1] * s1; M[3 * r + 2] = R[3 * r + 2] * s2; }
+    int o = 0;
+    for (int r = 0; r < 3; ++r)
+      for (int c = r; c < 3; ++c) cov6[6 * g + o++] = M[3 * r] * M[3 * c] + M[3 * r + 1] * M[3 * c + 1] + M[3 * r + 2] * M[3 * c + 2];
+  }
+}
+
+/* gsplat spherical_harmonics (sh_coeffs_to_color_fast, Sloan's recurrences) + rasterization()'s clamp_min(c + 0.5, 0);
+ * sh [G, ncoef, 3], dirs = mean - campos (normalised here), degree <= 4 */
+void raster_ref_sh_eval(int64_t G, int degree, int ncoef, const float* means, const float* campos, const float* sh, float* rgb) {
+  for (int64_t g = 0; g < G; ++g) {
+    const float dx = means[3 * g] - campos[0], dy = means[3 * g + 1] - campos[1], dz = means[3 * g + 2] - campos[2];
+    const float inorm = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = dx * inorm, y = dy * inorm, z = dz * inorm;
+    float b[25];
+    b[0] = 0.2820947917738781f;
+    if (degree >= 1) { b[1] = -0.48860251190292f * y; b[2] = 0.48860251190292f * z; b[3] = -0.48860251190292f * x; }
+    float z2 = 0, fC1 = 0, fS1 = 0, fC2 = 0, fS2 = 0;
+    if (degree >= 2) {
+      z2 = z * z;
+      const float fTmp0B = -1.092548430592079f * z;
+      fC1 = x * x - y * y;
+      fS1 = 2.0f * x * y;
+      b[6] = 0.9461746957575601f * z2 - 0.3153915652525201f; b[7] = fTmp0B * x; b[5] = fTmp0B * y; b[8] = 0.5462742152960395f * fC1; b[4] = 0.5462742152960395f * fS1;
+    }
+    if (degree >= 3) {
+      const float fTmp0C = -2.285228997322329f * z2 + 0.4570457994644658f, fTmp1B = 1.445305721320277f * z;
+      fC2 = x * fC1 - y * fS1;
+      fS2 = x * fS1 + y * fC1;
+      b[12] = z * (1.865881662950577f * z2 - 1.119528997770346f); b[13] = fTmp0C * x; b[11] = fTmp0C * y; b[14] = fTmp1B * fC1; b[10] = fTmp1B * fS1;
+      b[15] = -0.5900435899266435f * fC2; b[9] = -0.5900435899266435f * fS2;
+    }
+    if (degree >= 4) {
+      const float fTmp0D = z * (-4.683325804901025f * z2 + 2.007139630671868f), fTmp1C = 3.31161143515146f * z2 - 0.47308734787878f, fTmp2B = -1.770130769779931f * z;
+      const float fC3 = x * fC2 - y * fS2, fS3 = x * fS2 + y * fC2;
+      b[20] = 1.984313483298443f * z * b[12] - 1.006230589874905f * b[6]; b[21] = fTmp0D * x; b[19] = fTmp0D * y; b[22] = fTmp1C * fC1; b[18] = fTmp1C * fS1;
+      b[23] = fTmp2B * fC2; b[17] = fTmp2B * fS2; b[24] = 0.6258357354491763f * fC3; b[16] = 0.6258357354491763f * fS3;
+    }
+    const int nb = (degree + 1) * (degree + 1);
+    for (int ch = 0; ch < 3; ++ch) {
+      float r = 0.0f;
+      for (int i = 0; i < nb; ++i) r = r + b[i] * sh[((size_t)g * ncoef + i) * 3 + ch];
+      r += 0.5f;
+      rgb[3 * g + ch] = r < 0.0f ? 0.0f : r;
+    }
+  }
+}
+
+/* colors[P, C] += (1 - alpha[P]) * bg[C]  (gsplat `backgrounds`) */
+void raster_ref_blend_background(int64_t P, int C, float* colors, const float* alpha, const float* bg) {
+  for (int64_t p = 0; p < P; ++p)
+    for (int c = 0; c < C; ++c) colors[p * C + c] = colors[p * C + c] + (1.0f - alpha[p]) * bg[c];
+}

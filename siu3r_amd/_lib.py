@@ -90,6 +90,9 @@ SIGNATURES = {
     "siu3r_raster_composite_rgb": [C.POINTER(RasterCam), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     "siu3r_raster_composite_feat": [C.POINTER(RasterCam), _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "siu3r_scale_inplace": [_P, _L, _F, _P],
+    "siu3r_quat_scale_to_cov6": [_P, _P, _P, _L, _P],
+    "siu3r_sh_eval": [_P, _P, _P, _I, _I, _P, _L, _P],
+    "siu3r_blend_background": [_P, _P, _P, _I, _L, _P],
     "siu3r_lift_ids": [_P, _I, _I, _I, _I, _I, _F, _I, C.c_uint32, _P, _P, _P, _P, _P],
     "siu3r_panoptic_stage1": [_P] * 20 + [_I] * 9 + [_F, _F, _F, C.c_uint32, _P],
     "siu3r_panoptic_qcl": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -55,7 +55,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 __constant__ float c_SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
 __constant__ float c_SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
-__constant__ float c_SH_C4[9] = {2.5033429417967046f, 1.7701307697799304f, 0.9461746957575601f, 0.6690465435572892f, 0.10578554691520431f, 0.6690465435572892f, 0.47308734787878004f, 1.7701307697799304f, 0.6258357354491761f};
+__constant__ float c_SH_C4[9] = {2.5033429417967046f, -1.7701307697799304f, 0.9461746957575601f, -0.6690465435572892f, 0.10578554691520431f, -0.6690465435572892f, 0.47308734787878004f, -1.7701307697799304f, 0.6258357354491761f};
 
 __global__ void project_kernel(Cam c, int64_t G, const float* means, const float* cov6, const float* opac,
                                const float* colors, int channels, float* mean2d, float* conic_op, float* depth,
@@ -505,6 +505,93 @@ void to_cam(const siu3r_raster_cam* in, Cam* c) {
 
 }  // namespace
 
+// ---- viewer-semantics helpers (reference viewer.py:301-336: gsplat.rasterization fed with quats / exp(scales) / SH) ----------------
+__global__ void quat_scale_cov6_kernel(int64_t G, const float* quats, const float* scales, float* cov6) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const float4 q = *(const float4*)(quats + 4 * g);
+  float w = q.x, x = q.y, y = q.z, z = q.w;
+  const float inv = 1.0f / sqrtf(w * w + x * x + y * y + z * z);
+  w *= inv; x *= inv; y *= inv; z *= inv;
+  const float x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+  const float R[9] = {1.0f - 2.0f * (y2 + z2), 2.0f * (xy - wz), 2.0f * (xz + wy), 2.0f * (xy + wz), 1.0f - 2.0f * (x2 + z2), 2.0f * (yz - wx),
+                      2.0f * (xz - wy), 2.0f * (yz + wx), 1.0f - 2.0f * (x2 + y2)};
+  const float s0 = scales[3 * g], s1 = scales[3 * g + 1], s2 = scales[3 * g + 2];
+  float M[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { M[3 * r] = R[3 * r] * s0; M[3 * r + 1] = R[3 * r + 1] * s1; M[3 * r + 2] = R[3 * r + 2] * s2; }
+  int o = 0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = r; c < 3; ++c) cov6[6 * g + o++] = M[3 * r] * M[3 * c] + M[3 * r + 1] * M[3 * c + 1] + M[3 * r + 2] * M[3 * c + 2];
+}
+
+template <int DEG>
+__global__ void sh_eval_kernel(int64_t G, int ncoef, const float* means, float cx, float cy, float cz, const float* sh, float* rgb) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const float dx = means[3 * g] - cx, dy = means[3 * g + 1] - cy, dz = means[3 * g + 2] - cz;
+  const float inorm = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+  const float x = dx * inorm, y = dy * inorm, z = dz * inorm;
+  constexpr int NB = (DEG + 1) * (DEG + 1);
+  float b[25];
+  b[0] = 0.2820947917738781f;
+  if (DEG >= 1) { b[1] = -0.48860251190292f * y; b[2] = 0.48860251190292f * z; b[3] = -0.48860251190292f * x; }
+  float z2 = 0, fC1 = 0, fS1 = 0, fC2 = 0, fS2 = 0;
+  if (DEG >= 2) {
+    z2 = z * z;
+    const float fTmp0B = -1.092548430592079f * z;
+    fC1 = x * x - y * y;
+    fS1 = 2.0f * x * y;
+    b[6] = 0.9461746957575601f * z2 - 0.3153915652525201f; b[7] = fTmp0B * x; b[5] = fTmp0B * y; b[8] = 0.5462742152960395f * fC1; b[4] = 0.5462742152960395f * fS1;
+  }
+  if (DEG >= 3) {
+    const float fTmp0C = -2.285228997322329f * z2 + 0.4570457994644658f, fTmp1B = 1.445305721320277f * z;
+    fC2 = x * fC1 - y * fS1;
+    fS2 = x * fS1 + y * fC1;
+    b[12] = z * (1.865881662950577f * z2 - 1.119528997770346f); b[13] = fTmp0C * x; b[11] = fTmp0C * y; b[14] = fTmp1B * fC1; b[10] = fTmp1B * fS1;
+    b[15] = -0.5900435899266435f * fC2; b[9] = -0.5900435899266435f * fS2;
+  }
+  if (DEG >= 4) {
+    const float fTmp0D = z * (-4.683325804901025f * z2 + 2.007139630671868f), fTmp1C = 3.31161143515146f * z2 - 0.47308734787878f, fTmp2B = -1.770130769779931f * z;
+    const float fC3 = x * fC2 - y * fS2, fS3 = x * fS2 + y * fC2;
+    b[20] = 1.984313483298443f * z * b[12] - 1.006230589874905f * b[6]; b[21] = fTmp0D * x; b[19] = fTmp0D * y; b[22] = fTmp1C * fC1; b[18] = fTmp1C * fS1;
+    b[23] = fTmp2B * fC2; b[17] = fTmp2B * fS2; b[24] = 0.6258357354491763f * fC3; b[16] = 0.6258357354491763f * fS3;
+  }
+  // the coefficient block ([coef][rgb], 4-byte aligned) as 16-byte loads
+  struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
+  const float* shp = sh + (size_t)g * ncoef * 3;
+  float c[NB * 3 + 3];
+#pragma unroll
+  for (int q = 0; q < (NB * 3 + 3) / 4; ++q) {
+    if (4 * q + 4 <= ncoef * 3) {
+      const f4u t4 = *(const f4u*)(shp + 4 * q);
+      c[4 * q] = t4.v[0]; c[4 * q + 1] = t4.v[1]; c[4 * q + 2] = t4.v[2]; c[4 * q + 3] = t4.v[3];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c[4 * q + e] = (4 * q + e < ncoef * 3) ? shp[4 * q + e] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    float r = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) r = r + b[i] * c[i * 3 + ch];
+    r += 0.5f;
+    rgb[3 * g + ch] = r < 0.0f ? 0.0f : r;
+  }
+}
+
+__global__ void blend_bg_kernel(int64_t n, int C, float* colors, const float* alpha, float b0, float b1, float b2, const float* bg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t p = i / C;
+  const int c = (int)(i - p * C);
+  const float b = bg ? bg[c] : (c == 0 ? b0 : (c == 1 ? b1 : b2));
+  colors[i] = colors[i] + (1.0f - alpha[p]) * b;
+}
+
 // ---- C ABI -------------------------------------------------------------------------------------------------------
 extern "C" int siu3r_raster_bin(const siu3r_raster_cam* cam, int64_t G, const float* means, const float* cov6,
                                 const float* opacities, const float* colors, int channels, float* mean2d, float* conic_op,
@@ -576,5 +663,42 @@ extern "C" int siu3r_scale_inplace(float* x, int64_t n, float s, void* stream) {
   SIU3R_CHECK(x || n == 0, "scale_inplace: null pointer");
   if (n > 0) hipLaunchKernelGGL(scale_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, x, n, s);
   SIU3R_LAUNCH_CHECK("siu3r_scale_inplace");
+  return 0;
+}
+
+extern "C" int siu3r_quat_scale_to_cov6(const float* quats_wxyz, const float* scales, float* cov6, int64_t G, void* stream) {
+  SIU3R_CHECK(G == 0 || (quats_wxyz && scales && cov6), "quat_scale_to_cov6: null pointer");
+  SIU3R_CHECK(((uintptr_t)quats_wxyz & 15) == 0, "quat_scale_to_cov6: quats must be 16-byte aligned");
+  if (G > 0) hipLaunchKernelGGL(quat_scale_cov6_kernel, g1(G), dim3(256), 0, (hipStream_t)stream, G, quats_wxyz, scales, cov6);
+  SIU3R_LAUNCH_CHECK("siu3r_quat_scale_to_cov6");
+  return 0;
+}
+
+extern "C" int siu3r_sh_eval(const float* means, const float* campos3_host, const float* sh, int ncoef, int degree, float* rgb, int64_t G,
+                             void* stream) {
+  SIU3R_CHECK(G == 0 || (means && campos3_host && sh && rgb), "sh_eval: null pointer");
+  SIU3R_CHECK(degree >= 0 && degree <= 4 && ncoef >= (degree + 1) * (degree + 1), "sh_eval: degree %d needs %d coefficients, got %d", degree,
+              (degree + 1) * (degree + 1), ncoef);
+  if (G == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const float cx = campos3_host[0], cy = campos3_host[1], cz = campos3_host[2];
+  switch (degree) {
+    case 0: hipLaunchKernelGGL(sh_eval_kernel<0>, g1(G), dim3(256), 0, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
+    case 1: hipLaunchKernelGGL(sh_eval_kernel<1>, g1(G), dim3(256), 0, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
+    case 2: hipLaunchKernelGGL(sh_eval_kernel<2>, g1(G), dim3(256), 0, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
+    case 3: hipLaunchKernelGGL(sh_eval_kernel<3>, g1(G), dim3(256), 0, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
+    default: hipLaunchKernelGGL(sh_eval_kernel<4>, g1(G), dim3(256), 0, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
+  }
+  SIU3R_LAUNCH_CHECK("siu3r_sh_eval");
+  return 0;
+}
+
+extern "C" int siu3r_blend_background(float* colors, const float* alpha, const float* bg_host, int channels, int64_t pixels, void* stream) {
+  SIU3R_CHECK(pixels == 0 || (colors && alpha && bg_host), "blend_background: null pointer");
+  SIU3R_CHECK(channels >= 1 && channels <= 3, "blend_background: 1..3 channels (got %d)", channels);
+  if (pixels > 0)
+    hipLaunchKernelGGL(blend_bg_kernel, g1(pixels * channels), dim3(256), 0, (hipStream_t)stream, pixels * channels, channels, colors, alpha, bg_host[0],
+                       channels > 1 ? bg_host[1] : 0.f, channels > 2 ? bg_host[2] : 0.f, (const float*)nullptr);
+  SIU3R_LAUNCH_CHECK("siu3r_blend_background");
   return 0;
 }

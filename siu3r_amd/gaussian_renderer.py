@@ -111,3 +111,31 @@ def lift_query_class_logits(render_qc_logits: List[torch.Tensor], query_scores: 
         all_ins.append(ins)
         seg_infos.append(info)
     return torch.stack(all_sem), torch.stack(all_ins), seg_infos
+
+
+def rasterize_splats(splats: dict, camtoworlds: torch.Tensor, Ks: torch.Tensor, width: int, height: int, sh_degree: int = 4,
+                     radius_clip: float = 0.1, near_plane: float = 0.01, far_plane: float = 1e10, backgrounds=(1.0, 1.0, 1.0)):
+    """The reference viewer's render call (viewer.py:301-336 + 376-401): gsplat.rasterization semantics with
+    quats (w,x,y,z) / log-scales / logit-opacities / SH coefficients `sh0` [G,1,3] + `shN` [G,K-1,3] as loaded from the
+    exported PLY, pixel-unit intrinsics, white background, radius_clip = 0.1 px.  camtoworlds [C,4,4], Ks [C,3,3].
+    Returns (render_colors [C,H,W,3], render_alphas [C,H,W,1], info)."""
+    from . import raster
+
+    means = splats["means"].float()
+    cov6 = raster.quat_scale_to_cov6(splats["quats"], torch.exp(splats["scales"].float()))
+    opac = torch.sigmoid(splats["opacities"].float())
+    coeffs = torch.cat([splats["sh0"], splats["shN"]], 1).float() if "shN" in splats and splats["shN"] is not None else splats["sh0"].float()
+    assert coeffs.shape[1] >= (sh_degree + 1) ** 2
+    cols, alphas, visible, pairs = [], [], [], []
+    for c2w, K in zip(camtoworlds.cpu().float(), Ks.cpu().float()):
+        w2c = torch.linalg.inv(c2w)
+        cam = raster.make_cam_k3(w2c, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), width, height, near_plane, far_plane,
+                                 radius_clip=radius_clip)
+        rgb = raster.sh_eval(means, c2w[:3, 3].tolist(), coeffs, sh_degree)
+        o = raster.rasterize_k3(cam, means, cov6, opac, rgb)
+        raster.blend_background_(o["colors"], o["alphas"], backgrounds)
+        cols.append(o["colors"])
+        alphas.append(o["alphas"][..., None])
+        visible.append(o["state"]["tiles_touched"])
+        pairs.append(o["state"]["D"])
+    return torch.stack(cols), torch.stack(alphas), dict(tiles_touched=visible, tile_pairs=pairs)

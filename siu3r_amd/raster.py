@@ -115,6 +115,34 @@ def scale_inplace_(x: torch.Tensor, s: float):
     return x
 
 
+def quat_scale_to_cov6(quats_wxyz: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
+    """[G,4] (w,x,y,z) + [G,3] -> [G,6] (gsplat's quat_scale_to_covar, upper triangle)."""
+    _gpu(quats_wxyz, scales)
+    q, sc = quats_wxyz.contiguous().float(), scales.contiguous().float()
+    out = torch.empty((q.shape[0], 6), dtype=torch.float32, device=q.device)
+    check(_lib.lib().siu3r_quat_scale_to_cov6(_p(q), _p(sc), _p(out), q.shape[0], _stream()))
+    return out
+
+
+def sh_eval(means: torch.Tensor, campos, sh: torch.Tensor, degree: int) -> torch.Tensor:
+    """means [G,3], campos (3 floats, host), sh [G,ncoef,3] -> rgb [G,3] = max(SH . coeffs + 0.5, 0)."""
+    _gpu(means, sh)
+    means, sh = means.contiguous().float(), sh.contiguous().float()
+    cam = (C.c_float * 3)(*[float(v) for v in campos])
+    out = torch.empty((means.shape[0], 3), dtype=torch.float32, device=means.device)
+    check(_lib.lib().siu3r_sh_eval(_p(means), C.cast(cam, C.c_void_p), _p(sh), sh.shape[1], int(degree), _p(out), means.shape[0], _stream()))
+    return out
+
+
+def blend_background_(colors: torch.Tensor, alphas: torch.Tensor, bg) -> torch.Tensor:
+    """colors [H,W,C<=3] += (1 - alphas[H,W]) * bg, in place."""
+    _gpu(colors, alphas)
+    assert colors.is_contiguous() and alphas.is_contiguous() and colors.dtype == torch.float32
+    b = (C.c_float * 3)(*([float(v) for v in bg] + [0.0] * (3 - len(bg))))
+    check(_lib.lib().siu3r_blend_background(_p(colors), _p(alphas), C.cast(b, C.c_void_p), colors.shape[-1], alphas.numel(), _stream()))
+    return colors
+
+
 def algorithmic_bytes(G: int, G_v: int, D: int, P: int, channels: Optional[int] = None) -> int:
     """Algorithmic HBM bytes of one rendered view (SURVEY.md section 8(d)): RGB path 348 G + 48 G_v + 88 D + 20 P;
     C-channel path (44+4C) G + 36 G_v + (76+4C) D + (4C+4) P."""

@@ -95,3 +95,42 @@ def test_multiview_forward_against_reference_vectors():
         compare_summary(f, out[f], z, 2e-4)
     assert int(out["semantic_labels"].sum()) == int(z["semantic_labels.sum"]) and int(out["instance_labels"].sum()) == int(z["instance_labels.sum"])
     assert out["seg_infos"] == meta["seg_infos"] and out["query_scores"] == meta["query_scores"]
+
+
+def test_sh_basis_forms_agree():
+    """The two SH evaluations of the raster oracle -- explicit 3DGS-style polynomials (K2 path, raster_ref.c sh_to_rgb) and
+    Sloan's recurrences (gsplat path, raster_ref_sh_eval) -- are the same real basis with the same sign convention
+    (odd |m| negative) up to degree 4: one-hot coefficient probes through both give the same colours."""
+    import ctypes as C
+
+    from oracle import raster_oracle as RO
+
+    rng = np.random.default_rng(0)
+    G = 64
+    means = rng.normal(size=(G, 3)).astype(np.float32) + np.array([0, 0, 4], np.float32)
+    campos = np.array([0.1, -0.2, 0.3], np.float32)
+    cov6 = np.tile(np.array([1e-4, 0, 0, 1e-4, 0, 1e-4], np.float32), (G, 1))
+    from siu3r_amd._lib import RasterCam  # plain ctypes struct (no GPU needed)
+
+    cam = RasterCam()
+    cam.mode, cam.width, cam.height, cam.sh_degree, cam.sh_band4 = 0, 64, 64, 4, 1
+    for i, v in enumerate([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]):
+        cam.w2c[i] = v
+        cam.proj[i] = v
+    cam.tanfovx = cam.tanfovy = 0.5
+    cam.k2_znear_cull, cam.dilation = 0.2, 0.3
+    for i in range(3):
+        cam.campos[i] = float(campos[i])
+    for k in range(25):
+        sh = np.zeros((G, 25, 3), np.float32)
+        sh[:, k, :] = 1.0
+        a = RO.sh_eval(4, means, campos, sh)
+        out = np.zeros((G, 3), np.float32)
+        # the K2 evaluation is reachable through the full forward only: per-Gaussian colours land in the image for isolated splats;
+        # compare the bases directly instead through the library's exported helper when present
+        fn = getattr(RO.lib(), "raster_ref_sh_to_rgb", None)
+        if fn is None:
+            pytest.skip("oracle library without the exported K2 SH helper")
+        for g_ in range(G):
+            fn(C.byref(cam), means[g_].ctypes.data_as(C.c_void_p), sh[g_].ctypes.data_as(C.c_void_p), out[g_].ctypes.data_as(C.c_void_p))
+        assert np.abs(a - out).max() <= 2e-6, (k, np.abs(a - out).max())

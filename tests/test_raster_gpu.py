@@ -125,3 +125,41 @@ def test_splatting_cuda_mirror_and_lifting():
     rs, ri, rinfo = O.lift_ids(rq.cpu(), scores[0])
     assert sem.dtype == torch.int64 and torch.equal(sem[0].cpu(), rs) and torch.equal(ins[0].cpu(), ri)
     assert infos[0] == rinfo
+
+
+@pytest.mark.parametrize("degree", [0, 3, 4])
+def test_viewer_render_semantics(degree):
+    """rasterize_splats (reference viewer.py:301-336: quats / log-scales / logit-opacities / SH, white background,
+    radius_clip 0.1) vs the C oracle restatement: covariances and view-dependent colours bit-exact, tile lists exact."""
+    from oracle import raster_oracle as RO
+    from siu3r_amd import raster
+    from siu3r_amd.gaussian_renderer import rasterize_splats
+
+    G, H, W = 6000, 144, 208
+    means, cov, opac, sh = random_scene(G, seed=7)
+    g = torch.Generator().manual_seed(8)
+    quats = torch.randn(G, 4, generator=g) * 2.0          # un-normalised, as the viewer feeds them
+    lscale = torch.log(0.01 + 0.1 * torch.rand(G, 3, generator=g))
+    logit = torch.logit(opac.clamp(0.02, 0.98))
+    coeffs = sh.permute(0, 2, 1).contiguous()               # [G, 25, 3]
+    c2w = look_at_camera(3)
+    K = default_K().clone()
+    K[0] *= W
+    K[1] *= H
+    splats = dict(means=means.cuda(), quats=quats.cuda(), scales=lscale.cuda(), opacities=logit.cuda(), sh0=coeffs[:, :1].cuda(), shN=coeffs[:, 1:].cuda())
+    colors, alphas, info = rasterize_splats(splats, c2w[None], K[None], W, H, sh_degree=degree, radius_clip=0.1)
+    # oracle chain
+    cov6_ref = RO.quat_scale_to_cov6(quats.numpy(), torch.exp(lscale).numpy())
+    cov6 = raster.quat_scale_to_cov6(quats.cuda(), torch.exp(lscale).cuda()).cpu().numpy()
+    assert np.array_equal(cov6, cov6_ref), f"cov6 differs: {np.abs(cov6 - cov6_ref).max()}"
+    rgb_ref = RO.sh_eval(degree, means.numpy(), c2w[:3, 3].numpy(), coeffs.numpy())
+    rgb = raster.sh_eval(means.cuda(), c2w[:3, 3].tolist(), coeffs.cuda(), degree).cpu().numpy()
+    assert np.abs(rgb - rgb_ref).max() <= 1e-6, np.abs(rgb - rgb_ref).max()
+    cam = raster.make_cam_k3(torch.linalg.inv(c2w), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), W, H, radius_clip=0.1)
+    ref = RO.forward(cam, means.numpy(), cov6_ref, torch.sigmoid(logit).numpy(), rgb_ref)
+    want = RO.blend_background(ref["image"], ref["alpha"], np.ones(3, np.float32))
+    assert info["tile_pairs"][0] == ref["D"]
+    assert np.array_equal(info["tiles_touched"][0].cpu().numpy(), ref["tiles_touched"])
+    assert np.abs(alphas[0, ..., 0].cpu().numpy() - ref["alpha"]).max() <= 2e-6
+    assert np.abs(colors[0].cpu().numpy() - want).max() <= 5e-6
+    assert float(colors.min()) >= 0.0 and ref["D"] > 1000
