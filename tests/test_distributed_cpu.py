@@ -42,3 +42,50 @@ def test_single_process_paths():
     g = D.all_gather_stats(D.pack_stats(dict(n_pairs=3, n_images=6, sum_psnr=60.0)))
     assert g.shape == (1, len(D.STAT_KEYS)) and D.reduce_stats(g)["psnr"] == 10.0
     assert D.max_over_ranks(1.5) == 1.5
+
+
+def _metric_worker(rank, world, port, q):
+    import numpy as np
+
+    from siu3r_amd import metrics as M
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, _, w = D.init_from_env(backend="gloo")
+    acc = M.MetricAccumulator()
+    for i in D.shard_indices(5, r, w):       # scene i: a deterministic little prediction / ground-truth pair
+        rng = np.random.default_rng(100 + i)
+        gs = rng.integers(0, 8, (6, 10))
+        gi = rng.integers(0, 3, (6, 10))
+        ps = np.where(rng.random((6, 10)) < 0.3, rng.integers(0, 8, (6, 10)), gs)
+        acc.add_segmentation("context", ps, gi, gs, gi)
+        acc.add_render(rng.random((4, 4, 3)).astype(np.float32), rng.random((4, 4, 3)).astype(np.float32))
+    gathered = D.all_gather_stats(torch.from_numpy(acc.to_vector()))      # the path's single collective
+    q.put((rank, M.MetricAccumulator.from_vectors(gathered.numpy()).compute()))
+    dist.destroy_process_group()
+
+
+def test_metric_vector_gather_world2():
+    """Sharded evaluation == single-process evaluation (the statistics are additive; reference: rank-0 file-based evaluator)."""
+    import numpy as np
+
+    from siu3r_amd import metrics as M
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_metric_worker, args=(r, 2, 29631, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(timeout=60) for p in ps]
+    whole = M.MetricAccumulator()
+    for i in range(5):
+        rng = np.random.default_rng(100 + i)
+        gs = rng.integers(0, 8, (6, 10))
+        gi = rng.integers(0, 3, (6, 10))
+        pr = np.where(rng.random((6, 10)) < 0.3, rng.integers(0, 8, (6, 10)), gs)
+        whole.add_segmentation("context", pr, gi, gs, gi)
+        whole.add_render(rng.random((4, 4, 3)).astype(np.float32), rng.random((4, 4, 3)).astype(np.float32))
+    want = whole.compute()
+    for _, got in res:
+        assert set(got) == set(want)
+        assert abs(got["psnr"] - want["psnr"]) < 1e-12 and abs(got["context_pq"] - want["context_pq"]) < 1e-12
+        assert np.allclose(got["context_ious_per_class"], want["context_ious_per_class"], atol=1e-12)
