@@ -1,0 +1,60 @@
+"""BASELINE.json configs[4]: 8 views x 512^2 through the multi-view model (2 097 152 Gaussians), then one novel 1920x1080 view with the
+viewer's render semantics (gsplat-style, SH degree 4, white background) and with the K2 (SplattingCUDA) semantics.
+python tools/config5.py > gpurun_out/config5.json"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import weights as OW
+from siu3r_amd import raster, synthetic
+from siu3r_amd.gaussian_renderer import SplattingCUDA, rasterize_splats
+from siu3r_amd.gaussians_types import Gaussians
+from siu3r_amd.model import SIU3RMultiViewModel
+
+V, S, W, H = 8, 512, 1920, 1080
+dev = torch.device("cuda", 0)
+model = SIU3RMultiViewModel(OW.make_weights(0), image_size=(S, S), precision="bf16", device=dev)
+g = torch.Generator().manual_seed(5)
+images = torch.rand(1, V, 3, S, S, generator=g).to(dev)
+K = synthetic.default_intrinsics()[None, None].repeat(1, V, 1, 1).to(dev)
+for _ in range(3):
+    out = model(images, K)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 5
+for _ in range(n):
+    out = model(images, K)
+torch.cuda.synchronize()
+ms_model = (time.perf_counter() - t0) / n * 1e3
+G_ = out[0]
+res = dict(views=V, image_size=[S, S], gaussians=int(G_.means.shape[1]), model_ms_per_forward=ms_model, segments=len(out[3][0]))
+# viewer semantics (A25b): quats wxyz, log-scales, logit-opacities, SH [G,25,3]
+x, y, z, w = G_.rotations[0].unbind(-1)
+splats = dict(means=G_.means[0], quats=torch.stack((w, x, y, z), -1).contiguous(), scales=G_.scales[0].log(), opacities=torch.logit(G_.opacities[0].clamp(1e-6, 1 - 1e-6)),
+              sh0=G_.harmonics[0].permute(0, 2, 1)[:, :1].contiguous(), shN=G_.harmonics[0].permute(0, 2, 1)[:, 1:].contiguous())
+c2w = synthetic.target_views(3)[1][None]
+Kp = torch.tensor([[0.6 * W, 0, W / 2], [0, 0.6 * W, H / 2], [0, 0, 1]])[None]
+for _ in range(2):
+    col, al, info = rasterize_splats(splats, c2w, Kp, W, H, sh_degree=4, radius_clip=0.1)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    col, al, info = rasterize_splats(splats, c2w, Kp, W, H, sh_degree=4, radius_clip=0.1)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / n * 1e3
+Gv, D = int((info["tiles_touched"][0] > 0).sum()), int(info["tile_pairs"][0])
+b = raster.algorithmic_bytes(res["gaussians"], Gv, D, H * W, channels=3) + res["gaussians"] * 300
+res["viewer_render"] = dict(ms_per_frame=ms, resolution=[W, H], visible=Gv, tile_pairs=D, algorithmic_GBps=b / ms / 1e6, mean_alpha=float(al.mean()))
+# K2 semantics (SplattingCUDA.forward: x10 scene scale, black background, colour + depth)
+rend = SplattingCUDA()
+ext, Kt = c2w[None].to(dev), synthetic.default_intrinsics()[None, None].to(dev)
+def fresh():
+    return Gaussians(means=G_.means.clone(), covariances=G_.covariances.clone(), harmonics=G_.harmonics, opacities=G_.opacities)
+rend.forward(fresh(), ext, Kt, (H, W), render_color=True)
+gs = [fresh() for _ in range(n)]
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for g_ in gs:
+    rend.forward(g_, ext, Kt, (H, W), render_color=True)
+torch.cuda.synchronize()
+res["k2_render"] = dict(ms_per_frame=(time.perf_counter() - t0) / n * 1e3, resolution=[W, H])
+print(json.dumps(res))
