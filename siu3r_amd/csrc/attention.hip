@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
 //     only on a ragged last tile; the O rescale is skipped while no lane's running maximum grows;
 //   * P is packed with v_cvt_pk_bf16_f32; the cross-half maximum / sum use v_permlane32_swap.
 // Per 64-key tile and wave: 16 MFMAs (512 cycles) against ~32 v_exp_f32 (quarter rate, 512 cycles) + ~110 VALU.
-template <int D, int MASK>
+template <int D, int MASK, int SPLITKV>
 __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params p) {
   constexpr int K_BYTES = KT * D * 2;
   constexpr int V_BYTES = KT * D * 2;
@@ -385,7 +385,8 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q_row = blockIdx.x * 128 + wave * 32 + l31;
+  // SPLITKV: one 128-query tile (Nq <= 128); blockIdx.x is the key-range index instead
+  const int q_row = (SPLITKV ? 0 : blockIdx.x * 128) + wave * 32 + l31;
   const bool q_ok = q_row < p.Nq;
   const float sl2 = p.scale * 1.4426950408889634f;
 
@@ -436,6 +437,12 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
   float m_run = NEG_BIG, l_run = 0.f;
   const int nkt = (p.Nk + KT - 1) / KT;
   const bool ragged = (p.Nk & (KT - 1)) != 0;
+  int kt0 = 0, kt1 = nkt;  // this workgroup's range of 64-key tiles
+  if (SPLITKV) {
+    const int per = (nkt + p.splits - 1) / p.splits;
+    kt0 = blockIdx.x * per;
+    kt1 = min(nkt, kt0 + per);
+  }
 
   const uint8_t* mrow = nullptr;
   if constexpr (MASK) mrow = p.mask + ((int64_t)b * p.Nq + (q_ok ? q_row : p.Nq - 1)) * p.mask_ld;
@@ -551,27 +558,44 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
   };
   KVRegs r0, r1;
   uint4 mA[4], mB[4];
-  load_tile(0, r0);
-  load_mask(0, mA);
-  if (nkt > 1) load_tile(1, r1);
-  store_tile(0, r0);
-  lds_barrier();
-  for (int kt = 0; kt < nkt; kt += 2) {
-    if (kt + 2 < nkt) load_tile(kt + 2, r0);
-    if (kt + 1 < nkt) load_mask(kt + 1, mB);
-    process(kt, 0, mA);
-    if (kt + 1 < nkt) store_tile(1, r1);
+  if (kt0 < kt1) {
+    load_tile(kt0, r0);
+    load_mask(kt0, mA);
+    if (kt0 + 1 < kt1) load_tile(kt0 + 1, r1);
+    store_tile(0, r0);
     lds_barrier();
-    if (kt + 1 >= nkt) break;
-    if (kt + 3 < nkt) load_tile(kt + 3, r1);
-    if (kt + 2 < nkt) load_mask(kt + 2, mA);
-    process(kt + 1, 1, mB);
-    if (kt + 2 < nkt) store_tile(0, r0);
-    lds_barrier();
+    for (int kt = kt0; kt < kt1; kt += 2) {
+      if (kt + 2 < kt1) load_tile(kt + 2, r0);
+      if (kt + 1 < kt1) load_mask(kt + 1, mB);
+      process(kt, 0, mA);
+      if (kt + 1 < kt1) store_tile(1, r1);
+      lds_barrier();
+      if (kt + 1 >= kt1) break;
+      if (kt + 3 < kt1) load_tile(kt + 3, r1);
+      if (kt + 2 < kt1) load_mask(kt + 2, mA);
+      process(kt + 1, 1, mB);
+      if (kt + 2 < kt1) store_tile(0, r0);
+      lds_barrier();
+    }
   }
 
   // epilogue: O[q, h*D + d] = O^T[d][q] / l
   const float l_tot = l_run + other_half(l_run);
+  if (SPLITKV) {
+    // partial result of this key range: un-normalised O (relative to m_run), m_run and l; an empty range contributes
+    // (NEG_BIG, 0, 0), which the combine step weights by exp2(-inf) = 0
+    float* w = p.ws + ((((int64_t)b * p.H + h) * p.splits + blockIdx.x) * 128 + (wave * 32 + l31)) * (D + 4);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(float4*)(w + dt * 32 + 8 * g + 4 * lh) = make_float4(oacc[dt][4 * g], oacc[dt][4 * g + 1], oacc[dt][4 * g + 2], oacc[dt][4 * g + 3]);
+    if (lh == 0) {
+      w[D] = m_run;
+      w[D + 1] = l_tot;
+    }
+    return;
+  }
   const float inv = 1.f / l_tot;
   if (q_ok) {
     u16* op = (u16*)p.out + ((int64_t)b * p.Nq + q_row) * ((int64_t)p.H * D) + (int64_t)h * D;
@@ -588,13 +612,54 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
   }
 }
 
+// combine the key-range partials of attn_fast_kernel<.., SPLITKV=1>: one thread per (b, h, query, 4 d)
+template <int D>
+__global__ void attn_combine_kernel(const siu3r_attn_params p) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int d4 = (int)(i % (D / 4));
+  const int64_t r = i / (D / 4);
+  const int q = (int)(r % p.Nq);
+  const int64_t bh = r / p.Nq;
+  if (bh >= (int64_t)p.B * p.H) return;
+  const float sl2 = p.scale * 1.4426950408889634f;
+  const float* w = p.ws + (bh * p.splits * 128 + q) * (D + 4);
+  float M = NEG_BIG;
+  for (int s_ = 0; s_ < p.splits; ++s_) M = fmaxf(M, w[(int64_t)s_ * 128 * (D + 4) + D]);
+  float L = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+  for (int s_ = 0; s_ < p.splits; ++s_) {
+    const float* ws = w + (int64_t)s_ * 128 * (D + 4);
+    const float wt = __builtin_amdgcn_exp2f((ws[D] - M) * sl2);
+    const float4 o = *(const float4*)(ws + 4 * d4);
+    L += wt * ws[D + 1];
+    o0 += wt * o.x; o1 += wt * o.y; o2 += wt * o.z; o3 += wt * o.w;
+  }
+  const float inv = 1.f / L;
+  const int b = (int)(bh / p.H), h = (int)(bh % p.H);
+  u16* op = (u16*)p.out + ((int64_t)b * p.Nq + q) * ((int64_t)p.H * D) + (int64_t)h * D + 4 * d4;
+  uint2 pk;
+  pk.x = pack_bf16x2(o0 * inv, o1 * inv);
+  pk.y = pack_bf16x2(o2 * inv, o3 * inv);
+  *(uint2*)op = pk;
+}
+
 template <int D>
 int launch_fast(const siu3r_attn_params& p, hipStream_t s) {
-  dim3 grid((p.Nq + 127) / 128, p.H, p.B), block(256);
-  if (p.mask)
-    hipLaunchKernelGGL((attn_fast_kernel<D, 1>), grid, block, 0, s, p);
-  else
-    hipLaunchKernelGGL((attn_fast_kernel<D, 0>), grid, block, 0, s, p);
+  dim3 block(256);
+  if (p.splits > 1 && p.ws && p.Nq <= 128) {
+    dim3 grid(p.splits, p.H, p.B);
+    if (p.mask)
+      hipLaunchKernelGGL((attn_fast_kernel<D, 1, 1>), grid, block, 0, s, p);
+    else
+      hipLaunchKernelGGL((attn_fast_kernel<D, 0, 1>), grid, block, 0, s, p);
+    const int64_t n = (int64_t)p.B * p.H * p.Nq * (D / 4);
+    hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((unsigned)((n + 255) / 256)), block, 0, s, p);
+  } else {
+    dim3 grid((p.Nq + 127) / 128, p.H, p.B);
+    if (p.mask)
+      hipLaunchKernelGGL((attn_fast_kernel<D, 1, 0>), grid, block, 0, s, p);
+    else
+      hipLaunchKernelGGL((attn_fast_kernel<D, 0, 0>), grid, block, 0, s, p);
+  }
   SIU3R_LAUNCH_CHECK("siu3r_attention(fast)");
   return 0;
 }

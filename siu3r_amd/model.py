@@ -673,12 +673,31 @@ class VideoMask2FormerForVideoSegmentation:
         pos3 = ctx.cache[key]
         le = ctx.w.v(tm + ".level_embed.weight")
         ones = ctx.cache.setdefault("ones256", torch.ones(256, device=ctx.dev))
-        feats, keys_in = [], []
+        # Keys / values of the three memory levels for all nine layers up front: layer idx reads level idx % 3, and its
+        # key projection Wk (feats + pos) + bk = Wk feats + (Wk pos + bk) has an input-independent second term, so one GEMM per
+        # level yields K and V of its three layers (N = 6 x 256) with that constant riding in as the residual -- 3 launches on
+        # the bf16 LDS-DMA path instead of 18 fp32-A ones plus the position adds
+        feats = []
         for i in range(3):
-            f_ = ops.affine_add(ms[i], None, ones, le[i].contiguous(), out_dtype=torch.float32)
-            f_ = f_.view(B, T * sizes[i][0] * sizes[i][1], 256)
-            feats.append(f_)
-            keys_in.append(ops.add(f_, pos3[i]))
+            f_ = ops.affine_add(ms[i], None, ones, le[i].contiguous(), out_dtype=ctx.act)
+            feats.append(f_.view(B, T * sizes[i][0] * sizes[i][1], 256))
+        kvs = []
+        for lvl in range(3):
+            wkey, key = ("m2f_kvw", lvl), ("m2f_kv", T, sizes[lvl])
+            if wkey not in ctx.cache:   # shape-independent part, kept after release_source_weights()
+                wk, wv, bk, bv = [], [], [], []
+                for idx in (lvl, lvl + 3, lvl + 6):
+                    wi, bi = ctx.w.t(f"{dp}.layers.{idx}.cross_attn.in_proj_weight"), ctx.w.t(f"{dp}.layers.{idx}.cross_attn.in_proj_bias")
+                    wk.append(wi[256:512]); wv.append(wi[512:]); bk.append(bi[256:512]); bv.append(bi[512:])
+                wkk = torch.cat(wk, 0)
+                ctx.cache[wkey] = (ops.pack_matrix(torch.cat((wkk, torch.cat(wv, 0)), 0), None, ctx.split), wkk, torch.cat(bk, 0), torch.cat(bv, 0))
+            pw, wkk, bkk, bvv = ctx.cache[wkey]
+            if key not in ctx.cache:
+                posk = pos3[lvl] @ wkk.t() + bkk                                      # [S, 768]: constant folding, fp32
+                ctx.cache[key] = torch.cat((posk, bvv[None].expand(posk.shape[0], -1)), 1).contiguous()
+            res = ctx.cache[key]
+            kv = ops.linear(feats[lvl], pw, out_dtype=ctx.act, residual=res if B == 1 else res[None].expand(B, -1, -1))
+            kvs.append(kv.view(B, -1, 6, 8, 32))
         Q = self.num_queries
         qf = ctx.w.v(tm + ".queries_features.weight")
         qe = ctx.w.v(tm + ".queries_embedder.weight")
@@ -693,20 +712,24 @@ class VideoMask2FormerForVideoSegmentation:
             lvl = idx % 3
             if p + ".cross_attn.q" not in ctx.w.lin:
                 wi, bi = ctx.w.t(p + ".cross_attn.in_proj_weight"), ctx.w.t(p + ".cross_attn.in_proj_bias")
-                ctx.w.lin[p + ".cross_attn.q"] = ops.pack_matrix(wi[:256], bi[:256], ctx.split)
-                ctx.w.lin[p + ".cross_attn.k"] = ops.pack_matrix(wi[256:512], bi[256:512], ctx.split)
-                ctx.w.lin[p + ".cross_attn.v"] = ops.pack_matrix(wi[512:], bi[512:], ctx.split)
+                ctx.w.lin[p + ".cross_attn.q"] = ops.pack_matrix(wi[:256], None, ctx.split)
+                # W (hs + query_pos) + b = W hs + (W query_pos + b): the query-position term is a constant [Q, N] residual
+                ctx.cache[p + ".cross_attn.qres"] = (qe @ wi[:256].t() + bi[:256]).contiguous()
+                wq, wk_ = ctx.w.t(p + ".self_attn.q_proj.weight"), ctx.w.t(p + ".self_attn.k_proj.weight")
+                bq, bk_ = ctx.w.t(p + ".self_attn.q_proj.bias"), ctx.w.t(p + ".self_attn.k_proj.bias")
+                wqk = torch.cat((wq, wk_), 0)
+                ctx.w.lin[p + ".self_attn.qk0"] = ops.pack_matrix(wqk, None, ctx.split)
+                ctx.cache[p + ".self_attn.qkres"] = (qe @ wqk.t() + torch.cat((bq, bk_), 0)).contiguous()
+            bres = (lambda r: r if B == 1 else r[None].expand(B, -1, -1))
             # masked cross-attention (nn.MultiheadAttention, :975-983): q from hs + query pos, k from feats + pos3d, v from feats
-            qin = ops.add(hs, qe)
-            q = ops.linear(qin, ctx.w.lin[p + ".cross_attn.q"], out_dtype=ctx.act).view(B, Q, 8, d)
-            k = ops.linear(keys_in[lvl], ctx.w.lin[p + ".cross_attn.k"], out_dtype=ctx.act).view(B, -1, 8, d)
-            v = ops.linear(feats[lvl], ctx.w.lin[p + ".cross_attn.v"], out_dtype=ctx.act).view(B, -1, 8, d)
+            q = ops.linear(hs, ctx.w.lin[p + ".cross_attn.q"], out_dtype=ctx.act, residual=bres(ctx.cache[p + ".cross_attn.qres"])).view(B, Q, 8, d)
+            j = idx // 3
+            k, v = kvs[lvl][:, :, j], kvs[lvl][:, :, 3 + j]
             a = ops.attention(q, k, v, heads=8, head_dim=d, scale=d ** -0.5, mask=am, split3=ctx.split)
             a = ops.linear(a, ctx.w.linear(p + ".cross_attn.out_proj"), out_dtype=torch.float32, residual=hs)
             hs = ctx.ln(p + ".cross_attn_layer_norm", a, 1e-5, out_dtype=torch.float32)
             # self-attention, DETR style (:782-912): pos added to q and k, v from hs
-            qin = ops.add(hs, qe)
-            qk = ops.linear(qin, ctx.w.merged(p + ".self_attn.qk", [p + ".self_attn.q_proj", p + ".self_attn.k_proj"]), out_dtype=ctx.act).view(B, Q, 2, 8, d)
+            qk = ops.linear(hs, ctx.w.lin[p + ".self_attn.qk0"], out_dtype=ctx.act, residual=bres(ctx.cache[p + ".self_attn.qkres"])).view(B, Q, 2, 8, d)
             v = ops.linear(hs, ctx.w.linear(p + ".self_attn.v_proj"), out_dtype=ctx.act).view(B, Q, 8, d)
             a = ops.attention(qk[:, :, 0], qk[:, :, 1], v, heads=8, head_dim=d, scale=d ** -0.5, split3=ctx.split)
             a = ops.linear(a, ctx.w.linear(p + ".self_attn.out_proj"), out_dtype=torch.float32, residual=hs)

@@ -354,6 +354,13 @@ def attention(q, k, v, *, heads: int, head_dim: int, scale: float, rope=None, qp
         assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.shape[:2] == (B, Nq) and mask.shape[2] >= Nk
         p.mask, p.mask_ld = _p(mask), mask.shape[2]
     p.split3 = int(split3)
+    ws = None
+    if q.dtype == torch.bfloat16 and not split3 and rope is None and Nq <= 128 and Nk >= 1024:
+        # few queries against many keys (Mask2Former: 100 queries x 512..8192 keys): split the keys over workgroups
+        nkt = (Nk + 63) // 64
+        p.splits = min(16, nkt // 4)
+        ws = torch.empty((B, heads, p.splits, 128, head_dim + 4), dtype=torch.float32, device=q.device)
+        p.ws = _p(ws)
     check(_lib.lib().siu3r_attention(C.byref(p), _stream()))
     return out
 

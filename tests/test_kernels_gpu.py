@@ -435,7 +435,8 @@ print("WIDE_OK")
 
 
 @pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
-@pytest.mark.parametrize("case", [(2, 3, 257, 300, 64, False), (2, 8, 100, 520, 32, True), (1, 2, 128, 64, 64, True)], ids=["d64", "d32mask", "d64mask1tile"])
+@pytest.mark.parametrize("case", [(2, 3, 257, 300, 64, False), (2, 8, 100, 520, 32, True), (1, 2, 128, 64, 64, True), (1, 8, 100, 2100, 32, True), (2, 4, 37, 1100, 64, False)],
+                         ids=["d64", "d32mask", "d64mask1tile", "d32mask_splitkv", "d64_splitkv"])
 def test_attention_peaky(mode, case):
     """Concentrated softmax (|logit| up to ~40): with near-uniform weights a wrong key<->value pairing, a wrong row
     maximum or a wrong normaliser hides inside the bf16 tolerance; here every one of them is an O(1) error.
