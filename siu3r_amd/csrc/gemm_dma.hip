@@ -357,13 +357,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   if (dbg & 1) { if (acc[0][0][0] == 123.456f) ((float*)p.c)[0] = 1.f; return; }
   siu3r_epi::run<NI>(p, acc, smem, tile_m, tile_n, z, t);
   if (trace && t == 0) {
+    trace[6] = __builtin_readcyclecounter();  // last store issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    trace[5] = __builtin_readcyclecounter();
-    unsigned hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    trace[6] = ((uint64_t)xcc << 32) | hwid;
+    trace[7] = __builtin_readcyclecounter();  // stores acknowledged
   }
 #endif
 }

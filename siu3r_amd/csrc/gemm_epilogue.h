@@ -137,6 +137,7 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  if (p.trace && t == 0) p.trace[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8 + 5] = __builtin_readcyclecounter();
 
 #pragma unroll
   for (int g = 0; g < NG; ++g) {

@@ -16,17 +16,8 @@ ops.set_gemm_trace(None)
 b = buf.cpu().numpy()
 b = b[b[:, 0] != 0]
 t0 = b[:, 0].min()
-print(f"{len(b)} workgroups; kernel span {(b[:,5].max()-t0)} cycles")
-ph = ["setup", "prologue-issue", "first-tile-wait", "k-loop", "epilogue"]
-d = np.diff(b[:, :6], axis=1)
+print(f"{len(b)} workgroups")
+ph = ["setup", "prologue-issue", "first-tile-wait", "k-loop", "epi: stage", "epi: rows+stores issued", "epi: store drain"]
+d = np.diff(b[:, :8], axis=1)
 for i, n in enumerate(ph):
-    print(f"{n:16s} mean {d[:, i].mean():9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}")
-print("start time (rel) percentiles:", [int(np.percentile(b[:, 0] - t0, q)) for q in (0, 25, 50, 75, 100)])
-print("end   time (rel) percentiles:", [int(np.percentile(b[:, 5] - t0, q)) for q in (0, 25, 50, 75, 100)])
-hw = b[:, 6] & 0xffffffff; xcc = b[:, 6] >> 32
-cu = ((hw >> 8) & 0xf) | (((hw >> 13) & 0x7) << 4) | (xcc << 8)   # cu_id | se_id | xcc
-u, c = np.unique(cu, return_counts=True)
-print("distinct CUs", len(u), "workgroups per CU min/max", c.min(), c.max())
-order = np.argsort(b[:, 0])
-for i in order[:6].tolist() + order[-3:].tolist():
-    print("wg", i, "cu", hex(int(cu[i])), "start", int(b[i, 0] - t0), "phases", d[i].tolist())
+    print(f"{n:26s} mean {d[:, i].mean():9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}")
