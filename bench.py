@@ -173,6 +173,41 @@ def main():
                                          "frac": bytes_alg / (ms_frame * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_view": bytes_alg, "traffic": None,
                                          "note": "whole per-view pipeline (project+scan+fill+sort+composite, incl. host-side camera prep and the pair-count sync)"}}
 
+    if not args.no_render and world == 1:
+        # rasterizer stress leg (BASELINE.json configs[4] shape): 2 097 152 Gaussians (what 8 views x 512^2 produce), most of
+        # them in view, one 1920x1080 frame, SH degree 4 -> RGB + depth (K2 semantics).  The network's own output with
+        # synthetic weights leaves ~6 % of the Gaussians in view, which says little about the rasterizer's bandwidth
+        import math
+        from siu3r_amd import cuda_splatting as cs
+        Gs, Ws, Hs = 2_097_152, 1920, 1080
+        m_, cov_, op_, sh_ = (t.to(dev) for t in synthetic.random_scene(Gs, seed=1, spread=3.0, depth=(2.0, 9.0), scale=(0.004, 0.03)))
+        cov6 = raster.cov6_from_cov3x3(cov_)
+        shs = sh_.permute(0, 2, 1).contiguous()
+        c2w = synthetic.perturbed_camera(0, jitter=0.1)
+        w2c = torch.linalg.inv(c2w)
+        fx = 0.9 * Ws
+        fovx, fovy = 2 * math.atan(Ws / (2 * fx)), 2 * math.atan(Hs / (2 * fx))
+        proj = cs.get_projection_matrix(torch.tensor([0.1]), torch.tensor([100.0]), torch.tensor([fovx]), torch.tensor([fovy]))[0]
+        cam2 = raster.make_cam_k2(w2c=w2c, full_proj=proj @ w2c, tanfovx=math.tan(fovx / 2), tanfovy=math.tan(fovy / 2), campos=c2w[:3, 3],
+                                  bg=torch.zeros(3), width=Ws, height=Hs, sh_degree=4)
+        for _ in range(2):
+            o = raster.rasterize_k2(cam2, m_, cov6, shs, op_)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            o = raster.rasterize_k2(cam2, m_, cov6, shs, op_)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_s = e0.elapsed_time(e1) / 5
+        Gv_s, D_s = int((o["state"]["tiles_touched"] > 0).sum()), int(o["state"]["D"])
+        b_s = raster.algorithmic_bytes(Gs, Gv_s, D_s, Hs * Ws)
+        result["render_stress"] = {"ms_per_frame": ms_s, "resolution": [Ws, Hs], "gaussians": Gs, "visible": Gv_s, "tile_pairs": D_s,
+                                   "scene": "siu3r_amd.synthetic.random_scene(seed=1): configs[4] shape (8 views x 512^2 worth of Gaussians, 1080p)",
+                                   "roofline": {"bound": "hbm", "achieved": b_s / (ms_s * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                                "frac": b_s / (ms_s * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_view": b_s, "traffic": None}}
+        del m_, cov_, op_, sh_, cov6, shs, o
+
     if world == 1 and not args.no_cpu_baseline:
         from oracle import siu3r_oracle as O
 

@@ -175,7 +175,7 @@ typedef struct {
 } siu3r_raster_cam;
 /* stage 1+2: project G Gaussians (means [G,3], cov6 [G,6] upper-triangular, opacities [G], colors: mode 0 SH
  * [G,channels,3], mode 1 unused) and count/scan tiles.  Outputs: mean2d [G,2], conic_op [G,4], depth [G], radii [G,2]
- * i32, rect [G,4] i32, tiles_touched [G] i32, rgb [G,3] (mode 0), tile_count [T], tile_start [T+1], cursor [T] i32.
+ * i32, rect [G,4] i32, tiles_touched [G] i32, rgb [G,3] (mode 0), tile_count [8,T] (8 counter sets, see raster.hip), tile_start [T+1], cursor [8,T] i32.
  * tile_start[T] = D, the number of (tile, Gaussian) pairs, which sizes the key buffer of the next stage. */
 int siu3r_raster_bin(const siu3r_raster_cam* cam, int64_t G, const float* means, const float* cov6,
                      const float* opacities, const float* colors, int channels, float* mean2d, float* conic_op,

@@ -53,6 +53,7 @@ __device__ __forceinline__ float exp_det(float x) {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+constexpr int NPART = 8;  // counter sets of the binning atomics (see scan_kernel)
 __constant__ float c_SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
 __constant__ float c_SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
 __constant__ float c_SH_C4[9] = {2.5033429417967046f, -1.7701307697799304f, 0.9461746957575601f, -0.6690465435572892f, 0.10578554691520431f, -0.6690465435572892f, 0.47308734787878004f, -1.7701307697799304f, 0.6258357354491761f};
@@ -224,10 +225,16 @@ __global__ void project_kernel(Cam c, int64_t G, const float* means, const float
     }
   }
   for (int ty_ = ty0; ty_ < ty1; ++ty_)
-    for (int tx_ = tx0; tx_ < tx1; ++tx_) atomicAdd(&tile_count[ty_ * gw + tx_], 1);  // hipcc wave-aggregates same-address adds
+    for (int tx_ = tx0; tx_ < tx1; ++tx_)
+      atomicAdd(&tile_count[(blockIdx.x & (NPART - 1)) * (gw * gh) + ty_ * gw + tx_], 1);  // one of NPART counter sets: see scan_kernel
 }
 
-// exclusive scan of tile_count[T] -> tile_start[T+1] (+ cursor copy), single workgroup of 1024 threads
+// The per-tile counters are hot addresses (a 1080p frame has 8160 of them for ~14 M (Gaussian, tile) pairs): device-scope atomics on
+// one address serialise.  Workgroup b of project_kernel / fill_kernel therefore uses counter set b % NPART; the sets are summed here,
+// and set c of a tile gets the cursor base tile_start + (count of sets < c), so every pair still lands in its tile's range.  Which
+// workgroup a Gaussian belongs to is the same in both kernels (same grid), and the per-tile sort makes the final order independent
+// of the partition.
+// exclusive scan of sum_c tile_count[c][T] -> tile_start[T+1], cursor[c][T]; single workgroup of 1024 threads
 __global__ __launch_bounds__(1024) void scan_kernel(const int32_t* tile_count, int32_t* tile_start, int32_t* cursor, int T) {
   __shared__ int32_t wsum[16];
   __shared__ int32_t carry;
@@ -236,7 +243,13 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int32_t* tile_count, i
   __syncthreads();
   for (int base = 0; base < T; base += 1024) {
     const int i = base + t;
-    const int v = i < T ? tile_count[i] : 0;
+    int cnt[NPART];
+    int v = 0;
+#pragma unroll
+    for (int c = 0; c < NPART; ++c) {
+      cnt[c] = i < T ? tile_count[c * T + i] : 0;
+      v += cnt[c];
+    }
     int incl = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -250,7 +263,12 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int32_t* tile_count, i
     const int excl = carry + woff + incl - v;
     if (i < T) {
       tile_start[i] = excl;
-      cursor[i] = excl;
+      int run = excl;
+#pragma unroll
+      for (int c = 0; c < NPART; ++c) {
+        cursor[c * T + i] = run;
+        run += cnt[c];
+      }
     }
     __syncthreads();
     if (t == 1023) carry = excl + v;
@@ -259,7 +277,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int32_t* tile_count, i
   if (t == 0) tile_start[T] = carry;
 }
 
-__global__ void fill_kernel(int64_t G, const int32_t* rect, const float* depth, int32_t* cursor, uint64_t* keys, int gw) {
+__global__ void fill_kernel(int64_t G, const int32_t* rect, const float* depth, int32_t* cursor, uint64_t* keys, int gw, int T) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
   const int tx0 = rect[4 * g], ty0 = rect[4 * g + 1], tx1 = rect[4 * g + 2], ty1 = rect[4 * g + 3];
@@ -267,7 +285,7 @@ __global__ void fill_kernel(int64_t G, const int32_t* rect, const float* depth, 
   const uint64_t key = ((uint64_t)__float_as_uint(depth[g]) << 32) | (uint32_t)g;
   for (int ty = ty0; ty < ty1; ++ty)
     for (int tx = tx0; tx < tx1; ++tx) {
-      const int pos = atomicAdd(&cursor[ty * gw + tx], 1);
+      const int pos = atomicAdd(&cursor[(blockIdx.x & (NPART - 1)) * T + ty * gw + tx], 1);
       keys[pos] = key;
     }
 }
@@ -605,7 +623,7 @@ extern "C" int siu3r_raster_bin(const siu3r_raster_cam* cam, int64_t G, const fl
   to_cam(cam, &c);
   hipStream_t s = (hipStream_t)stream;
   const int T = ((c.width + TILE - 1) / TILE) * ((c.height + TILE - 1) / TILE);
-  if (hipMemsetAsync(tile_count, 0, sizeof(int32_t) * T, s) != hipSuccess) {
+  if (hipMemsetAsync(tile_count, 0, sizeof(int32_t) * T * NPART, s) != hipSuccess) {
     siu3r_set_error("raster_bin: memset failed");
     return 2;
   }
@@ -621,7 +639,7 @@ extern "C" int siu3r_raster_sort(const siu3r_raster_cam* cam, int64_t G, const i
   SIU3R_CHECK(cam && tile_start && cursor && keys && ids && (G == 0 || (rect && depth)), "raster_sort: null pointer");
   hipStream_t s = (hipStream_t)stream;
   const int gw = (cam->width + TILE - 1) / TILE, T = gw * ((cam->height + TILE - 1) / TILE);
-  if (G > 0) hipLaunchKernelGGL(fill_kernel, g1(G), dim3(256), 0, s, G, rect, depth, cursor, keys, gw);
+  if (G > 0) hipLaunchKernelGGL(fill_kernel, g1(G), dim3(256), 0, s, G, rect, depth, cursor, keys, gw, T);
   hipLaunchKernelGGL((sort_kernel<1024, 0>), dim3(T), dim3(256), 0, s, tile_start, keys, ids);
   hipLaunchKernelGGL((sort_kernel<4096, 1024>), dim3(T), dim3(256), 0, s, tile_start, keys, ids);
   hipLaunchKernelGGL((sort_kernel<SORT_CAP, 4096>), dim3(T), dim3(256), 0, s, tile_start, keys, ids);

@@ -64,7 +64,7 @@ def _bin_and_sort(cam: RasterCam, means, cov6, opac, colors, channels):
     f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
     st = dict(mean2d=f(G, 2), conic_op=f(G, 4), depth=f(G), radii=i32(G, 2), rect=i32(G, 4), tiles_touched=i32(G),
-              rgb=f(G, 3) if cam.mode == 0 else None, tile_count=i32(T), tile_start=i32(T + 1), cursor=i32(T))
+              rgb=f(G, 3) if cam.mode == 0 else None, tile_count=i32(8 * T), tile_start=i32(T + 1), cursor=i32(8 * T))
     check(_lib.lib().siu3r_raster_bin(C.byref(cam), G, _p(means), _p(cov6), _p(opac), _p(colors), channels, _p(st["mean2d"]),
                                       _p(st["conic_op"]), _p(st["depth"]), _p(st["radii"]), _p(st["rect"]), _p(st["tiles_touched"]),
                                       _p(st["rgb"]), _p(st["tile_count"]), _p(st["tile_start"]), _p(st["cursor"]), _stream()))

@@ -25,3 +25,21 @@ def target_views(n: int, seed: int = 0) -> torch.Tensor:
 
 def default_intrinsics() -> torch.Tensor:
     return torch.tensor([[318 / 256, 0, 0.5], [0, 318 / 256, 0.5], [0, 0, 1]], dtype=torch.float32)
+
+
+def random_scene(G, seed=0, spread=1.5, depth=(1.5, 8.0), scale=(0.01, 0.12), n_sh=25):
+    """Seeded random Gaussian scene in front of a camera at the origin looking down +z:
+    means [G,3], covariances [G,3,3] (random rotation x diag(scale^2)), opacities [G], SH [G,3,n_sh]."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=g)
+    means = torch.stack(((r(G) * 2 - 1) * spread, (r(G) * 2 - 1) * spread, depth[0] + r(G) * (depth[1] - depth[0])), -1)
+    q = torch.randn(G, 4, generator=g)
+    q = q / q.norm(dim=-1, keepdim=True)
+    x, y, z, w = q.unbind(-1)
+    R = torch.stack((1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                     2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)), -1).view(G, 3, 3)
+    s = scale[0] + r(G, 3) * (scale[1] - scale[0])
+    cov = R @ torch.diag_embed(s * s) @ R.transpose(1, 2)
+    opac = 0.05 + 0.9 * r(G)
+    sh = (r(G, 3, n_sh) * 2 - 1) * 0.5
+    return means.float(), cov.float(), opac.float(), sh.float()
