@@ -250,23 +250,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
 
   // ---- main loop: prefetch distance 2 (register sets r0/r1 alternate), LDS double buffer
   const int nkt = p.kpad / BK;
+  // raw barriers: __syncthreads() would also drain the global loads of the tiles in flight (hipcc puts s_waitcnt vmcnt(0) in
+  // front of it), i.e. undo the prefetch; LDS visibility only needs lgkmcnt(0)
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
   R r0, r1;
   load_tile(0, r0);
   if (nkt > 1) load_tile(1, r1);
   store_tile(0, r0);
-  __syncthreads();
+  lds_barrier();
   for (int kt = 0; kt < nkt; kt += 2) {
     // even step: tile kt is in LDS stage 0, tile kt+1 in r1; fetch tile kt+2 into r0
     if (kt + 2 < nkt) load_tile(kt + 2, r0);
     compute(0);
     if (kt + 1 < nkt) store_tile(1, r1);
-    __syncthreads();
+    lds_barrier();
     if (kt + 1 >= nkt) break;
     // odd step: tile kt+1 is in LDS stage 1, tile kt+2 in r0; fetch tile kt+3 into r1
     if (kt + 3 < nkt) load_tile(kt + 3, r1);
     compute(1);
     if (kt + 2 < nkt) store_tile(0, r0);
-    __syncthreads();
+    lds_barrier();
   }
 
   // ---- epilogue: LDS-staged, row-wise vectorised (gemm_epilogue.h)
