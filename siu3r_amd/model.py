@@ -416,13 +416,16 @@ class _DPTHead:
         xyz = ops.linear(x, ctx.w.linear(f"{p}.dpt.head.4"), out_dtype=torch.float32)
         return {"pts3d": ops.pts3d_exp_(xyz)}
 
-    def forward_gs(self, tokens, img_nhwc8, H, W):
-        """dpt_gs_head.py:121-171: feat_up(path_1) + ReLU(conv7x7(img)) fused into the 7x7 conv's epilogue."""
+    def forward_gs(self, tokens, img_nhwc8, H, W, out=None):
+        """dpt_gs_head.py:121-171: feat_up(path_1) + ReLU(conv7x7(img)) fused into the 7x7 conv's epilogue.
+        out: optional [B, H*W, 83] fp32 destination (a view of the model's [B, V, H*W, 83] raw-Gaussian buffer)."""
         ctx, p = self.ctx, self.p
         path1 = self.trunk(tokens, H, W)
         x = ops.conv2d(img_nhwc8, ctx.w.conv(f"{p}.dpt.input_merger.0", cin_pad=8), pad=3, out_dtype=ctx.act,
                        act=ACT_RELU, up_src=path1)
         x = ops.conv2d(x, ctx.w.conv(f"{p}.dpt.head.0"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
+        if out is not None:
+            return ops.linear(x.view(x.shape[0], H * W, -1), ctx.w.linear(f"{p}.dpt.head.4"), out=out)
         return ops.linear(x, ctx.w.linear(f"{p}.dpt.head.4"), out_dtype=torch.float32)  # [B,H,W,83]
 
 
@@ -777,7 +780,7 @@ class _Run:
     def __init__(self, images, K):
         self.images, self.K = images, K
         self.img_bv = self.img8 = self.enc = self.adapter = self.dstate = self.dec = self.ms = self.seg = self.gaussians = None
-        self.gs, self.pts = [None, None], [None, None]
+        self.gs, self.pts, self.raw = [None, None], [None, None], None
 
 
 class SIU3RModel:
@@ -872,7 +875,7 @@ class SIU3RModel:
             all1 = [t[:, 0, :-1] for t in st.enc["av"]]
             all2 = [t[:, 1, :-1] for t in st.enc["av"]]
             self._last = dict(dec1=decs[0], dec2=decs[1], decs=decs, all_feat1=all1, all_feat2=all2, ms=st.ms, pts1=st.pts[0],
-                              pts2=st.pts[1], gs_raw1=st.gs[0], gs_raw2=st.gs[1], seg_out=st.seg)
+                              pts2=st.pts[1], gs_raw1=st.gs[0].reshape(B, H, W, -1), gs_raw2=st.gs[1].reshape(-1, H, W, st.gs[1].shape[-1]), seg_out=st.seg)
         if enable_query_class_logit_lift:
             return gaussians, seg_out, masks, infos, qscores
         return gaussians, seg_out, masks, infos
@@ -883,6 +886,8 @@ class SIU3RModel:
 
         def dec_pre():
             st.dstate = bb.decode_begin(st.enc)
+            B, V, _, H, W = st.images.shape
+            st.raw = torch.empty((B, V, H * W, self.raw_gs_dim), dtype=torch.float32, device=self._ctx.dev)
 
         def dec_post():
             st.dec = bb.decode_end(st.dstate)
@@ -988,7 +993,10 @@ class SIU3RModel:
             img8 = st.img8.view(B, V, H, W, 8)
             img = (img8[:, 0] if first else self._rest_views(img8)).contiguous()
             head = self.gaussian_param_head1 if first else self.gaussian_param_head2
-            st.gs[0 if first else 1] = head.forward_gs(toks, img, H, W)
+            # the last GEMM writes straight into the [B, V, H*W, 83] buffer the Gaussian adapter reads (no 350 MB concat),
+            # whenever this head's views form one strided batch of it
+            dst = st.raw[:, 0] if first else (st.raw[:, 1] if V == 2 else (st.raw[0, 1:] if B == 1 else None))
+            st.gs[0 if first else 1] = head.forward_gs(toks, img, H, W, out=dst)
         else:
             head = self.downstream_head1 if first else self.downstream_head2
             st.pts[0 if first else 1] = head.forward_pts3d(toks, H, W)["pts3d"]
@@ -996,7 +1004,8 @@ class SIU3RModel:
     def _s_tail(self, st):
         B, V, _, H, W = st.images.shape
         cat = lambda a, b_: torch.cat((a.reshape(B, 1, H * W, -1), b_.reshape(B, V - 1, H * W, -1)), dim=1)
-        st.gaussians = self.gaussian_adapter.forward(cat(st.pts[0], st.pts[1]), cat(st.gs[0], st.gs[1]))
+        raw = st.raw if (V == 2 or B == 1) else cat(st.gs[0], st.gs[1])
+        st.gaussians = self.gaussian_adapter.forward(cat(st.pts[0], st.pts[1]), raw)
 
     __call__ = forward
 
