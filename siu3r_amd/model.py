@@ -854,16 +854,18 @@ class SIU3RModel:
 
                 try:
                     for name, fn in self._stages(st):
-                        capture(name, fn)
+                        if name != "tail":  # the tail (2 launches) stays eager: its outputs are then fresh tensors, not graph memory
+                            capture(name, fn)
                 finally:
                     ctx.concurrent = conc
                 torch.cuda.synchronize()
             st = ent["st"]
             st.images.copy_(images, non_blocking=True)
             st.K.copy_(K, non_blocking=True)
-            self._run_stages(st, lambda name, fn: ent["graphs"][name].replay())
-            # results leave the graphs' private memory: the next replay overwrites it
-            gaussians = Gaussians(**{f: getattr(st.gaussians, f).clone() for f in Gaussians.FIELDS})
+            self._run_stages(st, lambda name, fn: fn() if name == "tail" else ent["graphs"][name].replay())
+            # the Gaussians come from the eager tail (fresh memory); the logits leave the graphs' private memory, which the
+            # next replay overwrites
+            gaussians = st.gaussians
             seg_out = VideoMask2FormerForVideoSegmentationOutput(st.seg)
             for k_ in ("class_queries_logits", "masks_queries_logits"):
                 seg_out[k_] = seg_out[k_].clone()

@@ -14,7 +14,7 @@ for _ in range(4):
 ent = next(iter(m._graphs.values()))
 st = ent["st"]
 def body():
-    m._run_stages(st, lambda name, fn: ent["graphs"][name].replay())
+    m._run_stages(st, lambda name, fn: fn() if name == "tail" else ent["graphs"][name].replay())
 for f, name in ((body, "graph body"),):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): f()
