@@ -15,6 +15,8 @@
 // MODE 2 (any cin % 8 == 0, e.g. the 7x7 stem) keeps per-lane tap arithmetic.
 // The LDS image keeps gemm.hip's XOR swizzle: the DMA destination is lane-linear, so the permutation is applied
 // to the per-lane SOURCE address (cdna_hip_programming.md rule 21).  Same tiles, MFMA layout and epilogue as gemm.hip.
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm_epilogue.h"
 
@@ -29,21 +31,29 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) short i16x2;
 
-template <int NI, int MODE, bool RELU>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_dma_kernel(const siu3r_gemm_params p) {
+// KSPL = 2 (NI = 1 only): eight waves per workgroup; waves 4..7 work on the SAME 64x32 sub-tiles as waves 0..3 but on the second
+// half of every K tile (k-substeps 2,3), and the two partial accumulators are summed in the epilogue.  A single wave can issue
+// one ds_read_b128 per ~31 cycles and one LDS-DMA piece per ~55 whatever the rest of the CU does (tools/probes/lds_bw_probe.hip),
+// so a K step costs a wave 12 x 31 + 6 x 55 cycles of issue against 256 cycles of MFMA; splitting the K tile over twice the
+// waves halves that per wave and lets the CU's LDS (~220 B/clk from 8+ waves) rather than one wave's issue rate set the pace.
+template <int NI, int MODE, bool RELU, int KSPL>
+__global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_params p) {
 #if __HIP_DEVICE_COMPILE__  // the buffer-resource type has no host representation; the host pass only needs the stub
   constexpr int BN = 64 * NI;
   constexpr int B_TILE_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
-  constexpr int A_DMA = 4;        // 1-KiB DMA pieces per wave per K-tile for A (16 pieces / 4 waves)
-  constexpr int W_DMA = 2 * NI;   // ... for W (BN/8 pieces / 4 waves)
+  constexpr int A_DMA = 4 / KSPL;        // 1-KiB DMA pieces per wave per K-tile for A (16 pieces / 4 KSPL waves)
+  constexpr int W_DMA = 2 * NI / KSPL;   // ... for W (BN/8 pieces)
   constexpr int LP = A_DMA + W_DMA;
+  constexpr int KSW = 4 / KSPL;          // k-substeps (of 16) of a K tile handled by one wave
+  static_assert(STAGES * STAGE_BYTES >= siu3r_epi::staging_bytes<NI, KSPL>(), "epilogue staging must fit the ring");
   __shared__ __attribute__((aligned(128))) unsigned char smem[STAGES * STAGE_BYTES];
 
   const int t = threadIdx.x;
   const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);  // 0 .. 4 KSPL - 1
+  const int khalf = wave >> 2, wq = wave & 3;                // K half of this wave, position in the 2x2 sub-tile grid
+  const int wm = wq >> 1, wn = wq & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
   const int M = p.m, N = p.n, K = p.k, kpad = p.kpad;
@@ -218,7 +228,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   // A ds_read_b128 round trip is ~180 cycles with four waves reading; a k-substep's MFMAs last 64 (NI=1) / 128 cycles,
   // so reading one substep ahead left most of that latency exposed four times per K tile.  The waits are counted
   // (LDS returns in order; an interleaved scalar load can only make a counted wait more conservative).
-  // The DMA pieces of the K tile two ahead are spread over the four MFMA groups.
   auto issue_tile_reads = [&](int stage, u32x4 (&fa)[4][2], u32x4 (&fb)[4][NI]) {
     const unsigned int sbase = lds_base + stage * STAGE_BYTES;  // 128-byte aligned: the XOR stays inside the row
     unsigned int adA[2], adB[NI];
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     // lgkmcnt is a 4-bit counter: never more than 15 reads in flight.  NI = 2 (16 reads per tile) issues its last
     // k-substep from tile_body, after the first wait
 #pragma unroll
-    for (int ks = 0; ks < (NI == 2 ? 3 : 4); ++ks) read_frags(adA, adB, ks, fa[ks], fb[ks]);
+    for (int j = 0; j < ((NI == 2 && KSPL == 1) ? 3 : KSW); ++j) read_frags(adA, adB, khalf * KSW + j, fa[j], fb[j]);
   };
   auto issue_last_reads = [&](int stage, u32x4 (&fa)[4][2], u32x4 (&fb)[4][NI]) {
     const unsigned int sbase = lds_base + stage * STAGE_BYTES;
@@ -249,9 +258,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #define SIU3R_WAIT_FRAGS(CNT)                                                                                              \
   do {                                                                                                                     \
     if (NI == 2)                                                                                                           \
-      asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa[ks][0]), "+v"(fa[ks][1]), "+v"(fb[ks][0]), "+v"(fb[ks][NI - 1])::"memory"); \
+      asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa[j][0]), "+v"(fa[j][1]), "+v"(fb[j][0]), "+v"(fb[j][NI - 1])::"memory"); \
     else                                                                                                                   \
-      asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa[ks][0]), "+v"(fa[ks][1]), "+v"(fb[ks][0])::"memory");          \
+      asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa[j][0]), "+v"(fa[j][1]), "+v"(fb[j][0])::"memory");          \
   } while (0)
   auto tile_body = [&](int kt, int st, u32x4 (&fa)[4][2], u32x4 (&fb)[4][NI], u32x4 (&na)[4][2], u32x4 (&nb)[4][NI]) {
     const int kt_next = (kt + 2 < nkt && !(dbg & 2)) ? kt + 2 : -1;  // wave-uniform
@@ -260,9 +269,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     int stage_read = st + 1;
     if (stage_read >= STAGES) stage_read -= STAGES;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      // fragments of k-substep ks: (3 - ks) * (2 + NI) younger reads may still be in flight
-      if (ks == 0) {
+    for (int j = 0; j < KSW; ++j) {
+      // fragments of this wave's j-th k-substep: (KSW - 1 - j) * (2 + NI) younger reads may still be in flight
+      if (KSPL == 2) {
+        if (j == 1) SIU3R_WAIT_FRAGS(0);
+        else if (NI == 2) SIU3R_WAIT_FRAGS(4);
+        else SIU3R_WAIT_FRAGS(3);
+      } else if (j == 0) {
         if (NI == 2) {
           SIU3R_WAIT_FRAGS(8);
           issue_last_reads(st, fa, fb);
@@ -270,15 +283,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
           SIU3R_WAIT_FRAGS(9);
         }
       }
-      else if (ks == 1) { if (NI == 2) SIU3R_WAIT_FRAGS(8); else SIU3R_WAIT_FRAGS(6); }
-      else if (ks == 2) { if (NI == 2) SIU3R_WAIT_FRAGS(4); else SIU3R_WAIT_FRAGS(3); }
+      else if (j == 1) { if (NI == 2) SIU3R_WAIT_FRAGS(8); else SIU3R_WAIT_FRAGS(6); }
+      else if (j == 2) { if (NI == 2) SIU3R_WAIT_FRAGS(4); else SIU3R_WAIT_FRAGS(3); }
       else SIU3R_WAIT_FRAGS(0);
-      if (ks == 3 && kt + 1 < nkt) {
-        // this wave has finished reading tile kt.  Tile kt+1 must have landed: only the pieces of tile kt+2 issued in
-        // k-substeps 0..2 of this tile (3 A + 3 or 2 W) may remain in flight
+      if (j == KSW - 1 && kt + 1 < nkt) {
+        // this wave has finished reading tile kt.  Tile kt+1 must have landed: only the LP pieces of tile kt+2 (issued in
+        // this tile's first group) may remain in flight
         if (kt_next >= 0) {
-          if (NI == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+          if (LP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else if (LP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else if (LP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -290,7 +305,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       bf16x8 a[2], bq[NI];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        u32x4 v = fa[ks][i];
+        u32x4 v = fa[j][i];
         if (RELU) {  // fused input ReLU (ResidualConvUnit): a negative bf16 is a negative int16
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -305,19 +320,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         a[i] = cv.h;
       }
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
+      for (int jj = 0; jj < NI; ++jj) {
         union { u32x4 u; bf16x8 h; } cv;
-        cv.u = fb[ks][j];
-        bq[j] = cv.h;
+        cv.u = fb[j][jj];
+        bq[jj] = cv.h;
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) if (!(dbg & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
-      if (kt_next >= 0) {
-        issue_a(kt_next, stage_next, ks);
-        if (NI == 2) issue_w(kt_next, stage_next, ks);
-        else if (ks < 2) issue_w(kt_next, stage_next, ks);  // NI = 1: two W pieces, in k-substeps 0 and 1
+        for (int jj = 0; jj < NI; ++jj) if (!(dbg & 4)) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[jj], acc[i][jj], 0, 0, 0);
+      // all pieces of tile kt+2 go out behind the first MFMA group: they then have almost two K tiles to land (spreading them
+      // over the groups measured 2-5 % slower: the late pieces had barely one)
+      if (kt_next >= 0 && j == 0) {
+#pragma unroll
+        for (int i = 0; i < A_DMA; ++i) issue_a(kt_next, stage_next, i);
+#pragma unroll
+        for (int i = 0; i < W_DMA; ++i) issue_w(kt_next, stage_next, i);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -331,7 +349,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   stamp(2);
   if (nkt > 1) {
     if (LP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (LP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (LP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -355,7 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 
   // ---- epilogue: LDS-staged, row-wise vectorised (gemm_epilogue.h)
   if (dbg & 1) { if (acc[0][0][0] == 123.456f) ((float*)p.c)[0] = 1.f; return; }
-  siu3r_epi::run<NI>(p, acc, smem, tile_m, tile_n, z, t);
+  siu3r_epi::run<NI, KSPL>(p, acc, smem, tile_m, tile_n, z, t);
   if (trace && t == 0) {
     trace[6] = __builtin_readcyclecounter();  // last store issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -386,19 +406,22 @@ int siu3r_gemm_dma_launch(const siu3r_gemm_params& p, int ni, void* stream) {
   const int tiles = 8 * p.map_rm * p.map_rn;
   dim3 grid(tiles, 1, p.batch > 0 ? p.batch : 1);
   hipStream_t s = (hipStream_t)stream;
-  dim3 block(256);
-#define SIU3R_DMA_LAUNCH(NI_, MODE_, RELU_) hipLaunchKernelGGL((gemm_dma_kernel<NI_, MODE_, RELU_>), grid, block, 0, s, p)
-  if (ni == 1) {
-    if (mode == 0) SIU3R_DMA_LAUNCH(1, 0, false);
-    else if (mode == 1 && p.relu_in) SIU3R_DMA_LAUNCH(1, 1, true);
-    else if (mode == 1) SIU3R_DMA_LAUNCH(1, 1, false);
-    else SIU3R_DMA_LAUNCH(1, 2, false);
-  } else {
-    if (mode == 0) SIU3R_DMA_LAUNCH(2, 0, false);
-    else if (mode == 1 && p.relu_in) SIU3R_DMA_LAUNCH(2, 1, true);
-    else if (mode == 1) SIU3R_DMA_LAUNCH(2, 1, false);
-    else SIU3R_DMA_LAUNCH(2, 2, false);
-  }
+  static const bool no_ksplit = getenv("SIU3R_GEMM_NO_KSPLIT") != nullptr;  // A/B switch: 4-wave workgroups for the 128x64 tile
+  const int kspl = no_ksplit ? 1 : 2;
+  dim3 block(256 * kspl);
+#define SIU3R_DMA_LAUNCH(NI_, MODE_, RELU_, KS_) hipLaunchKernelGGL((gemm_dma_kernel<NI_, MODE_, RELU_, KS_>), grid, block, 0, s, p)
+#define SIU3R_DMA_MODES(NI_, KS_)                                      \
+  do {                                                                 \
+    if (mode == 0) SIU3R_DMA_LAUNCH(NI_, 0, false, KS_);               \
+    else if (mode == 1 && p.relu_in) SIU3R_DMA_LAUNCH(NI_, 1, true, KS_); \
+    else if (mode == 1) SIU3R_DMA_LAUNCH(NI_, 1, false, KS_);          \
+    else SIU3R_DMA_LAUNCH(NI_, 2, false, KS_);                         \
+  } while (0)
+  if (ni == 2 && kspl == 2) SIU3R_DMA_MODES(2, 2);
+  else if (ni == 2) SIU3R_DMA_MODES(2, 1);
+  else if (kspl == 2) SIU3R_DMA_MODES(1, 2);
+  else SIU3R_DMA_MODES(1, 1);
+#undef SIU3R_DMA_MODES
 #undef SIU3R_DMA_LAUNCH
   SIU3R_LAUNCH_CHECK("siu3r_gemm(dma)");
   return 0;

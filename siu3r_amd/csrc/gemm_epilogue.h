@@ -32,7 +32,7 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * (ax * e + x);
 }
 
-template <int NI>
+template <int NI, int KSPL = 1>
 constexpr int staging_bytes() { return 128 * (64 * NI + 4) * 4; }
 
 // The whole 128 x BN accumulator tile is staged once (two raw barriers); every thread then owns ONE 8-column chunk
@@ -40,17 +40,20 @@ constexpr int staging_bytes() { return 128 * (64 * NI + 4) * 4; }
 // residual, RoPE positions, then the cos/sin rows -- are issued before any of them is used, and the first group's are
 // issued before the staging barriers, so the tile pays one memory latency instead of one per row (the per-row
 // dependent loads of the previous version cost as much as a K = 1024 main loop).
-template <int NI>
+// KSPL = 2: the workgroup has 8 waves; waves 4..7 hold the accumulators of the second half of every K tile for the same
+// sub-tiles as waves 0..3.  They hand their partial sums to waves 0..3 through the staging area first (same lane, same
+// register <-> same address), then the tile is staged once and all 512 threads run the row pass.
+template <int NI, int KSPL = 1>
 __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2][NI], unsigned char* smem, int tile_m,
                                     int tile_n, int z, int t) {
   constexpr int BN = 64 * NI, BM = 128;
   constexpr int LDC = BN + 4;            // floats per staged row (16-B aligned rows, spreads banks)
   constexpr int CHUNKS = BN / 8;         // 8-column chunks per row
-  constexpr int RPP = 256 / CHUNKS;      // rows per pass of the 256 threads
-  constexpr int NTASK = BM / RPP;        // rows per thread (4 or 8)
-  constexpr int G = 4, NG = NTASK / G;
+  constexpr int RPP = 256 * KSPL / CHUNKS;  // rows per pass of the workgroup's threads
+  constexpr int NTASK = BM / RPP;        // rows per thread
+  constexpr int G = NTASK < 4 ? NTASK : 4, NG = NTASK / G;
   float* cs = (float*)smem;
-  const int lane = t & 63, wave = t >> 6;
+  const int lane = t & 63, wave = (t >> 6) & 3, kh = t >> 8;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
   unsigned char* Cb = (unsigned char*)p.c;
@@ -121,22 +124,48 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
 
   issue_loads(0);
   // ---- stage the tile.  Raw barriers: the loads above stay in flight across them
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();  // main loop no longer reads the ring
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  lds_barrier();  // main loop no longer reads the ring
+  if (KSPL == 2) {
+    if (kh == 1) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int col = wn * (32 * NI) + j * 32 + l31;
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lr = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        cs[lr * LDC + col] = acc[i][j][r];
-      }
+          for (int r = 0; r < 16; ++r)
+            cs[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wn * (32 * NI) + j * 32 + l31] = acc[i][j][r];
     }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+    lds_barrier();
+    if (kh == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[i][j][r] += cs[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wn * (32 * NI) + j * 32 + l31];
+    }
+    lds_barrier();  // the partials have been read: the area may be overwritten with the totals
+  }
+  if (kh == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int col = wn * (32 * NI) + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          cs[lr * LDC + col] = acc[i][j][r];
+        }
+      }
+  }
+  lds_barrier();
   if (p.trace && t == 0) p.trace[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8 + 5] = __builtin_readcyclecounter();
 
 #pragma unroll
@@ -167,8 +196,8 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
       for (int e = 0; e < 8; ++e) v[e] += bias[e];
       // ---- RoPE2D on q|k columns
       if (rope) {
-        const float4 a = *(const float4*)(cs + lr * LDC + pc * 8);
-        const float4 b = *(const float4*)(cs + lr * LDC + pc * 8 + 4);
+        float4 a = *(const float4*)(cs + lr * LDC + pc * 8);
+        float4 b = *(const float4*)(cs + lr * LDC + pc * 8 + 4);
         const float pv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         const float cc[8] = {rc[k][0].x, rc[k][0].y, rc[k][0].z, rc[k][0].w, rc[k][1].x, rc[k][1].y, rc[k][1].z, rc[k][1].w};
         const float ss[8] = {rs[k][0].x, rs[k][0].y, rs[k][0].z, rs[k][0].w, rs[k][1].x, rs[k][1].y, rs[k][1].z, rs[k][1].w};
