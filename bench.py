@@ -119,10 +119,10 @@ def main():
         traffic, traffic_src = None, None
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         if os.path.exists(pmc_path) and args.precision == "bf16" and B == 1 and (H, W) == (512, 512):
-            pmc = json.load(open(pmc_path)).get("siu3r_gemm_dma::gemm_dma_kernel<1, 0, false>") if name == "gemm_dma_kernel<1,0,false>" else None
+            pmc = json.load(open(pmc_path)).get("siu3r_gemm_dma::gemm_dma_kernel<1, 0, false, 2>") if name == "gemm_dma_kernel<1,0,false,2>" else None
             if pmc:
                 traffic = (2.0 * pmc["fetch_size_per_launch"] + pmc["write_size_per_launch"]) * 1024.0
-                traffic_src = "profiles/r01_pmc_summary.json (gemm_dma_kernel<1,0,false>, mean per launch)"
+                traffic_src = "profiles/r01_pmc_summary.json (gemm_dma_kernel<1,0,false,2>, mean per launch)"
         result["roofline"] = {
             "kernel": f"siu3r_gemm_dma::{name} (dense Linear launches; HIP events around every launch of one eager single-stream step, queued behind a sleep kernel, after the timed region)",
             "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -150,11 +150,11 @@ def _gemm_launch(p: GemmParams):
     elif p.a_dtype == F32 or p.a_mode == 2:
         variant = "gemm_kernel<1,0,1> (fp32 A)"
     elif p.a_mode == 0:
-        variant = "gemm_dma_kernel<1,0,false>" if not p.relu_in else "gemm_kernel<0,0,1>"
+        variant = "gemm_dma_kernel<1,0,false,2>" if not p.relu_in else "gemm_kernel<0,0,1>"
     elif p.cin % 64 == 0 and p.kh * p.kw <= 32 and p.kpad == p.k:
-        variant = "gemm_dma_kernel<1,1,true>" if p.relu_in else "gemm_dma_kernel<1,1,false>"
+        variant = "gemm_dma_kernel<1,1,true,2>" if p.relu_in else "gemm_dma_kernel<1,1,false,2>"
     else:
-        variant = "gemm_dma_kernel<1,2,false>" if not p.relu_in else "gemm_kernel<0,0,1>"
+        variant = "gemm_dma_kernel<1,2,false,2>" if not p.relu_in else "gemm_kernel<0,0,1>"
     flops = 2.0 * p.m * p.n * p.k * max(1, p.batch)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
