@@ -209,3 +209,32 @@ def test_inference_cli_writes_ply(tmp_path):
     names = v.dtype.names
     assert names[:9] == ("x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2") and "semantic_label" in names and "rot_3" in names
     assert np.isfinite(v["x"]).all() and np.isfinite(v["opacity"]).all() and (v["opacity"] >= 0).all() and (v["opacity"] <= 1).all()
+
+
+def test_batch_of_pairs_matches_single_pairs():
+    """B = 2 pairs in one forward (graph-captured on the third call) == each pair alone: every kernel keeps per-item results
+    independent of the batch (same K-accumulation order per output element), so the outputs agree to fp32 rounding of the
+    few batch-shaped reductions, and the integer outputs exactly."""
+    from oracle import weights as OW
+    from siu3r_amd.model import SIU3RModel
+
+    if "sd" not in _STATE:
+        _STATE["sd"] = OW.make_weights(0)
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(2, 2, 3, 128, 128, generator=g).cuda()
+    K = torch.tensor([[318 / 256, 0, 0.5], [0, 318 / 256, 0.5], [0, 0, 1]])[None, None].repeat(2, 2, 1, 1).cuda()
+    model = SIU3RModel(_STATE["sd"], image_size=(128, 128), precision="bf16x3")
+    with torch.no_grad():
+        outs = [model(img, K) for _ in range(3)]            # eager, capture, replay
+        singles = [model(img[i:i + 1], K[i:i + 1]) for i in range(2)]
+    for o in outs[1:]:
+        assert torch.equal(o[0].means, outs[0][0].means) and torch.equal(o[1].class_queries_logits, outs[0][1].class_queries_logits)
+    for i in range(2):
+        gb, gs_ = outs[0][0], singles[i][0]
+        for f in ("means", "covariances", "harmonics", "opacities"):
+            a, b = getattr(gb, f)[i], getattr(gs_, f)[0]
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), f
+        assert torch.equal(gb.semantic_labels[i], gs_.semantic_labels[0]) and torch.equal(gb.instance_labels[i], gs_.instance_labels[0])
+        assert outs[0][3][i] == singles[i][3][0]
+    del model
+    torch.cuda.empty_cache()
