@@ -79,6 +79,10 @@ int siu3r_gemm(const siu3r_gemm_params* p, void* stream);
  * croco/blocks.py:127-191 (eps 1e-6), video_seg_decoder.py:945-1018 (eps 1e-5). */
 int siu3r_layernorm(const float* x, void* y, int y_dtype, const float* gamma, const float* beta,
                     int64_t rows, int C, int64_t ldx, int64_t ldy, float eps, void* stream);
+/* same, plus a second bf16 copy y2 of the result (row stride ldy2): the fp32 output remains the residual stream, the bf16 one is
+ * the next GEMM's A operand */
+int siu3r_layernorm2(const float* x, void* y, int y_dtype, void* y2_bf16, const float* gamma, const float* beta, int64_t rows, int C,
+                     int64_t ldx, int64_t ldy, int64_t ldy2, float eps, void* stream);
 
 /* ---- fused attention (flash style, online softmax), head_dim 64 or 32.
  * Replaces Attention/CrossAttention (croco/blocks.py:94-112,149-169, incl. RoPE2D on q,k) and

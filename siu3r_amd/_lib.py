@@ -73,6 +73,7 @@ SIGNATURES = {
     "siu3r_rope2d": [_P, _I, _I, _I, _I, _I, _L, _L, _L, _P, _F, _F, _P],
     "siu3r_gemm": [C.POINTER(GemmParams), _P],
     "siu3r_layernorm": [_P, _P, _I, _P, _P, _L, _I, _L, _L, _F, _P],
+    "siu3r_layernorm2": [_P, _P, _I, _P, _P, _P, _L, _I, _L, _L, _L, _F, _P],
     "siu3r_attention": [C.POINTER(AttnParams), _P],
     "siu3r_add": [_P, _P, _P, _L, _L, _I, _P],
     "siu3r_pack_image_nhwc8": [_P, _P, _I, _I, _I, _I, _P],

@@ -77,9 +77,11 @@ __global__ void rope2d_kernel(T* tokens, const int64_t* pos, int B, int N, int H
 
 // ================================ LayerNorm ======================================================
 // One wave per row; the row lives in registers (C <= 2048); two-pass mean / variance.
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, void* y, int y_dtype, const float* gamma,
+// y2 (optional): a second, bf16 copy of the result -- the fp32 one stays the residual stream, the bf16 one feeds the next
+// GEMM through the LDS-DMA path (which takes bf16 A) instead of the slower fp32-A kernel.
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, void* y, int y_dtype, void* y2, const float* gamma,
                                                         const float* beta, int64_t rows, int C, int64_t ldx,
-                                                        int64_t ldy, float eps) {
+                                                        int64_t ldy, int64_t ldy2, float eps) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -116,6 +118,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, void* y,
       o.v[2] = (v[i].z - mean) * rstd * g.z + bb.z;
       o.v[3] = (v[i].w - mean) * rstd * g.w + bb.w;
       store4(y, y_dtype, row * ldy + c, o);
+      if (y2) store4(y2, SIU3R_BF16, row * ldy2 + c, o);
     }
   }
 }
@@ -563,8 +566,18 @@ extern "C" int siu3r_layernorm(const float* x, void* y, int y_dtype, const float
   SIU3R_CHECK(x && y && gamma && beta, "layernorm: null pointer");
   SIU3R_CHECK(C % 4 == 0 && C <= 2048 && ldx % 4 == 0 && ldy % 4 == 0, "layernorm: C=%d must be a multiple of 4 and <= 2048", C);
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, y_dtype, gamma, beta, rows, C, ldx, ldy, eps);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, y_dtype, (void*)nullptr, gamma, beta, rows, C, ldx, ldy, (int64_t)0, eps);
   SIU3R_LAUNCH_CHECK("siu3r_layernorm");
+  return 0;
+}
+
+extern "C" int siu3r_layernorm2(const float* x, void* y, int y_dtype, void* y2_bf16, const float* gamma, const float* beta, int64_t rows,
+                                int C, int64_t ldx, int64_t ldy, int64_t ldy2, float eps, void* stream) {
+  SIU3R_CHECK(x && y && y2_bf16 && gamma && beta, "layernorm2: null pointer");
+  SIU3R_CHECK(C % 4 == 0 && C <= 2048 && ldx % 4 == 0 && ldy % 4 == 0 && ldy2 % 4 == 0, "layernorm2: C=%d must be a multiple of 4 and <= 2048", C);
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, y_dtype, y2_bf16, gamma, beta, rows, C, ldx, ldy, ldy2, eps);
+  SIU3R_LAUNCH_CHECK("siu3r_layernorm2");
   return 0;
 }
 

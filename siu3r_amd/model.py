@@ -116,6 +116,14 @@ class _Ctx:
     def ln(self, name, x, eps, out_dtype=None):
         return ops.layernorm(x, self.w.v(name + ".weight"), self.w.v(name + ".bias"), eps, out_dtype or self.act)
 
+    def ln2(self, name, x, eps):
+        """(fp32 result for the residual stream, the same values in the GEMM-input dtype).  bf16 mode: one kernel writes both;
+        bf16x3 mode: the GEMMs take fp32, so both are the one fp32 tensor."""
+        if self.split:
+            y = ops.layernorm(x, self.w.v(name + ".weight"), self.w.v(name + ".bias"), eps, torch.float32)
+            return y, y
+        return ops.layernorm2(x, self.w.v(name + ".weight"), self.w.v(name + ".bias"), eps)
+
 
 # ==================================================================================================
 # backbone  (reference backbone_croco.py:24-347; croco/blocks.py:81-191)
@@ -624,17 +632,31 @@ class VideoMask2FormerForVideoSegmentation:
             n = shapes[lvl][0] * shapes[lvl][1]
             hs[:, o:o + n] = e.view(N2, n, 256)  # layout plumbing: concatenate levels
             o += n
+        # hs: fp32 residual stream; hsb: the same tokens in the GEMM-input dtype (a bf16 copy written by the producing LayerNorm in
+        # bf16 mode, so that every projection runs on the LDS-DMA GEMM instead of the fp32-A kernel).  The query-position term of
+        # the offset / weight projection, W (hs + pos) = W hs + W pos, is a constant [S, 288] residual.
+        hsb = hs if ctx.split else hs.to(ctx.act)
         for i in range(6):
             p = f"{pd}.encoder.layers.{i}"
-            q = ops.add(hs, pos)
-            offs_aw = ops.linear(q, ctx.w.merged(p + ".self_attn.offs_aw", [p + ".self_attn.sampling_offsets", p + ".self_attn.attention_weights"]), out_dtype=torch.float32)
-            value = ops.linear(hs, ctx.w.linear(p + ".self_attn.value_proj"), out_dtype=ctx.act)
+            wkey = p + ".self_attn.offs_aw0"
+            if wkey not in ctx.w.lin:
+                w_oa = torch.cat((ctx.w.t(p + ".self_attn.sampling_offsets.weight"), ctx.w.t(p + ".self_attn.attention_weights.weight")), 0)
+                b_oa = torch.cat((ctx.w.t(p + ".self_attn.sampling_offsets.bias"), ctx.w.t(p + ".self_attn.attention_weights.bias")), 0)
+                ctx.w.lin[wkey] = ops.pack_matrix(w_oa, None, ctx.split)
+                ctx.cache[wkey] = (w_oa, b_oa)
+            rkey = (wkey, tuple(shapes))
+            if rkey not in ctx.cache:
+                w_oa, b_oa = ctx.cache[wkey]
+                ctx.cache[rkey] = (pos @ w_oa.t() + b_oa).contiguous()
+            pres = ctx.cache[rkey]
+            offs_aw = ops.linear(hsb, ctx.w.lin[wkey], out_dtype=torch.float32, residual=pres if N2 == 1 else pres[None].expand(N2, -1, -1))
+            value = ops.linear(hsb, ctx.w.linear(p + ".self_attn.value_proj"), out_dtype=ctx.act)
             samp = ops.msdeform_sample(value, offs_aw, ref, shapes, 8, 4, ctx.act)
             a = ops.linear(samp, ctx.w.linear(p + ".self_attn.output_proj"), out_dtype=torch.float32, residual=hs)
-            hs = ctx.ln(p + ".self_attn_layer_norm", a, 1e-5, out_dtype=torch.float32)
-            f_ = ops.linear(hs, ctx.w.linear(p + ".fc1"), out_dtype=ctx.act, act=ACT_RELU)
+            hs, hsb = ctx.ln2(p + ".self_attn_layer_norm", a, 1e-5)
+            f_ = ops.linear(hsb, ctx.w.linear(p + ".fc1"), out_dtype=ctx.act, act=ACT_RELU)
             f_ = ops.linear(f_, ctx.w.linear(p + ".fc2"), out_dtype=torch.float32, residual=hs)
-            hs = ctx.ln(p + ".final_layer_norm", f_, 1e-5, out_dtype=torch.float32)
+            hs, hsb = ctx.ln2(p + ".final_layer_norm", f_, 1e-5)
         outs, o = [], 0
         for (hh, ww) in shapes:
             outs.append(hs[:, o:o + hh * ww].contiguous().view(N2, hh, ww, 256))
@@ -655,9 +677,14 @@ class VideoMask2FormerForVideoSegmentation:
         p = "mask2former.model.transformer_module.decoder.mask_predictor.mask_embedder"
         e = ops.linear(inter, ctx.w.linear(p + ".0.0"), out_dtype=ctx.act, act=ACT_RELU)
         e = ops.linear(e, ctx.w.linear(p + ".1.0"), out_dtype=ctx.act, act=ACT_RELU)
-        e = ops.linear(e, ctx.w.linear(p + ".2.0"), out_dtype=torch.float32)
-        B, Q, Cc = e.shape
-        hi, lo, kpad = ops.split_bf16(e.view(B * Q, Cc), ctx.split)
+        if ctx.split:
+            e = ops.linear(e, ctx.w.linear(p + ".2.0"), out_dtype=torch.float32)
+            B, Q, Cc = e.shape
+            hi, lo, kpad = ops.split_bf16(e.view(B * Q, Cc), True)
+        else:  # bf16 mode: the embedding leaves the GEMM as the bf16 "weight" plane of the mask product (256 = 4 x 64: no K padding)
+            hi, lo = ops.linear(e, ctx.w.linear(p + ".2.0"), out_dtype=torch.bfloat16), None
+            B, Q, Cc = hi.shape
+            kpad = Cc
         m = ops.bmm_nt(mask_features_bt, hi.view(B, Q, kpad), None if lo is None else lo.view(B, Q, kpad), Q, Cc)
         m = m.view(B, self._T, self._H4, self._W4, Q)
         am = ops.m2f_attn_mask(m, size) if size is not None else None
@@ -671,6 +698,8 @@ class VideoMask2FormerForVideoSegmentation:
         H4, W4 = mask_features.shape[1], mask_features.shape[2]
         self._T, self._H4, self._W4 = T, H4, W4
         mf_bt = mask_features.view(B, T * H4 * W4, 256)
+        if not ctx.split:
+            mf_bt = mf_bt.to(ctx.act)  # one cast per forward: the ten mask products then run on the bf16 LDS-DMA GEMM
         sizes = [(f.shape[1], f.shape[2]) for f in ms]
         key = ("m2f_pos3d", T, tuple(sizes))
         if key not in ctx.cache:
@@ -707,10 +736,11 @@ class VideoMask2FormerForVideoSegmentation:
         qf = ctx.w.v(tm + ".queries_features.weight")
         qe = ctx.w.v(tm + ".queries_embedder.weight")
         hs = qf.unsqueeze(0).expand(B, -1, -1).contiguous()
+        hsb = hs if ctx.split else hs.to(ctx.act)   # GEMM-input copy of the residual stream (see _pixel_decoder)
         d = 32
-        inter = ctx.ln(dp + ".layernorm", hs, 1e-5, out_dtype=torch.float32)
+        inter, interb = ctx.ln2(dp + ".layernorm", hs, 1e-5)
         masks, inters = [], [inter]
-        m, am = self._mask_predictor(inter, mf_bt, sizes[0])
+        m, am = self._mask_predictor(interb, mf_bt, sizes[0])
         masks.append(m)
         for idx in range(9):
             p = f"{dp}.layers.{idx}"
@@ -727,26 +757,26 @@ class VideoMask2FormerForVideoSegmentation:
                 ctx.cache[p + ".self_attn.qkres"] = (qe @ wqk.t() + torch.cat((bq, bk_), 0)).contiguous()
             bres = (lambda r: r if B == 1 else r[None].expand(B, -1, -1))
             # masked cross-attention (nn.MultiheadAttention, :975-983): q from hs + query pos, k from feats + pos3d, v from feats
-            q = ops.linear(hs, ctx.w.lin[p + ".cross_attn.q"], out_dtype=ctx.act, residual=bres(ctx.cache[p + ".cross_attn.qres"])).view(B, Q, 8, d)
+            q = ops.linear(hsb, ctx.w.lin[p + ".cross_attn.q"], out_dtype=ctx.act, residual=bres(ctx.cache[p + ".cross_attn.qres"])).view(B, Q, 8, d)
             j = idx // 3
             k, v = kvs[lvl][:, :, j], kvs[lvl][:, :, 3 + j]
             a = ops.attention(q, k, v, heads=8, head_dim=d, scale=d ** -0.5, mask=am, split3=ctx.split)
             a = ops.linear(a, ctx.w.linear(p + ".cross_attn.out_proj"), out_dtype=torch.float32, residual=hs)
-            hs = ctx.ln(p + ".cross_attn_layer_norm", a, 1e-5, out_dtype=torch.float32)
+            hs, hsb = ctx.ln2(p + ".cross_attn_layer_norm", a, 1e-5)
             # self-attention, DETR style (:782-912): pos added to q and k, v from hs
-            qk = ops.linear(hs, ctx.w.lin[p + ".self_attn.qk0"], out_dtype=ctx.act, residual=bres(ctx.cache[p + ".self_attn.qkres"])).view(B, Q, 2, 8, d)
-            v = ops.linear(hs, ctx.w.linear(p + ".self_attn.v_proj"), out_dtype=ctx.act).view(B, Q, 8, d)
+            qk = ops.linear(hsb, ctx.w.lin[p + ".self_attn.qk0"], out_dtype=ctx.act, residual=bres(ctx.cache[p + ".self_attn.qkres"])).view(B, Q, 2, 8, d)
+            v = ops.linear(hsb, ctx.w.linear(p + ".self_attn.v_proj"), out_dtype=ctx.act).view(B, Q, 8, d)
             a = ops.attention(qk[:, :, 0], qk[:, :, 1], v, heads=8, head_dim=d, scale=d ** -0.5, split3=ctx.split)
             a = ops.linear(a, ctx.w.linear(p + ".self_attn.out_proj"), out_dtype=torch.float32, residual=hs)
-            hs = ctx.ln(p + ".self_attn_layer_norm", a, 1e-5, out_dtype=torch.float32)
-            f_ = ops.linear(hs, ctx.w.linear(p + ".fc1"), out_dtype=ctx.act, act=ACT_RELU)
+            hs, hsb = ctx.ln2(p + ".self_attn_layer_norm", a, 1e-5)
+            f_ = ops.linear(hsb, ctx.w.linear(p + ".fc1"), out_dtype=ctx.act, act=ACT_RELU)
             f_ = ops.linear(f_, ctx.w.linear(p + ".fc2"), out_dtype=torch.float32, residual=hs)
-            hs = ctx.ln(p + ".final_layer_norm", f_, 1e-5, out_dtype=torch.float32)
-            inter = ctx.ln(dp + ".layernorm", hs, 1e-5, out_dtype=torch.float32)
-            m, am = self._mask_predictor(inter, mf_bt, sizes[(idx + 1) % 3])
+            hs, hsb = ctx.ln2(p + ".final_layer_norm", f_, 1e-5)
+            inter, interb = ctx.ln2(dp + ".layernorm", hs, 1e-5)
+            m, am = self._mask_predictor(interb, mf_bt, sizes[(idx + 1) % 3])
             masks.append(m)
             inters.append(inter)
-        class_logits = ops.linear(inters[-1], ctx.w.linear("mask2former.class_predictor"), out_dtype=torch.float32)
+        class_logits = ops.linear(interb, ctx.w.linear("mask2former.class_predictor"), out_dtype=torch.float32)
         return class_logits, masks[-1], masks, inters
 
     def forward_nhwc(self, feats_nhwc: Sequence[torch.Tensor], B: int, T: int):

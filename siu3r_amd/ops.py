@@ -365,6 +365,18 @@ def attention(q, k, v, *, heads: int, head_dim: int, scale: float, rope=None, qp
     return out
 
 
+def layernorm2(x: torch.Tensor, gamma, beta, eps: float):
+    """LayerNorm with two outputs: (fp32, bf16 copy).  x contiguous fp32."""
+    _gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    out2 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().siu3r_layernorm2(_p(x), _p(out), F32, _p(out2), _p(gamma), _p(beta), rows, Cc, Cc, Cc, Cc, eps, _stream()))
+    return out, out2
+
+
 def layernorm(x: torch.Tensor, gamma, beta, eps: float, out_dtype=torch.float32):
     _gpu(x)
     assert x.dtype == torch.float32 and x.stride(-1) == 1
