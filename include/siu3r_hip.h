@@ -179,15 +179,18 @@ typedef struct {
 } siu3r_raster_cam;
 /* stage 1+2: project G Gaussians (means [G,3], cov6 [G,6] upper-triangular, opacities [G], colors: mode 0 SH
  * [G,channels,3], mode 1 unused) and count/scan tiles.  Outputs: mean2d [G,2], conic_op [G,4], depth [G], radii [G,2]
- * i32, rect [G,4] i32, tiles_touched [G] i32, rgb [G,3] (mode 0), tile_count [8,T] (8 counter sets, see raster.hip), tile_start [T+1], cursor [8,T] i32.
- * tile_start[T] = D, the number of (tile, Gaussian) pairs, which sizes the key buffer of the next stage. */
+ * i32, rect [G,4] i32, tiles_touched [G] i32, rgb [G,3] (mode 0), tile_count [8,T] (8 counter sets, see raster.hip), tile_start [T+2], cursor [8,T] i32.
+ * cap = capacity (in pairs) of the keys/ids buffers handed to siu3r_raster_sort: tile_start[0..T] are clamped to it, tile_start[T+1]
+ * holds the true pair count D, so the caller can size the buffers by an upper bound, enqueue the whole frame without reading D back,
+ * and verify D <= cap afterwards (the CUDA originals resize their buffers behind a device-to-host copy instead).
+ * tile_start[T] = min(D, cap). */
 int siu3r_raster_bin(const siu3r_raster_cam* cam, int64_t G, const float* means, const float* cov6,
                      const float* opacities, const float* colors, int channels, float* mean2d, float* conic_op,
                      float* depth, int32_t* radii, int32_t* rect, int32_t* tiles_touched, float* rgb, int32_t* tile_count,
-                     int32_t* tile_start, int32_t* cursor, void* stream);
+                     int32_t* tile_start, int32_t* cursor, int64_t cap, void* stream);
 /* stage 3+4: fill and sort the per-tile lists; keys [D] u64 (depth bits << 32 | id), ids [D] i32 (front to back) */
 int siu3r_raster_sort(const siu3r_raster_cam* cam, int64_t G, const int32_t* rect, const float* depth,
-                      const int32_t* tile_start, int32_t* cursor, uint64_t* keys, int32_t* ids, void* stream);
+                      const int32_t* tile_start, int32_t* cursor, uint64_t* keys, int32_t* ids, int64_t cap, void* stream);
 /* stage 5 (mode 0): image [3,H,W], depth [H,W], accumulated opacity [H,W], n_touched [G] i32 */
 int siu3r_raster_composite_rgb(const siu3r_raster_cam* cam, const int32_t* tile_start, const int32_t* ids,
                                const float* mean2d, const float* conic_op, const float* depth, const float* rgb,

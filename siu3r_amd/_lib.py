@@ -87,8 +87,8 @@ SIGNATURES = {
     "siu3r_gaussian_adapter": [_P, _I, _P, _P, _P, _P, _P, _L, _P],
     "siu3r_m2f_attn_mask": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "siu3r_split_bf16": [_P, _P, _P, _L, _I, _I, _L, _P],
-    "siu3r_raster_bin": [C.POINTER(RasterCam), _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "siu3r_raster_sort": [C.POINTER(RasterCam), _L, _P, _P, _P, _P, _P, _P, _P],
+    "siu3r_raster_bin": [C.POINTER(RasterCam), _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
+    "siu3r_raster_sort": [C.POINTER(RasterCam), _L, _P, _P, _P, _P, _P, _P, _L, _P],
     "siu3r_raster_composite_rgb": [C.POINTER(RasterCam), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     "siu3r_raster_composite_feat": [C.POINTER(RasterCam), _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "siu3r_scale_inplace": [_P, _L, _F, _P],

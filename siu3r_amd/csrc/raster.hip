@@ -235,7 +235,7 @@ __global__ void project_kernel(Cam c, int64_t G, const float* means, const float
 // workgroup a Gaussian belongs to is the same in both kernels (same grid), and the per-tile sort makes the final order independent
 // of the partition.
 // exclusive scan of sum_c tile_count[c][T] -> tile_start[T+1], cursor[c][T]; single workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void scan_kernel(const int32_t* tile_count, int32_t* tile_start, int32_t* cursor, int T) {
+__global__ __launch_bounds__(1024) void scan_kernel(const int32_t* tile_count, int32_t* tile_start, int32_t* cursor, int T, int cap) {
   __shared__ int32_t wsum[16];
   __shared__ int32_t carry;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int32_t* tile_count, i
     for (int w = 0; w < wave; ++w) woff += wsum[w];
     const int excl = carry + woff + incl - v;
     if (i < T) {
-      tile_start[i] = excl;
+      tile_start[i] = min(excl, cap);  // ranges are clamped to the pair buffers' capacity (see siu3r_raster_bin)
       int run = excl;
 #pragma unroll
       for (int c = 0; c < NPART; ++c) {
@@ -274,10 +274,13 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int32_t* tile_count, i
     if (t == 1023) carry = excl + v;
     __syncthreads();
   }
-  if (t == 0) tile_start[T] = carry;
+  if (t == 0) {
+    tile_start[T] = min(carry, cap);
+    tile_start[T + 1] = carry;  // the true pair count: the host compares it with cap after the frame has been enqueued
+  }
 }
 
-__global__ void fill_kernel(int64_t G, const int32_t* rect, const float* depth, int32_t* cursor, uint64_t* keys, int gw, int T) {
+__global__ void fill_kernel(int64_t G, const int32_t* rect, const float* depth, int32_t* cursor, uint64_t* keys, int gw, int T, int cap) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
   const int tx0 = rect[4 * g], ty0 = rect[4 * g + 1], tx1 = rect[4 * g + 2], ty1 = rect[4 * g + 3];
@@ -286,7 +289,7 @@ __global__ void fill_kernel(int64_t G, const int32_t* rect, const float* depth, 
   for (int ty = ty0; ty < ty1; ++ty)
     for (int tx = tx0; tx < tx1; ++tx) {
       const int pos = atomicAdd(&cursor[(blockIdx.x & (NPART - 1)) * T + ty * gw + tx], 1);
-      keys[pos] = key;
+      if (pos < cap) keys[pos] = key;
     }
 }
 
@@ -614,8 +617,9 @@ __global__ void blend_bg_kernel(int64_t n, int C, float* colors, const float* al
 extern "C" int siu3r_raster_bin(const siu3r_raster_cam* cam, int64_t G, const float* means, const float* cov6,
                                 const float* opacities, const float* colors, int channels, float* mean2d, float* conic_op,
                                 float* depth, int32_t* radii, int32_t* rect, int32_t* tiles_touched, float* rgb,
-                                int32_t* tile_count, int32_t* tile_start, int32_t* cursor, void* stream) {
+                                int32_t* tile_count, int32_t* tile_start, int32_t* cursor, int64_t cap, void* stream) {
   SIU3R_CHECK(cam && tile_count && tile_start && cursor, "raster_bin: null pointer");
+  SIU3R_CHECK(cap > 0 && cap < (1ll << 31), "raster_bin: pair capacity %ld out of range", (long)cap);
   SIU3R_CHECK(G == 0 || (means && cov6 && opacities && mean2d && conic_op && depth && radii && rect && tiles_touched), "raster_bin: null per-Gaussian pointer");
   SIU3R_CHECK(cam->mode == 0 || cam->mode == 1, "raster_bin: bad mode %d", cam->mode);
   SIU3R_CHECK(cam->mode == 1 || G == 0 || (colors && rgb && channels >= (cam->sh_degree + 1) * (cam->sh_degree + 1)), "raster_bin: SH colours missing / too few coefficients");
@@ -629,17 +633,17 @@ extern "C" int siu3r_raster_bin(const siu3r_raster_cam* cam, int64_t G, const fl
   }
   if (G > 0)
     hipLaunchKernelGGL(project_kernel, g1(G), dim3(256), 0, s, c, G, means, cov6, opacities, colors, channels, mean2d, conic_op, depth, radii, rect, tiles_touched, rgb, tile_count);
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, tile_count, tile_start, cursor, T);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, tile_count, tile_start, cursor, T, (int)cap);
   SIU3R_LAUNCH_CHECK("siu3r_raster_bin");
   return 0;
 }
 
 extern "C" int siu3r_raster_sort(const siu3r_raster_cam* cam, int64_t G, const int32_t* rect, const float* depth,
-                                 const int32_t* tile_start, int32_t* cursor, uint64_t* keys, int32_t* ids, void* stream) {
+                                 const int32_t* tile_start, int32_t* cursor, uint64_t* keys, int32_t* ids, int64_t cap, void* stream) {
   SIU3R_CHECK(cam && tile_start && cursor && keys && ids && (G == 0 || (rect && depth)), "raster_sort: null pointer");
   hipStream_t s = (hipStream_t)stream;
   const int gw = (cam->width + TILE - 1) / TILE, T = gw * ((cam->height + TILE - 1) / TILE);
-  if (G > 0) hipLaunchKernelGGL(fill_kernel, g1(G), dim3(256), 0, s, G, rect, depth, cursor, keys, gw, T);
+  if (G > 0) hipLaunchKernelGGL(fill_kernel, g1(G), dim3(256), 0, s, G, rect, depth, cursor, keys, gw, T, (int)cap);
   hipLaunchKernelGGL((sort_kernel<1024, 0>), dim3(T), dim3(256), 0, s, tile_start, keys, ids);
   hipLaunchKernelGGL((sort_kernel<4096, 1024>), dim3(T), dim3(256), 0, s, tile_start, keys, ids);
   hipLaunchKernelGGL((sort_kernel<SORT_CAP, 4096>), dim3(T), dim3(256), 0, s, tile_start, keys, ids);

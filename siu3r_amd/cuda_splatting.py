@@ -59,10 +59,15 @@ def render_cuda(extrinsics, intrinsics, near, far, image_shape, background_color
     w2c = torch.linalg.inv(ext)
     full = proj @ w2c  # column-vector form of the reference's row-vector view @ proj (cuda_splatting.py:74-77)
     images, depths, aux = [], [], []
+    prev = None
     for i in range(b):
         means = gaussian_means[i]
-        cov6 = raster.cov6_from_cov3x3(gaussian_covariances[i])
-        shs = gaussian_sh_coefficients[i].permute(0, 2, 1).contiguous()  # 'g xyz n -> g n xyz' (:65)
+        # the reference's callers pass the same Gaussians expanded over the views: repack them (6-entry covariances, 'g xyz n ->
+        # g n xyz' coefficients (:65), a 157 MB copy at 524 288 Gaussians) once, not per view
+        key = (gaussian_covariances[i].data_ptr(), gaussian_sh_coefficients[i].data_ptr())
+        if prev is None or prev[0] != key:
+            prev = (key, raster.cov6_from_cov3x3(gaussian_covariances[i]), gaussian_sh_coefficients[i].permute(0, 2, 1).contiguous())
+        cov6, shs = prev[1], prev[2]
         cam = raster.make_cam_k2(w2c[i], full[i], float(tan_x[i]), float(tan_y[i]), ext[i, :3, 3].tolist(),
                                  background_color[i].detach().float().cpu().tolist(), w, h, sh_degree=degree, sh_band4=sh_band4)
         out = raster.rasterize_k2(cam, means, cov6, shs, gaussian_opacities[i])
@@ -70,4 +75,6 @@ def render_cuda(extrinsics, intrinsics, near, far, image_shape, background_color
         depths.append(out["depth"])
         aux.append(out)
     res = (torch.stack(images), torch.stack(depths))
+    for out in aux:  # one synchronisation per call, after every view has been enqueued: the deferred pair-count check
+        out["state"]["D"]
     return res + (aux,) if return_aux else res

@@ -50,7 +50,7 @@ class SplattingCUDA:
             depth = torch.stack(depths)
         if render_qc_logits:
             height, width = image_shape
-            all_qc = []
+            all_qc, states = [], []
             for i in range(b):
                 means, opac = gaussians.means[i], gaussians.opacities[i]
                 cov6 = raster.cov6_from_cov3x3(gaussians.covariances[i])
@@ -66,9 +66,12 @@ class SplattingCUDA:
                     cam = raster.make_cam_k3(w2c, K[0, 0], K[1, 1], K[0, 2], K[1, 2], width, height, near_plane=near, far_plane=far)
                     out = raster.rasterize_k3(cam, means, cov6, opac, feats)
                     views.append(out["colors"])  # [h, w, q*c]
+                    states.append(out["state"])
                 stacked = torch.stack(views)  # [v, h, w, q*c]
                 # reference layout 'n h w (q c) -> n q c h w' as a view of the channel-last buffer
                 all_qc.append(stacked.view(v, height, width, q, c).permute(0, 3, 4, 1, 2))
+            for st_ in states:  # deferred pair-count check (one synchronisation, after the last view was enqueued)
+                st_["D"]
         return {"render_color": color, "render_depth": depth, "render_qc_logits": all_qc}
 
     __call__ = forward
@@ -137,5 +140,6 @@ def rasterize_splats(splats: dict, camtoworlds: torch.Tensor, Ks: torch.Tensor, 
         cols.append(o["colors"])
         alphas.append(o["alphas"][..., None])
         visible.append(o["state"]["tiles_touched"])
-        pairs.append(o["state"]["D"])
+        pairs.append(o["state"])
+    pairs = [st_["D"] for st_ in pairs]  # deferred pair-count read-back / overflow check, after the last view was enqueued
     return torch.stack(cols), torch.stack(alphas), dict(tiles_touched=visible, tile_pairs=pairs)

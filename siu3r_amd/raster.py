@@ -56,24 +56,47 @@ def cov6_from_cov3x3(cov: torch.Tensor) -> torch.Tensor:
     return torch.stack((cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]), dim=-1).contiguous()
 
 
-def _bin_and_sort(cam: RasterCam, means, cov6, opac, colors, channels):
+class _State(dict):
+    """Per-view binning state.  "D" (the number of (tile, Gaussian) pairs) lives on the device until someone asks for it:
+    reading it is the only host synchronisation of a rendered view, and it is deferred to the first access."""
+
+    def __getitem__(self, k):
+        if k == "D" and not dict.__contains__(self, "D"):
+            d = int(dict.__getitem__(self, "D_dev").item())
+            if d > dict.__getitem__(self, "cap"):
+                raise RuntimeError(f"rasterizer pair buffers overflowed: D = {d} > capacity {dict.__getitem__(self, 'cap')} "
+                                   f"(pass a larger pair_capacity)")
+            dict.__setitem__(self, "D", d)
+        return dict.__getitem__(self, k)
+
+
+def default_pair_capacity(G: int) -> int:
+    """Upper bound used to size the key / id buffers without reading the pair count back: 8 pairs per Gaussian (the 2 M-Gaussian
+    1080p stress scene needs 6.7), at least 1 M.  96 B per Gaussian of HBM in the worst case."""
+    return int(min(max(8 * G, 1 << 20), (1 << 31) - 1024))
+
+
+def _bin_and_sort(cam: RasterCam, means, cov6, opac, colors, channels, pair_capacity=None):
     G = means.shape[0]
     dev = means.device
     gw, gh = (cam.width + TILE - 1) // TILE, (cam.height + TILE - 1) // TILE
     T = gw * gh
+    cap = int(pair_capacity) if pair_capacity else default_pair_capacity(G)
     f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
-    st = dict(mean2d=f(G, 2), conic_op=f(G, 4), depth=f(G), radii=i32(G, 2), rect=i32(G, 4), tiles_touched=i32(G),
-              rgb=f(G, 3) if cam.mode == 0 else None, tile_count=i32(8 * T), tile_start=i32(T + 1), cursor=i32(8 * T))
+    st = _State(mean2d=f(G, 2), conic_op=f(G, 4), depth=f(G), radii=i32(G, 2), rect=i32(G, 4), tiles_touched=i32(G),
+                rgb=f(G, 3) if cam.mode == 0 else None, tile_count=i32(8 * T), tile_start=i32(T + 2), cursor=i32(8 * T), cap=cap)
     check(_lib.lib().siu3r_raster_bin(C.byref(cam), G, _p(means), _p(cov6), _p(opac), _p(colors), channels, _p(st["mean2d"]),
                                       _p(st["conic_op"]), _p(st["depth"]), _p(st["radii"]), _p(st["rect"]), _p(st["tiles_touched"]),
-                                      _p(st["rgb"]), _p(st["tile_count"]), _p(st["tile_start"]), _p(st["cursor"]), _stream()))
-    D = int(st["tile_start"][T].item())  # sizes the pair buffers (the CUDA originals resize their buffers the same way)
-    st["D"] = D
-    st["keys"] = torch.empty((max(D, 1),), dtype=torch.int64, device=dev)
-    st["ids"] = i32(max(D, 1))
+                                      _p(st["rgb"]), _p(st["tile_count"]), _p(st["tile_start"]), _p(st["cursor"]), cap, _stream()))
+    # no read-back of D here (the CUDA originals resize their buffers behind one): the buffers are sized by the bound above, the
+    # kernels clamp to it, and D is checked when it is first asked for (SplattingCUDA.forward does so once per call, after the
+    # last view has been enqueued)
+    st["D_dev"] = st["tile_start"][T + 1]
+    st["keys"] = torch.empty((cap,), dtype=torch.int64, device=dev)
+    st["ids"] = i32(cap)
     check(_lib.lib().siu3r_raster_sort(C.byref(cam), G, _p(st["rect"]), _p(st["depth"]), _p(st["tile_start"]), _p(st["cursor"]),
-                                       _p(st["keys"]), _p(st["ids"]), _stream()))
+                                       _p(st["keys"]), _p(st["ids"]), cap, _stream()))
     return st
 
 

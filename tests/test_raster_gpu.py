@@ -163,3 +163,23 @@ def test_viewer_render_semantics(degree):
     assert np.abs(alphas[0, ..., 0].cpu().numpy() - ref["alpha"]).max() <= 2e-6
     assert np.abs(colors[0].cpu().numpy() - want).max() <= 5e-6
     assert float(colors.min()) >= 0.0 and ref["D"] > 1000
+
+
+def test_pair_capacity_overflow_is_detected():
+    """The pair buffers are sized by a bound and D is read back late: an undersized bound must raise, never write out of bounds."""
+    from siu3r_amd import raster
+
+    G, H, W = 4000, 96, 128
+    means, cov, opac, sh = random_scene(G, seed=11, scale=(0.05, 0.2))
+    cam = _k3_cam(H, W, 2)
+    args = (cam, means.cuda(), raster.cov6_from_cov3x3(cov.cuda()), opac.cuda(), torch.rand(G, 5).cuda())
+    full = raster.rasterize_k3(*args)
+    D = full["state"]["D"]
+    assert D > 2000
+    st = raster._bin_and_sort(cam, args[1].contiguous(), args[2], args[3], None, 0, pair_capacity=D // 2)
+    torch.cuda.synchronize()
+    assert int(st["tile_start"][:-1].max()) <= D // 2          # every range was clamped to the capacity
+    with pytest.raises(RuntimeError, match="overflowed"):
+        st["D"]
+    exact = raster._bin_and_sort(cam, args[1].contiguous(), args[2], args[3], None, 0, pair_capacity=D)
+    assert exact["D"] == D and torch.equal(exact["ids"][:D], full["state"]["ids"][:D])
