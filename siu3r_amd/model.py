@@ -880,7 +880,9 @@ class SIU3RModel:
 
                 def capture(name, fn):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    # thread_local: only this thread's calls belong to the capture (a RCCL watchdog thread of a multi-GPU job
+                    # must not be able to invalidate it)
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         fn()
                     ent["graphs"][name] = g
 
