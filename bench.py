@@ -48,6 +48,7 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    local = local % torch.cuda.device_count()  # (lets a gloo dry run put two ranks on one GPU; one GPU per rank otherwise)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     H = W = args.size
@@ -63,7 +64,8 @@ def main():
         with torch.no_grad():
             return model(images, K, enable_query_class_logit_lift=True)
 
-    for _ in range(max(1, args.warmup)):
+    # untimed warm-up: at least 3 passes whatever W is (1st packs the weights eagerly, 2nd captures the HIP graphs, 3rd replays)
+    for _ in range(max(3, args.warmup)):
         out = step()
     model.release_source_weights()
     del sd
