@@ -42,7 +42,7 @@ def main():
     from siu3r_amd import distributed as D
     from siu3r_amd import ops
     from siu3r_amd.model import SIU3RModel
-    from oracle import weights as OW  # shared synthetic-weight generator (no checkpoint offline)
+    from siu3r_amd import synthetic_weights as OW  # shared synthetic-weight generator (no checkpoint offline)
 
     rank, local, world = D.init_from_env()
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"

@@ -53,7 +53,7 @@ def main():
         ck = torch.load(a.model_path, map_location="cpu", weights_only=False)
         sd = ck.get("state_dict", ck.get("model", ck))
     else:
-        from oracle import weights as OW  # synthetic stand-in weights (plumbing run)
+        from siu3r_amd import synthetic_weights as OW  # synthetic stand-in weights (plumbing run)
 
         print("no --model_path: using seeded synthetic weights (plumbing only)", file=sys.stderr)
         sd = OW.make_weights(0)

@@ -4,7 +4,7 @@ python tools/config5.py > gpurun_out/config5.json"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import weights as OW
+from siu3r_amd import synthetic_weights as OW
 from siu3r_amd import raster, synthetic
 from siu3r_amd.gaussian_renderer import SplattingCUDA, rasterize_splats
 from siu3r_amd.gaussians_types import Gaussians

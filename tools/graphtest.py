@@ -1,7 +1,7 @@
 import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from siu3r_amd.model import SIU3RModel
-from oracle import weights as OW
+from siu3r_amd import synthetic_weights as OW
 dev = torch.device("cuda", 0)
 sd = OW.make_weights(0)
 m = SIU3RModel(sd, image_size=(512, 512), precision="bf16", device=dev)

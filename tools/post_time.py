@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from siu3r_amd.model import SIU3RModel
 from siu3r_amd import postprocess as pp
-from oracle import weights as OW
+from siu3r_amd import synthetic_weights as OW
 dev = torch.device("cuda", 0)
 m = SIU3RModel(OW.make_weights(0), image_size=(512, 512), precision="bf16", device=dev)
 img = torch.rand(1, 2, 3, 512, 512).to(dev)

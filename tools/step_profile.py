@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from siu3r_amd import ops
 from siu3r_amd.model import SIU3RModel
-from oracle import weights as OW
+from siu3r_amd import synthetic_weights as OW
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
