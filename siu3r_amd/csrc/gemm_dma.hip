@@ -12,7 +12,7 @@
 //   * MODE 1 (3x3/1x1 convs with cin % 64 == 0): one filter tap per K tile, tracked by a scalar cursor, border validity
 //     as one bit test against a per-row tap mask;
 //   * the fused input ReLU is one v_pk_max_i16 per fragment dword and compiled in only where it is used.
-// MODE 2 (any cin % 8 == 0, e.g. the 7x7 stem) keeps per-lane tap arithmetic.
+// MODE 2 (any cin % 8 == 0, e.g. the 7x7 stem): per-lane tap state for the lane's two chunk columns, advanced without divisions.
 // The LDS image keeps gemm.hip's XOR swizzle: the DMA destination is lane-linear, so the permutation is applied
 // to the per-lane SOURCE address (cdna_hip_programming.md rule 21).  Same tiles, MFMA layout and epilogue as gemm.hip.
 #include <stdlib.h>
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
   // the lane fetches the LOGICAL chunk that the swizzle stores there.
   const int prow = lane >> 3, pchunk = lane & 7;
   const int cin = p.cin, iw = p.iw, ih = p.ih, kw = p.kw, kh = p.kh;
-  const int pad_bias = (MODE == 1) ? (p.pad * iw + p.pad) * cin * 2 : 0;  // keeps every per-row offset non-negative
+  const int pad_bias = (MODE != 0) ? (p.pad * iw + p.pad) * cin * 2 : 0;  // keeps every per-row offset non-negative
   __amdgpu_buffer_rsrc_t rA, rW;
   if (MODE == 0)
     rA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, (short)0, (int)(((int64_t)(M - 1) * p.lda + K) * 2), RSRC_FLAGS);
@@ -91,11 +91,10 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
     rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Ab - pad_bias), (short)0, (int)OOB, RSRC_FLAGS);
   rW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, (short)0, (int)((int64_t)N * kpad * 2), RSRC_FLAGS);
 
-  unsigned a_voff[A_DMA];          // MODE 0/1: byte offset of the lane's chunk at K-tile 0 / tap (0,0)
+  unsigned a_voff[A_DMA];          // byte offset of the lane's chunk at K-tile 0 / of the row's (iy0, ix0) pixel (conv, biased)
   unsigned a_mask[A_DMA];          // MODE 1: bit (ky*kw+kx) set <=> that tap is inside the image for this row
-  int a_c[A_DMA];                  // logical 8-element k-chunk fetched by this lane for piece i
-  const u16* a_ptr[A_DMA];         // MODE 2: image base of the row's batch item
-  int a_iy0[A_DMA], a_ix0[A_DMA];  // MODE 2
+  int a_c[A_DMA];                  // logical 8-element k-chunk fetched by this lane for piece i (a_c[i] == a_c[i & 1])
+  int a_iy0[A_DMA], a_ix0[A_DMA];  // MODE 2: top-left input pixel of the row
 #pragma unroll
   for (int i = 0; i < A_DMA; ++i) {
     const int r = (wave * A_DMA + i) * 8 + prow;
@@ -103,7 +102,6 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
     int m = tile_m * BM + r;
     if (m > M - 1) m = M - 1;  // rows beyond M: clamped, never stored
     a_voff[i] = a_mask[i] = 0;
-    a_ptr[i] = nullptr;
     a_iy0[i] = a_ix0[i] = 0;
     if (MODE == 0) {
       a_voff[i] = (unsigned)(((int64_t)m * p.lda + a_c[i] * 8) * 2);
@@ -120,7 +118,7 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
             if (iy0 + ky >= 0 && iy0 + ky < ih && ix0 + kx >= 0 && ix0 + kx < iw) mk |= 1u << (ky * kw + kx);
         a_mask[i] = mk;
       } else {
-        a_ptr[i] = Ab + (int64_t)b * ih * iw * cin;
+        a_voff[i] = (unsigned)((((b * ih + iy0) * iw + ix0) * cin) * 2 + pad_bias);
         a_iy0[i] = iy0;
         a_ix0[i] = ix0;
       }
@@ -154,6 +152,38 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
     }
   };
 
+  // MODE 2 (any cin % 8 == 0, e.g. the 7x7 stem with cin = 8): a lane fetches only two chunk columns of the K tile (a_c[0] for
+  // its even pieces, a_c[1] for the odd ones); for each it tracks (channel offset, kx, ky) of the NEXT tile to issue and advances
+  // them by 64 K elements with two conditional wraps -- no per-piece divisions (they cost ~300 VALU per K tile and wave)
+  int s_c0[2] = {0, 0}, s_kx[2] = {0, 0}, s_ky[2] = {0, 0};
+  int q64_r = 0, q64_qx = 0, q64_qy = 0;
+  if (MODE == 2) {
+    const int q64 = BK / cin;
+    q64_r = BK - q64 * cin;
+    q64_qy = q64 / kw;
+    q64_qx = q64 - q64_qy * kw;
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const int k0 = a_c[s_] * 8;
+      const int tap = k0 / cin;
+      s_c0[s_] = k0 - tap * cin;
+      s_ky[s_] = tap / kw;
+      s_kx[s_] = tap - s_ky[s_] * kw;
+    }
+  }
+  auto state_advance = [&]() {
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      s_c0[s_] += q64_r;
+      const int carry = s_c0[s_] >= cin ? 1 : 0;
+      s_c0[s_] -= carry * cin;
+      s_kx[s_] += q64_qx + carry;
+      const int wrap = s_kx[s_] >= kw ? 1 : 0;
+      s_kx[s_] -= wrap * kw;
+      s_ky[s_] += q64_qy + wrap;
+    }
+  };
+
   // one A piece (index i) and/or W pieces of K-tile kt into ring stage `stage`
   auto issue_a = [&](int kt, int stage, int i) {
     unsigned char* dst = smem + stage * STAGE_BYTES + (wave * A_DMA + i) * 1024;
@@ -165,12 +195,12 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
       const unsigned voff = (a_mask[i] & cur_bit) ? a_voff[i] : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, voff, cur_toff, 0, 0);
     } else {
-      const int k0 = kt * BK + a_c[i] * 8;
-      const int tap = k0 / cin, c0 = k0 - tap * cin;
-      const int ky = tap / kw, kx = tap - ky * kw;
+      const int s_ = i & 1;
+      const int ky = s_ky[s_], kx = s_kx[s_];
       const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-      const bool ok = k0 < K && iy >= 0 && iy < ih && ix >= 0 && ix < iw;
-      const unsigned voff = ok ? (unsigned)(((a_ptr[i] - Ab) + ((int64_t)iy * iw + ix) * cin + c0) * 2) : OOB;
+      // ky >= kh <=> the chunk lies in the zero-padded K tail
+      const bool ok = ky < kh && (unsigned)iy < (unsigned)ih && (unsigned)ix < (unsigned)iw;
+      const unsigned voff = ok ? a_voff[i] + (unsigned)(((ky * iw + kx) * cin + s_c0[s_]) * 2) : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, voff, 0, 0, 0);
     }
   };
@@ -184,6 +214,7 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
 #pragma unroll
     for (int i = 0; i < W_DMA; ++i) issue_w(kt, stage, i);
     if (MODE == 1) cursor_advance();
+    if (MODE == 2) state_advance();
   };
 
   f32x16 acc[2][NI];
@@ -340,6 +371,7 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
       __builtin_amdgcn_sched_barrier(0);
     }
     if (MODE == 1 && kt_next >= 0) cursor_advance();
+    if (MODE == 2 && kt_next >= 0) state_advance();
   };
 
   // ---- 3-stage ring, prefetch distance 2, one raw barrier per K-tile, counted vmcnt
