@@ -23,6 +23,7 @@ extern "C" {
 #define SIU3R_F32 1
 
 const char* siu3r_last_error(void);
+#define SIU3R_ABI_VERSION 2 /* 2: gemm_params.trace, attn_params.ws/splits, layernorm2, raster pair capacity, viewer helpers */
 int siu3r_abi_version(void);
 
 /* ---- seam 1: curope.rope_2d(tokens, positions, base, fwd)

@@ -67,6 +67,8 @@ class RasterCam(C.Structure):
 
 # name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/siu3r_hip.h.
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+ABI_VERSION = 2  # SIU3R_ABI_VERSION of include/siu3r_hip.h these ctypes declarations mirror
+
 SIGNATURES = {
     "siu3r_last_error": [],
     "siu3r_abi_version": [],
@@ -122,6 +124,9 @@ def lib():
         fn = getattr(l, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
+    if l.siu3r_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has ABI version {l.siu3r_abi_version()}, these bindings expect {ABI_VERSION}: rebuild it "
+                           f"(python -m siu3r_amd.build)")
     _lib = l
     return l
 

@@ -13,4 +13,4 @@ void siu3r_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* siu3r_last_error(void) { return g_err; }
-extern "C" int siu3r_abi_version(void) { return 1; }
+extern "C" int siu3r_abi_version(void) { return SIU3R_ABI_VERSION; }
