@@ -100,11 +100,14 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
     const int r = (wave * A_DMA + i) * 8 + prow;
     a_c[i] = pchunk ^ ((r >> 1) & 7);
     int m = tile_m * BM + r;
-    if (m > M - 1) m = M - 1;  // rows beyond M: clamped, never stored
+    // rows beyond M are never stored: their pieces are out-of-range fetches (zeros, no memory traffic) -- M = 2 x 1025 tokens
+    // leaves a 2-row seventeenth tile row whose workgroups then move a third of the bytes
+    const bool row_ok = m < M;
+    if (!row_ok) m = M - 1;
     a_voff[i] = a_mask[i] = 0;
     a_iy0[i] = a_ix0[i] = 0;
     if (MODE == 0) {
-      a_voff[i] = (unsigned)(((int64_t)m * p.lda + a_c[i] * 8) * 2);
+      a_voff[i] = row_ok ? (unsigned)(((int64_t)m * p.lda + a_c[i] * 8) * 2) : OOB;
     } else {
       const int ohw = p.oh * p.ow;
       const int b = m / ohw, rr = m - b * ohw;
@@ -116,10 +119,10 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
         for (int ky = 0; ky < kh; ++ky)
           for (int kx = 0; kx < kw; ++kx)
             if (iy0 + ky >= 0 && iy0 + ky < ih && ix0 + kx >= 0 && ix0 + kx < iw) mk |= 1u << (ky * kw + kx);
-        a_mask[i] = mk;
+        a_mask[i] = row_ok ? mk : 0u;
       } else {
         a_voff[i] = (unsigned)((((b * ih + iy0) * iw + ix0) * cin) * 2 + pad_bias);
-        a_iy0[i] = iy0;
+        a_iy0[i] = row_ok ? iy0 : -(1 << 20);  // fails every bounds test
         a_ix0[i] = ix0;
       }
     }
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
     unsigned char* dst = smem + stage * STAGE_BYTES + (wave * A_DMA + i) * 1024;
     if (MODE == 0) {
       unsigned voff = a_voff[i];
-      if (ktail && kt == nkt - 1) voff = (kt * BK + a_c[i] * 8 < K) ? voff : OOB;
+      if (ktail && kt == nkt - 1) voff = (kt * BK + a_c[i] * 8 < K) ? voff : OOB;  // (an out-of-range row stays out of range)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, voff, kt * (BK * 2), 0, 0);
     } else if (MODE == 1) {
       const unsigned voff = (a_mask[i] & cur_bit) ? a_voff[i] : OOB;
