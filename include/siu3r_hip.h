@@ -23,7 +23,7 @@ extern "C" {
 #define SIU3R_F32 1
 
 const char* siu3r_last_error(void);
-#define SIU3R_ABI_VERSION 2 /* 2: gemm_params.trace, attn_params.ws/splits, layernorm2, raster pair capacity, viewer helpers */
+#define SIU3R_ABI_VERSION 3 /* 3: view-batched sort-free rasterizer (project/sort/bin/composite/tile_lists), raster_cam.nt_post_blend */
 int siu3r_abi_version(void);
 
 /* ---- seam 1: curope.rope_2d(tokens, positions, base, fwd)
@@ -150,12 +150,15 @@ int siu3r_gaussian_adapter(const void* raw, int raw_dtype, float* opacities, flo
 int siu3r_m2f_attn_mask(const float* mask_logits, uint8_t* out, int32_t* row_counts_ws, int B, int T, int IH,
                         int IW, int OH, int OW, int Q, int64_t out_ld, void* stream);
 
-/* ---- Gaussian splat rasterizer (tile-binned).  Replaces the reference's two un-vendored CUDA dependencies at their
- * call sites: GaussianRasterizer(settings)(means3D, ..., cov3D_precomp, ...) -> (image, radii, depth, opacity,
- * n_touched) (reference src/models/cuda_splatting.py:90-118; mode 0) and gsplat.rasterization(means, covars,
- * opacities, colors[N,C], viewmats, Ks, width, height, near_plane, far_plane) -> (colors, alphas, meta)
- * (reference src/models/gaussian_renderer.py:92-106; mode 1).  One camera per call.  All constants of the published
- * algorithms are explicit parameters. */
+/* ---- Gaussian splat rasterizer (tile-binned, all views of a call in every launch).  Replaces the reference's two
+ * un-vendored CUDA dependencies at their call sites: GaussianRasterizer(settings)(means3D, ..., cov3D_precomp, ...) ->
+ * (image, radii, depth, opacity, n_touched) (reference src/models/cuda_splatting.py:90-118; mode 0) and
+ * gsplat.rasterization(means, covars, opacities, colors[N,C], viewmats, Ks, width, height, near_plane, far_plane) ->
+ * (colors, alphas, meta) (reference src/models/gaussian_renderer.py:92-106; mode 1).  The reference loops over the views in
+ * Python (cuda_splatting.py:82-121); here V cameras go in as one HOST array (copied to `cams_dev` on the stream) and
+ * blockIdx.y is the view.  All constants of the published algorithms are explicit parameters.
+ * Stages: project -> sort (one stable depth radix sort per view) -> bin (depth-ordered coarse bins of cb x cb tiles) ->
+ * composite_rgb (mode 0; walks the bins, no per-tile lists) | tile_lists + composite_feat (mode 1). */
 typedef struct {
   int32_t mode;        /* 0 = K2 (3DGS family), 1 = K3 (gsplat family) */
   int32_t width, height;
@@ -168,7 +171,7 @@ typedef struct {
   int32_t sh_band4;    /* K2: evaluate SH coefficients 16..24 (open question of the fork; default 0) */
   float k2_znear_cull; /* 0.2 */
   float fx, fy, cx, cy; /* K3: pixel-unit intrinsics */
-  float near_plane, far_plane;
+  float near_plane, far_plane; /* K3; near_plane must be > 0 (depth keys are the float bit patterns) */
   float eps2d;         /* 0.3 */
   float radius_clip;
   float extent_sigma;  /* 3.33 */
@@ -177,29 +180,42 @@ typedef struct {
   float alpha_max;     /* 0.99 (K2) / 0.999 (K3) */
   float t_min;         /* 1e-4 */
   float dilation;      /* K2 low-pass 0.3 */
+  int32_t nt_post_blend; /* K2 n_touched: count a pixel when the transmittance AFTER blending the Gaussian is > 0.5
+                            (1, the MonoGS fork's `test_T > 0.5f`) or the one before it (0) */
 } siu3r_raster_cam;
-/* stage 1+2: project G Gaussians (means [G,3], cov6 [G,6] upper-triangular, opacities [G], colors: mode 0 SH
- * [G,channels,3], mode 1 unused) and count/scan tiles.  Outputs: mean2d [G,2], conic_op [G,4], depth [G], radii [G,2]
- * i32, rect [G,4] i32, tiles_touched [G] i32, rgb [G,3] (mode 0), tile_count [8,T] (8 counter sets, see raster.hip), tile_start [T+2], cursor [8,T] i32.
- * cap = capacity (in pairs) of the keys/ids buffers handed to siu3r_raster_sort: tile_start[0..T] are clamped to it, tile_start[T+1]
- * holds the true pair count D, so the caller can size the buffers by an upper bound, enqueue the whole frame without reading D back,
- * and verify D <= cap afterwards (the CUDA originals resize their buffers behind a device-to-host copy instead).
- * tile_start[T] = min(D, cap). */
-int siu3r_raster_bin(const siu3r_raster_cam* cam, int64_t G, const float* means, const float* cov6,
-                     const float* opacities, const float* colors, int channels, float* mean2d, float* conic_op,
-                     float* depth, int32_t* radii, int32_t* rect, int32_t* tiles_touched, float* rgb, int32_t* tile_count,
-                     int32_t* tile_start, int32_t* cursor, int64_t cap, void* stream);
-/* stage 3+4: fill and sort the per-tile lists; keys [D] u64 (depth bits << 32 | id), ids [D] i32 (front to back) */
-int siu3r_raster_sort(const siu3r_raster_cam* cam, int64_t G, const int32_t* rect, const float* depth,
-                      const int32_t* tile_start, int32_t* cursor, uint64_t* keys, int32_t* ids, int64_t cap, void* stream);
-/* stage 5 (mode 0): image [3,H,W], depth [H,W], accumulated opacity [H,W], n_touched [G] i32 */
-int siu3r_raster_composite_rgb(const siu3r_raster_cam* cam, const int32_t* tile_start, const int32_t* ids,
-                               const float* mean2d, const float* conic_op, const float* depth, const float* rgb,
-                               float* image, float* out_depth, float* out_alpha, int32_t* n_touched, int64_t G, void* stream);
-/* stage 5 (mode 1): feats [G,channels] -> out [H,W,channels] (+ alphas [H,W]), 32 channels per pass */
-int siu3r_raster_composite_feat(const siu3r_raster_cam* cam, const int32_t* tile_start, const int32_t* ids,
-                                const float* mean2d, const float* conic_op, const float* feats, int channels, float* out,
-                                float* out_alpha, void* stream);
+/* frame geometry / workspace sizes: out8 = {gw, gh, T = tiles, cb = coarse-bin edge in tiles, NB = coarse bins,
+ * nchunks_sort (columns of rs_hist), nchunks_bin (columns of bin_hist), sizeof(siu3r_raster_cam)} */
+int siu3r_raster_geometry(int width, int height, int64_t G, int32_t* out8);
+/* stage 1: project G Gaussians (means [G,3], cov6 [G,6] upper-triangular, opacities [G], colors: mode 0 SH [G,channels,3],
+ * mode 1 unused; shared by the V views) for every view.  cams_host: V structs in HOST memory, copied to cams_dev (device,
+ * V * sizeof(siu3r_raster_cam) bytes) on the stream.  Outputs, all [V, G, ...]: mean2d [.,2], conic_op [.,4], depth, radii [.,2] i32,
+ * rect [.,4] i32 (tile rect [min,max)), tiles_touched i32, rgb [.,3] (mode 0), keys u32 (depth bits; 0xffffffff = culled).
+ * stats: u64 [V,4] = {visible Gaussians, tile pairs D, coarse entries E (stage 3), flags: bit 0 entries overflowed cap_e,
+ * bit 1 tile lists overflowed cap_d}; zeroed here. */
+int siu3r_raster_project(const siu3r_raster_cam* cams_host, int V, void* cams_dev, int64_t G, const float* means, const float* cov6,
+                         const float* opacities, const float* colors, int channels, float* mean2d, float* conic_op, float* depth,
+                         int32_t* radii, int32_t* rect, int32_t* tiles_touched, float* rgb, uint32_t* keys, uint64_t* stats, void* stream);
+/* stage 2: per view, stable LSD radix sort (4 x 8 bits) of keys_a [V,G] with the Gaussian index as payload; keys_b / ids_a / ids_b
+ * [V,G] ping-pong buffers; rs_hist i32 [V,256,nchunks_sort], rs_tot i32 [V,256].  Result (depth, id)-ordered in keys_a / ids_a. */
+int siu3r_raster_sort(int V, int64_t G, uint32_t* keys_a, uint32_t* keys_b, int32_t* ids_a, int32_t* ids_b, int32_t* rs_hist,
+                      int32_t* rs_tot, void* stream);
+/* stage 3: depth-ordered coarse bins.  bin_hist i32 [V,NB,nchunks_bin], bin_tot i32 [V,NB], bin_start i32 [V,NB+1] (out),
+ * entries: 8-byte records [V,cap_e] (Gaussian id, rect clipped to the bin).  Entries beyond cap_e are dropped and flagged in
+ * stats (the true count is stats[v][2]): size by a bound, enqueue the whole frame, check once afterwards. */
+int siu3r_raster_bin(const siu3r_raster_cam* cams_host, int V, int64_t G, const uint32_t* keys, const int32_t* ids, const int32_t* rect,
+                     int32_t* bin_hist, int32_t* bin_tot, int32_t* bin_start, void* entries, int64_t cap_e, uint64_t* stats, void* stream);
+/* stage 4 (mode 0): image [V,3,H,W], depth [V,H,W], accumulated opacity [V,H,W], n_touched [V,G] i32 (NULL = not wanted) */
+int siu3r_raster_composite_rgb(const siu3r_raster_cam* cams_host, int V, const void* cams_dev, int64_t G, const int32_t* bin_start,
+                               const void* entries, int64_t cap_e, const float* mean2d, const float* conic_op, const float* depth,
+                               const float* rgb, float* image, float* out_depth, float* out_alpha, int32_t* n_touched, void* stream);
+/* per-tile Gaussian lists, front to back (wave ballot + prefix popcount over the coarse bins): tile_count i32 [V,T] workspace,
+ * tile_start i32 [V,T+2] ([0..T] clamped to cap_d, [T+1] = true pair count), ids i32 [V,cap_d] */
+int siu3r_raster_tile_lists(const siu3r_raster_cam* cams_host, int V, const int32_t* bin_start, const void* entries, int64_t cap_e,
+                            int32_t* tile_count, int32_t* tile_start, int32_t* ids, int64_t cap_d, uint64_t* stats, void* stream);
+/* stage 4 (mode 1): feats [G,channels] -> out [V,H,W,channels] (+ alphas [V,H,W]), 32 channels per pass over the tile lists */
+int siu3r_raster_composite_feat(const siu3r_raster_cam* cams_host, int V, const void* cams_dev, int64_t G, const int32_t* tile_start,
+                                const int32_t* ids, int64_t cap_d, const float* mean2d, const float* conic_op, const float* feats,
+                                int channels, float* out, float* out_alpha, void* stream);
 /* x *= s in place (the reference rescales the scene x10 in place, src/models/gaussian_renderer.py:43-46) */
 int siu3r_scale_inplace(float* x, int64_t n, float s, void* stream);
 /* query-class-logit lifting (reference src/pipeline.py:137-193): rendered [V,H,W,q*C] -> sem_id, ins_id int64 [V,H,W];

@@ -48,6 +48,7 @@ typedef struct {
   float alpha_max;     /* 0.99 (K2) / 0.999 (K3) */
   float t_min;         /* 1e-4 */
   float dilation;      /* 0.3 (K2 low-pass) */
+  int32_t nt_post_blend; /* n_touched counts a pixel when the transmittance AFTER (1: `test_T > 0.5f`, MonoGS fork) or BEFORE (0) the blend is > 0.5 */
 } raster_cam;
 
 typedef struct {
@@ -313,7 +314,7 @@ int64_t raster_ref_forward(const raster_cam* c, int64_t G, const float* means, c
             for (int k = 0; k < 3; ++k) acc[k] += rgb[3 * g + k] * wgt;
             dacc += q->depth * wgt;
             oacc += wgt;
-            if (n_touched && Tr > 0.5f) {
+            if (n_touched && (c->nt_post_blend ? nT : Tr) > 0.5f) {
 #ifdef _OPENMP
 #pragma omp atomic
 #endif

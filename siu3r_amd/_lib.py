@@ -62,12 +62,13 @@ class RasterCam(C.Structure):
         ("near_plane", C.c_float), ("far_plane", C.c_float), ("eps2d", C.c_float), ("radius_clip", C.c_float),
         ("extent_sigma", C.c_float), ("opacity_aware_extent", C.c_int32),
         ("alpha_min", C.c_float), ("alpha_max", C.c_float), ("t_min", C.c_float), ("dilation", C.c_float),
+        ("nt_post_blend", C.c_int32),
     ]
 
 
 # name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/siu3r_hip.h.
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
-ABI_VERSION = 2  # SIU3R_ABI_VERSION of include/siu3r_hip.h these ctypes declarations mirror
+ABI_VERSION = 3  # SIU3R_ABI_VERSION of include/siu3r_hip.h these ctypes declarations mirror
 
 SIGNATURES = {
     "siu3r_last_error": [],
@@ -89,10 +90,13 @@ SIGNATURES = {
     "siu3r_gaussian_adapter": [_P, _I, _P, _P, _P, _P, _P, _L, _P],
     "siu3r_m2f_attn_mask": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "siu3r_split_bf16": [_P, _P, _P, _L, _I, _I, _L, _P],
-    "siu3r_raster_bin": [C.POINTER(RasterCam), _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
-    "siu3r_raster_sort": [C.POINTER(RasterCam), _L, _P, _P, _P, _P, _P, _P, _L, _P],
-    "siu3r_raster_composite_rgb": [C.POINTER(RasterCam), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
-    "siu3r_raster_composite_feat": [C.POINTER(RasterCam), _P, _P, _P, _P, _P, _I, _P, _P, _P],
+    "siu3r_raster_geometry": [_I, _I, _L, C.POINTER(C.c_int32)],
+    "siu3r_raster_project": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "siu3r_raster_sort": [_I, _L, _P, _P, _P, _P, _P, _P, _P],
+    "siu3r_raster_bin": [C.POINTER(RasterCam), _I, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
+    "siu3r_raster_composite_rgb": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "siu3r_raster_tile_lists": [C.POINTER(RasterCam), _I, _P, _P, _L, _P, _P, _P, _L, _P, _P],
+    "siu3r_raster_composite_feat": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _L, _P, _P, _P, _I, _P, _P, _P],
     "siu3r_scale_inplace": [_P, _L, _F, _P],
     "siu3r_quat_scale_to_cov6": [_P, _P, _P, _L, _P],
     "siu3r_sh_eval": [_P, _P, _P, _I, _I, _P, _L, _P],

@@ -5,15 +5,29 @@
 //                SH->RGB, colour + depth + accumulated opacity + radii + n_touched, pixel centres at integers
 //   mode 1 "K3": gsplat semantics (src/models/gaussian_renderer.py:92-106): N-channel features + alphas,
 //                near/far cull, eps2d, pixel centres at +0.5, channels rendered in chunks of 32
-// Pipeline (all on the caller's stream):
-//   project   one lane per Gaussian: EWA projection, extent, tile rect, SH->RGB; per-tile population counts with
-//             wavefront-aggregated atomics
-//   scan      exclusive scan of the tile counts (single workgroup, wave prefix sums via DPP/shuffles)
-//   fill      (depth, id) pairs appended to each touched tile's segment
-//   sort      one workgroup per tile: bitonic sort of the 64-bit keys (depth bits << 32 | Gaussian id) in LDS --
-//             unique keys, so the order (and hence every integer output) is deterministic run to run
-//   composite one 16x16 workgroup per tile: Gaussians staged through LDS in batches of 256, front-to-back alpha
-//             blend, wave-ballot early termination
+//
+// All V views of a call are processed by every launch (blockIdx.y = view; the cameras live in device memory).
+// There is NO per-(tile, Gaussian) atomic and NO per-tile sort:
+//   project     one lane per (view, Gaussian): EWA projection, extent, tile rect, SH->RGB, 32-bit depth key
+//               (0xffffffff = culled); per-view totals (visible count, tile pairs) via one atomic per workgroup
+//   depth sort  ONE stable LSD radix sort per view of the G depth keys (4 passes x 8 bits, payload = Gaussian id,
+//               initial order = id): afterwards the Gaussians of a view are in (depth, id) order -- exactly the
+//               order the published algorithm gives every tile list -- so no list ever needs sorting again.
+//               Stable placement inside a 256-key slice: every thread sets its bit in an LDS bit matrix
+//               [digit][256 bits]; its rank among equal digits = popcount of the bits below it
+//   coarse bins stable counting sort of the depth-ordered Gaussians into bins of cb x cb tiles (cb = 4: 64 x 64 px):
+//               per-workgroup LDS histograms -> [bin][chunk] table -> wave prefix scans -> placement with the same
+//               bit-matrix ranking (a Gaussian spanning several bins sets one bit per bin).  An entry is 8 bytes:
+//               Gaussian id + its tile rect clipped to the bin (4 x 5 bits)
+//   composite   (K2) one 16x16 workgroup per tile walks ITS bin's depth-ordered entries in slices of 256: each lane
+//               tests one entry's rect against the tile, a wave ballot + prefix popcount compacts the survivors into
+//               an LDS staging area (order preserved), and the pixels blend them front to back; a tile stops reading
+//               as soon as all its pixels are saturated.  The filter costs one lane-test per entry against ~10^3
+//               lane-instructions per blended pair, and the per-tile pair lists (D x 12 B written, sorted and read
+//               back in the published design) are never materialised.  n_touched: per-wave ballot -> one LDS add per
+//               (entry, wave) -> one global add per staged entry
+//   tile lists  (K3, and on request) the same ballot / prefix-popcount filter writes the per-tile id lists
+//               (tile_start + ids, front to back): gsplat semantics re-use one list for every 32-channel chunk
 // Arithmetic matches oracle/raster_ref.c operation for operation (same expression order, contraction off, and a
 // shared polynomial exp) so that integer outputs are bit-exact and the maps agree to fp32 rounding.
 #include "common.h"
@@ -21,17 +35,7 @@
 namespace {
 
 constexpr int TILE = 16;
-
-struct Cam {
-  int mode, width, height;
-  float w2c[16], proj[16];
-  float tanfovx, tanfovy, campos[3], bg[3];
-  int sh_degree, sh_band4;
-  float k2_znear_cull;
-  float fx, fy, cx, cy, near_plane, far_plane, eps2d, radius_clip, extent_sigma;
-  int opacity_aware_extent;
-  float alpha_min, alpha_max, t_min, dilation;
-};
+typedef siu3r_raster_cam Cam;
 
 // exp(x) for x <= 0 with plain fp32 operations only (identical in oracle/raster_ref.c): 2^(x*log2e), argument
 // reduced to [-0.5, 0.5], degree-7 Taylor of 2^f (|err| < 1e-7 rel), exact scaling by 2^n.
@@ -53,373 +57,545 @@ __device__ __forceinline__ float exp_det(float x) {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-constexpr int NPART = 8;  // counter sets of the binning atomics (see scan_kernel)
+// ---- frame geometry shared by host and device ------------------------------------------------------------------
+constexpr int NB_MAX = 1024;            // coarse bins per view (LDS: 40 B per bin in bin_scatter_kernel)
+constexpr int RS_ITEMS = 16, RS_CH = 256 * RS_ITEMS;  // radix sort: keys per workgroup
+constexpr int BN_ITEMS = 8, BN_CH = 256 * BN_ITEMS;   // coarse binning: sorted Gaussians per workgroup
+struct Geo {
+  int gw, gh, T, cb, nbx, nby, NB;
+};
+__host__ __device__ inline Geo make_geo(int width, int height) {
+  Geo g;
+  g.gw = (width + TILE - 1) / TILE;
+  g.gh = (height + TILE - 1) / TILE;
+  g.T = g.gw * g.gh;
+  g.cb = 4;
+  for (;;) {
+    g.nbx = (g.gw + g.cb - 1) / g.cb;
+    g.nby = (g.gh + g.cb - 1) / g.cb;
+    g.NB = g.nbx * g.nby;
+    if (g.NB <= NB_MAX || g.cb >= 16) break;
+    g.cb *= 2;
+  }
+  return g;
+}
+
 __constant__ float c_SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
 __constant__ float c_SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
 __constant__ float c_SH_C4[9] = {2.5033429417967046f, -1.7701307697799304f, 0.9461746957575601f, -0.6690465435572892f, 0.10578554691520431f, -0.6690465435572892f, 0.47308734787878004f, -1.7701307697799304f, 0.6258357354491761f};
 
-__global__ void project_kernel(Cam c, int64_t G, const float* means, const float* cov6, const float* opac,
-                               const float* colors, int channels, float* mean2d, float* conic_op, float* depth,
-                               int32_t* radii, int32_t* rect, int32_t* tiles_touched, float* rgb, int32_t* tile_count) {
+// stats[v] = {visible Gaussians, tile pairs D, coarse entries E, overflow flags}
+enum { ST_GV = 0, ST_D = 1, ST_E = 2, ST_FLAGS = 3, ST_N = 4 };
+
+__global__ __launch_bounds__(256) void project_kernel(const Cam* __restrict__ cams, int64_t G, const float* __restrict__ means,
+                                                      const float* __restrict__ cov6, const float* __restrict__ opac,
+                                                      const float* __restrict__ colors, int channels, float* __restrict__ mean2d,
+                                                      float* __restrict__ conic_op, float* __restrict__ depth, int32_t* __restrict__ radii,
+                                                      int32_t* __restrict__ rect, int32_t* __restrict__ tiles_touched, float* __restrict__ rgb,
+                                                      uint32_t* __restrict__ keys, unsigned long long* __restrict__ stats) {
+  const int v = blockIdx.y;
+  const Cam& c = cams[v];
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= G) return;
   const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
-  const float* V = c.w2c;
-  const float m0 = means[3 * g], m1 = means[3 * g + 1], m2 = means[3 * g + 2];
-  int rx_i = 0, ry_i = 0, tx0 = 0, ty0 = 0, tx1 = 0, ty1 = 0;
+  int ntiles = 0;
   bool valid = false;
-  float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
-  const float tx = V[0] * m0 + V[1] * m1 + V[2] * m2 + V[3];
-  const float ty = V[4] * m0 + V[5] * m1 + V[6] * m2 + V[7];
-  const float tz = V[8] * m0 + V[9] * m1 + V[10] * m2 + V[11];
-  const int gw = (c.width + TILE - 1) / TILE, gh = (c.height + TILE - 1) / TILE;
-  const float opacity = opac[g];
-  do {
-    float fx, fy;
-    if (c.mode == 0) {
-      if (tz <= c.k2_znear_cull) break;
-      fx = c.width / (2.0f * c.tanfovx);
-      fy = c.height / (2.0f * c.tanfovy);
-    } else {
-      if (tz < c.near_plane || tz > c.far_plane) break;
-      fx = c.fx;
-      fy = c.fy;
-    }
-    float limx_pos, limx_neg, limy_pos, limy_neg;
-    if (c.mode == 0) {
-      limx_pos = limx_neg = 1.3f * c.tanfovx;
-      limy_pos = limy_neg = 1.3f * c.tanfovy;
-    } else {
-      const float tfx = 0.5f * c.width / fx, tfy = 0.5f * c.height / fy;
-      limx_pos = (c.width - c.cx) / fx + 0.3f * tfx;
-      limx_neg = c.cx / fx + 0.3f * tfx;
-      limy_pos = (c.height - c.cy) / fy + 0.3f * tfy;
-      limy_neg = c.cy / fy + 0.3f * tfy;
-    }
-    const float rz = 1.0f / tz;
-    const float txz = tx * rz, tyz = ty * rz;
-    const float cxz = fminf(limx_pos, fmaxf(-limx_neg, txz)), cyz = fminf(limy_pos, fmaxf(-limy_neg, tyz));
-    const float ctx = cxz * tz, cty = cyz * tz;
-    const float j00 = fx * rz, j02 = -(fx * ctx) * rz * rz, j11 = fy * rz, j12 = -(fy * cty) * rz * rz;
-    const float m00 = j00 * V[0] + j02 * V[8], m01 = j00 * V[1] + j02 * V[9], m02 = j00 * V[2] + j02 * V[10];
-    const float m10 = j11 * V[4] + j12 * V[8], m11 = j11 * V[5] + j12 * V[9], m12 = j11 * V[6] + j12 * V[10];
-    const float sxx = cov6[6 * g], sxy = cov6[6 * g + 1], sxz = cov6[6 * g + 2], syy = cov6[6 * g + 3], syz = cov6[6 * g + 4], szz = cov6[6 * g + 5];
-    const float a0 = m00 * sxx + m01 * sxy + m02 * sxz, a1 = m00 * sxy + m01 * syy + m02 * syz, a2 = m00 * sxz + m01 * syz + m02 * szz;
-    const float b0 = m10 * sxx + m11 * sxy + m12 * sxz, b1 = m10 * sxy + m11 * syy + m12 * syz, b2 = m10 * sxz + m11 * syz + m12 * szz;
-    float c00 = a0 * m00 + a1 * m01 + a2 * m02;
-    const float c01 = a0 * m10 + a1 * m11 + a2 * m12;
-    float c11 = b0 * m10 + b1 * m11 + b2 * m12;
-    const float blur = c.mode == 0 ? c.dilation : c.eps2d;
-    c00 += blur;
-    c11 += blur;
-    const float det = c00 * c11 - c01 * c01;
-    if (c.mode == 0 ? (det == 0.0f) : (det <= 0.0f)) break;
-    const float det_inv = 1.0f / det;
-    ca = c11 * det_inv;
-    cb = -c01 * det_inv;
-    cc = c00 * det_inv;
-    if (c.mode == 0) {
-      const float* P = c.proj;
-      const float hx = P[0] * m0 + P[1] * m1 + P[2] * m2 + P[3];
-      const float hy = P[4] * m0 + P[5] * m1 + P[6] * m2 + P[7];
-      const float hw = P[12] * m0 + P[13] * m1 + P[14] * m2 + P[15];
-      const float pw = 1.0f / (hw + 0.0000001f);
-      mx = ((hx * pw + 1.0f) * c.width - 1.0f) * 0.5f;
-      my = ((hy * pw + 1.0f) * c.height - 1.0f) * 0.5f;
-      const float mid = 0.5f * (c00 + c11);
-      const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
-      const float lam2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
-      const int rad = (int)ceilf(3.0f * sqrtf(fmaxf(lam, lam2)));
-      rx_i = ry_i = rad;
-      tx0 = clampi((int)((mx - rad) / TILE), 0, gw);
-      ty0 = clampi((int)((my - rad) / TILE), 0, gh);
-      tx1 = clampi((int)((mx + rad + TILE - 1) / TILE), 0, gw);
-      ty1 = clampi((int)((my + rad + TILE - 1) / TILE), 0, gh);
-    } else {
-      mx = fx * txz + c.cx;
-      my = fy * tyz + c.cy;
-      float extend = c.extent_sigma;
-      if (c.opacity_aware_extent) {
-        if (opacity < c.alpha_min) break;
-        extend = fminf(extend, sqrtf(2.0f * logf(opacity / c.alpha_min)));
+  if (g < G) {
+    const int64_t o = (int64_t)v * G + g;
+    const float* V = c.w2c;
+    const float m0 = means[3 * g], m1 = means[3 * g + 1], m2 = means[3 * g + 2];
+    int rx_i = 0, ry_i = 0, tx0 = 0, ty0 = 0, tx1 = 0, ty1 = 0;
+    float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
+    const float tx = V[0] * m0 + V[1] * m1 + V[2] * m2 + V[3];
+    const float ty = V[4] * m0 + V[5] * m1 + V[6] * m2 + V[7];
+    const float tz = V[8] * m0 + V[9] * m1 + V[10] * m2 + V[11];
+    const int gw = (c.width + TILE - 1) / TILE, gh = (c.height + TILE - 1) / TILE;
+    const float opacity = opac[g];
+    do {
+      float fx, fy;
+      if (c.mode == 0) {
+        if (tz <= c.k2_znear_cull) break;
+        fx = c.width / (2.0f * c.tanfovx);
+        fy = c.height / (2.0f * c.tanfovy);
+      } else {
+        if (tz < c.near_plane || tz > c.far_plane) break;
+        fx = c.fx;
+        fy = c.fy;
       }
-      const float rx = ceilf(extend * sqrtf(c00)), ry = ceilf(extend * sqrtf(c11));
-      if (rx <= c.radius_clip && ry <= c.radius_clip) break;
-      if (mx + rx <= 0 || mx - rx >= c.width || my + ry <= 0 || my - ry >= c.height) break;
-      rx_i = (int)rx;
-      ry_i = (int)ry;
-      tx0 = clampi((int)floorf((mx - rx) / TILE), 0, gw);
-      ty0 = clampi((int)floorf((my - ry) / TILE), 0, gh);
-      tx1 = clampi((int)ceilf((mx + rx) / TILE), 0, gw);
-      ty1 = clampi((int)ceilf((my + ry) / TILE), 0, gh);
-    }
-    if ((tx1 - tx0) * (ty1 - ty0) == 0) {
-      if (c.mode == 0) rx_i = ry_i = 0;
-      break;
-    }
-    valid = true;
-  } while (false);
-  radii[2 * g] = rx_i;
-  radii[2 * g + 1] = ry_i;
-  tiles_touched[g] = valid ? (tx1 - tx0) * (ty1 - ty0) : 0;
-  rect[4 * g] = valid ? tx0 : 0;
-  rect[4 * g + 1] = valid ? ty0 : 0;
-  rect[4 * g + 2] = valid ? tx1 : 0;
-  rect[4 * g + 3] = valid ? ty1 : 0;
-  mean2d[2 * g] = mx;
-  mean2d[2 * g + 1] = my;
-  conic_op[4 * g] = ca;
-  conic_op[4 * g + 1] = cb;
-  conic_op[4 * g + 2] = cc;
-  conic_op[4 * g + 3] = opacity;
-  depth[g] = tz;
-  if (!valid) return;
-  if (c.mode == 0) {
-    const float dx = m0 - c.campos[0], dy = m1 - c.campos[1], dz = m2 - c.campos[2];
-    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-    const float x = dx * inv, y = dy * inv, z = dz * inv;
-    const int deg = c.sh_degree;
-    // the Gaussian's coefficient block ([coef][rgb], 12 B per coefficient, 4-byte aligned) as 16-byte loads: a lane's
-    // block is contiguous, so 12 (19 with band 4) wide loads replace 48 (75) scalar ones that each touched 64 cache lines
-    struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
-    const float* shp = colors + (size_t)g * channels * 3;
-    float sh[76];
-    const int nf = ((deg > 3 && c.sh_band4) ? 25 : (deg > 2 ? 16 : (deg > 1 ? 9 : (deg > 0 ? 4 : 1)))) * 3;
-#pragma unroll
-    for (int q = 0; q < 19; ++q) {
-      if (4 * q < nf) {
-        if (4 * q + 4 <= channels * 3) {
-          const f4u t4 = *(const f4u*)(shp + 4 * q);
-          sh[4 * q] = t4.v[0]; sh[4 * q + 1] = t4.v[1]; sh[4 * q + 2] = t4.v[2]; sh[4 * q + 3] = t4.v[3];
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sh[4 * q + e] = (4 * q + e < channels * 3) ? shp[4 * q + e] : 0.f;
+      float limx_pos, limx_neg, limy_pos, limy_neg;
+      if (c.mode == 0) {
+        limx_pos = limx_neg = 1.3f * c.tanfovx;
+        limy_pos = limy_neg = 1.3f * c.tanfovy;
+      } else {
+        const float tfx = 0.5f * c.width / fx, tfy = 0.5f * c.height / fy;
+        limx_pos = (c.width - c.cx) / fx + 0.3f * tfx;
+        limx_neg = c.cx / fx + 0.3f * tfx;
+        limy_pos = (c.height - c.cy) / fy + 0.3f * tfy;
+        limy_neg = c.cy / fy + 0.3f * tfy;
+      }
+      const float rz = 1.0f / tz;
+      const float txz = tx * rz, tyz = ty * rz;
+      const float cxz = fminf(limx_pos, fmaxf(-limx_neg, txz)), cyz = fminf(limy_pos, fmaxf(-limy_neg, tyz));
+      const float ctx = cxz * tz, cty = cyz * tz;
+      const float j00 = fx * rz, j02 = -(fx * ctx) * rz * rz, j11 = fy * rz, j12 = -(fy * cty) * rz * rz;
+      const float m00 = j00 * V[0] + j02 * V[8], m01 = j00 * V[1] + j02 * V[9], m02 = j00 * V[2] + j02 * V[10];
+      const float m10 = j11 * V[4] + j12 * V[8], m11 = j11 * V[5] + j12 * V[9], m12 = j11 * V[6] + j12 * V[10];
+      const float sxx = cov6[6 * g], sxy = cov6[6 * g + 1], sxz = cov6[6 * g + 2], syy = cov6[6 * g + 3], syz = cov6[6 * g + 4], szz = cov6[6 * g + 5];
+      const float a0 = m00 * sxx + m01 * sxy + m02 * sxz, a1 = m00 * sxy + m01 * syy + m02 * syz, a2 = m00 * sxz + m01 * syz + m02 * szz;
+      const float b0 = m10 * sxx + m11 * sxy + m12 * sxz, b1 = m10 * sxy + m11 * syy + m12 * syz, b2 = m10 * sxz + m11 * syz + m12 * szz;
+      float c00 = a0 * m00 + a1 * m01 + a2 * m02;
+      const float c01 = a0 * m10 + a1 * m11 + a2 * m12;
+      float c11 = b0 * m10 + b1 * m11 + b2 * m12;
+      const float blur = c.mode == 0 ? c.dilation : c.eps2d;
+      c00 += blur;
+      c11 += blur;
+      const float det = c00 * c11 - c01 * c01;
+      if (c.mode == 0 ? (det == 0.0f) : (det <= 0.0f)) break;
+      const float det_inv = 1.0f / det;
+      ca = c11 * det_inv;
+      cb = -c01 * det_inv;
+      cc = c00 * det_inv;
+      if (c.mode == 0) {
+        const float* P = c.proj;
+        const float hx = P[0] * m0 + P[1] * m1 + P[2] * m2 + P[3];
+        const float hy = P[4] * m0 + P[5] * m1 + P[6] * m2 + P[7];
+        const float hw = P[12] * m0 + P[13] * m1 + P[14] * m2 + P[15];
+        const float pw = 1.0f / (hw + 0.0000001f);
+        mx = ((hx * pw + 1.0f) * c.width - 1.0f) * 0.5f;
+        my = ((hy * pw + 1.0f) * c.height - 1.0f) * 0.5f;
+        const float mid = 0.5f * (c00 + c11);
+        const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float lam2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+        const int rad = (int)ceilf(3.0f * sqrtf(fmaxf(lam, lam2)));
+        rx_i = ry_i = rad;
+        tx0 = clampi((int)((mx - rad) / TILE), 0, gw);
+        ty0 = clampi((int)((my - rad) / TILE), 0, gh);
+        tx1 = clampi((int)((mx + rad + TILE - 1) / TILE), 0, gw);
+        ty1 = clampi((int)((my + rad + TILE - 1) / TILE), 0, gh);
+      } else {
+        mx = fx * txz + c.cx;
+        my = fy * tyz + c.cy;
+        float extend = c.extent_sigma;
+        if (c.opacity_aware_extent) {
+          if (opacity < c.alpha_min) break;
+          extend = fminf(extend, sqrtf(2.0f * logf(opacity / c.alpha_min)));
         }
+        const float rx = ceilf(extend * sqrtf(c00)), ry = ceilf(extend * sqrtf(c11));
+        if (rx <= c.radius_clip && ry <= c.radius_clip) break;
+        if (mx + rx <= 0 || mx - rx >= c.width || my + ry <= 0 || my - ry >= c.height) break;
+        rx_i = (int)rx;
+        ry_i = (int)ry;
+        tx0 = clampi((int)floorf((mx - rx) / TILE), 0, gw);
+        ty0 = clampi((int)floorf((my - ry) / TILE), 0, gh);
+        tx1 = clampi((int)ceilf((mx + rx) / TILE), 0, gw);
+        ty1 = clampi((int)ceilf((my + ry) / TILE), 0, gh);
       }
-    }
+      if ((tx1 - tx0) * (ty1 - ty0) == 0) {
+        if (c.mode == 0) rx_i = ry_i = 0;
+        break;
+      }
+      valid = true;
+    } while (false);
+    ntiles = valid ? (tx1 - tx0) * (ty1 - ty0) : 0;
+    radii[2 * o] = rx_i;
+    radii[2 * o + 1] = ry_i;
+    tiles_touched[o] = ntiles;
+    *(int4*)(rect + 4 * o) = valid ? make_int4(tx0, ty0, tx1, ty1) : make_int4(0, 0, 0, 0);
+    *(float2*)(mean2d + 2 * o) = make_float2(mx, my);
+    *(float4*)(conic_op + 4 * o) = make_float4(ca, cb, cc, opacity);
+    depth[o] = tz;
+    // positive floats order like their bit patterns; culled Gaussians sort behind every visible one
+    keys[o] = valid ? __float_as_uint(tz) : 0xffffffffu;
+    if (valid && c.mode == 0) {
+      const float dx = m0 - c.campos[0], dy = m1 - c.campos[1], dz = m2 - c.campos[2];
+      const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+      const float x = dx * inv, y = dy * inv, z = dz * inv;
+      const int deg = c.sh_degree;
+      // the Gaussian's coefficient block ([coef][rgb], 12 B per coefficient, 4-byte aligned) as 16-byte loads: a lane's
+      // block is contiguous, so 12 (19 with band 4) wide loads replace 48 (75) scalar ones that each touched 64 cache lines
+      struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
+      const float* shp = colors + (size_t)g * channels * 3;
+      float sh[76];
+      const int nf = ((deg > 3 && c.sh_band4) ? 25 : (deg > 2 ? 16 : (deg > 1 ? 9 : (deg > 0 ? 4 : 1)))) * 3;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-#define S(i) sh[(i) * 3 + ch]
-      float r = SH_C0 * S(0);
-      if (deg > 0) {
-        r = r - SH_C1 * y * S(1) + SH_C1 * z * S(2) - SH_C1 * x * S(3);
-        if (deg > 1) {
-          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-          r = r + c_SH_C2[0] * xy * S(4) + c_SH_C2[1] * yz * S(5) + c_SH_C2[2] * (2.0f * zz - xx - yy) * S(6) + c_SH_C2[3] * xz * S(7) + c_SH_C2[4] * (xx - yy) * S(8);
-          if (deg > 2) {
-            r = r + c_SH_C3[0] * y * (3.0f * xx - yy) * S(9) + c_SH_C3[1] * xy * z * S(10) + c_SH_C3[2] * y * (4.0f * zz - xx - yy) * S(11) +
-                c_SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * S(12) + c_SH_C3[4] * x * (4.0f * zz - xx - yy) * S(13) +
-                c_SH_C3[5] * z * (xx - yy) * S(14) + c_SH_C3[6] * x * (xx - 3.0f * yy) * S(15);
-            if (deg > 3 && c.sh_band4) {
-              r = r + c_SH_C4[0] * xy * (xx - yy) * S(16) + c_SH_C4[1] * yz * (3.0f * xx - yy) * S(17) + c_SH_C4[2] * xy * (7.0f * zz - 1.0f) * S(18) +
-                  c_SH_C4[3] * yz * (7.0f * zz - 3.0f) * S(19) + c_SH_C4[4] * (zz * (35.0f * zz - 30.0f) + 3.0f) * S(20) +
-                  c_SH_C4[5] * xz * (7.0f * zz - 3.0f) * S(21) + c_SH_C4[6] * (xx - yy) * (7.0f * zz - 1.0f) * S(22) +
-                  c_SH_C4[7] * xz * (xx - 3.0f * yy) * S(23) + c_SH_C4[8] * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy)) * S(24);
-            }
+      for (int q = 0; q < 19; ++q) {
+        if (4 * q < nf) {
+          if (4 * q + 4 <= channels * 3) {
+            const f4u t4 = *(const f4u*)(shp + 4 * q);
+            sh[4 * q] = t4.v[0]; sh[4 * q + 1] = t4.v[1]; sh[4 * q + 2] = t4.v[2]; sh[4 * q + 3] = t4.v[3];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sh[4 * q + e] = (4 * q + e < channels * 3) ? shp[4 * q + e] : 0.f;
           }
         }
       }
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+#define S(i) sh[(i) * 3 + ch]
+        float r = SH_C0 * S(0);
+        if (deg > 0) {
+          r = r - SH_C1 * y * S(1) + SH_C1 * z * S(2) - SH_C1 * x * S(3);
+          if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            r = r + c_SH_C2[0] * xy * S(4) + c_SH_C2[1] * yz * S(5) + c_SH_C2[2] * (2.0f * zz - xx - yy) * S(6) + c_SH_C2[3] * xz * S(7) + c_SH_C2[4] * (xx - yy) * S(8);
+            if (deg > 2) {
+              r = r + c_SH_C3[0] * y * (3.0f * xx - yy) * S(9) + c_SH_C3[1] * xy * z * S(10) + c_SH_C3[2] * y * (4.0f * zz - xx - yy) * S(11) +
+                  c_SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * S(12) + c_SH_C3[4] * x * (4.0f * zz - xx - yy) * S(13) +
+                  c_SH_C3[5] * z * (xx - yy) * S(14) + c_SH_C3[6] * x * (xx - 3.0f * yy) * S(15);
+              if (deg > 3 && c.sh_band4) {
+                r = r + c_SH_C4[0] * xy * (xx - yy) * S(16) + c_SH_C4[1] * yz * (3.0f * xx - yy) * S(17) + c_SH_C4[2] * xy * (7.0f * zz - 1.0f) * S(18) +
+                    c_SH_C4[3] * yz * (7.0f * zz - 3.0f) * S(19) + c_SH_C4[4] * (zz * (35.0f * zz - 30.0f) + 3.0f) * S(20) +
+                    c_SH_C4[5] * xz * (7.0f * zz - 3.0f) * S(21) + c_SH_C4[6] * (xx - yy) * (7.0f * zz - 1.0f) * S(22) +
+                    c_SH_C4[7] * xz * (xx - 3.0f * yy) * S(23) + c_SH_C4[8] * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy)) * S(24);
+              }
+            }
+          }
+        }
 #undef S
-      r += 0.5f;
-      rgb[3 * g + ch] = r < 0.0f ? 0.0f : r;
+        r += 0.5f;
+        rgb[3 * o + ch] = r < 0.0f ? 0.0f : r;
+      }
     }
   }
-  for (int ty_ = ty0; ty_ < ty1; ++ty_)
-    for (int tx_ = tx0; tx_ < tx1; ++tx_)
-      atomicAdd(&tile_count[(blockIdx.x & (NPART - 1)) * (gw * gh) + ty_ * gw + tx_], 1);  // one of NPART counter sets: see scan_kernel
+  // per-view totals: wave reduction, then one atomic pair per workgroup
+  __shared__ int s_cnt[4], s_pairs[4];
+  int cnt = valid ? 1 : 0, pairs = ntiles;
+#pragma unroll
+  for (int o_ = 32; o_ > 0; o_ >>= 1) {
+    cnt += __shfl_xor(cnt, o_);
+    pairs += __shfl_xor(pairs, o_);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    s_cnt[wave] = cnt;
+    s_pairs[wave] = pairs;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int c4 = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    const long long p4 = (long long)s_pairs[0] + s_pairs[1] + s_pairs[2] + s_pairs[3];
+    if (c4) atomicAdd(&stats[v * ST_N + ST_GV], (unsigned long long)c4);
+    if (p4) atomicAdd(&stats[v * ST_N + ST_D], (unsigned long long)p4);
+  }
 }
 
-// The per-tile counters are hot addresses (a 1080p frame has 8160 of them for ~14 M (Gaussian, tile) pairs): device-scope atomics on
-// one address serialise.  Workgroup b of project_kernel / fill_kernel therefore uses counter set b % NPART; the sets are summed here,
-// and set c of a tile gets the cursor base tile_start + (count of sets < c), so every pair still lands in its tile's range.  Which
-// workgroup a Gaussian belongs to is the same in both kernels (same grid), and the per-tile sort makes the final order independent
-// of the partition.
-// exclusive scan of sum_c tile_count[c][T] -> tile_start[T+1], cursor[c][T]; single workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void scan_kernel(const int32_t* tile_count, int32_t* tile_start, int32_t* cursor, int T, int cap) {
-  __shared__ int32_t wsum[16];
-  __shared__ int32_t carry;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (t == 0) carry = 0;
+// ---- stable LSD radix sort of the depth keys (per view) --------------------------------------------------------
+// hist[(v * 256 + digit) * nchunks + chunk]: digit-major, so that the scan below reads rows
+__global__ __launch_bounds__(256) void rs_hist_kernel(const uint32_t* __restrict__ keys, int32_t* __restrict__ hist, int64_t G, int shift, int nchunks) {
+  __shared__ int h[256];
+  const int v = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+  h[t] = 0;
   __syncthreads();
-  for (int base = 0; base < T; base += 1024) {
-    const int i = base + t;
-    int cnt[NPART];
-    int v = 0;
+  const uint32_t* kp = keys + (int64_t)v * G;
 #pragma unroll
-    for (int c = 0; c < NPART; ++c) {
-      cnt[c] = i < T ? tile_count[c * T + i] : 0;
-      v += cnt[c];
-    }
-    int incl = v;
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const int64_t idx = (int64_t)chunk * RS_CH + i * 256 + t;
+    if (idx < G) atomicAdd(&h[(kp[idx] >> shift) & 255u], 1);
+  }
+  __syncthreads();
+  hist[((int64_t)v * 256 + t) * nchunks + chunk] = h[t];
+}
+
+// in-place exclusive scan of every row of a [V * nrows, ncols] table; one wave per row; row totals -> tot
+__global__ __launch_bounds__(256) void row_scan_kernel(int32_t* __restrict__ tab, int32_t* __restrict__ tot, int nrows, int ncols) {
+  const int v = blockIdx.y, lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  int32_t* p = tab + ((int64_t)v * nrows + row) * ncols;
+  int carry = 0;
+  for (int base = 0; base < ncols; base += 64) {
+    const int i = base + lane;
+    const int x = i < ncols ? p[i] : 0;
+    int incl = x;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int n = __shfl_up(incl, o);
       if (lane >= o) incl += n;
     }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wsum[w];
-    const int excl = carry + woff + incl - v;
-    if (i < T) {
-      tile_start[i] = min(excl, cap);  // ranges are clamped to the pair buffers' capacity (see siu3r_raster_bin)
-      int run = excl;
+    if (i < ncols) p[i] = carry + incl - x;
+    carry += __shfl(incl, 63);
+  }
+  if (lane == 0) tot[(int64_t)v * nrows + row] = carry;
+}
+
+// popcount of the bits of a 256-bit LDS row strictly below position t, and of the whole row
+__device__ __forceinline__ void row_rank(const uint32_t* row, int t, int& rank, int& total) {
+  const uint4 a = *(const uint4*)row, b = *(const uint4*)(row + 4);
+  const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  const int wi = t >> 5;
+  const uint32_t low = (1u << (t & 31)) - 1u;
+  rank = 0;
+  total = 0;
 #pragma unroll
-      for (int c = 0; c < NPART; ++c) {
-        cursor[c * T + i] = run;
-        run += cnt[c];
-      }
-    }
-    __syncthreads();
-    if (t == 1023) carry = excl + v;
-    __syncthreads();
-  }
-  if (t == 0) {
-    tile_start[T] = min(carry, cap);
-    tile_start[T + 1] = carry;  // the true pair count: the host compares it with cap after the frame has been enqueued
+  for (int i = 0; i < 8; ++i) {
+    const int pc = __popc(w[i]);
+    total += pc;
+    rank += i < wi ? pc : (i == wi ? __popc(w[i] & low) : 0);
   }
 }
 
-__global__ void fill_kernel(int64_t G, const int32_t* rect, const float* depth, int32_t* cursor, uint64_t* keys, int gw, int T, int cap) {
-  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= G) return;
-  const int tx0 = rect[4 * g], ty0 = rect[4 * g + 1], tx1 = rect[4 * g + 2], ty1 = rect[4 * g + 3];
-  if (tx1 <= tx0 || ty1 <= ty0) return;
-  const uint64_t key = ((uint64_t)__float_as_uint(depth[g]) << 32) | (uint32_t)g;
-  for (int ty = ty0; ty < ty1; ++ty)
-    for (int tx = tx0; tx < tx1; ++tx) {
-      const int pos = atomicAdd(&cursor[(blockIdx.x & (NPART - 1)) * T + ty * gw + tx], 1);
-      if (pos < cap) keys[pos] = key;
-    }
+// block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix, total in *tot
+__device__ __forceinline__ int block_excl_scan(int x, int* s_w, int* tot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = x;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int n = __shfl_up(incl, o);
+    if (lane >= o) incl += n;
+  }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  int off = 0;
+  for (int w = 0; w < wave; ++w) off += s_w[w];
+  if (tot) *tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  __syncthreads();
+  return off + incl - x;
 }
 
-// One workgroup per tile: bitonic sort of the tile's (depth bits << 32 | id) keys in LDS.  Three instantiations by
-// capacity (a tile is handled by the smallest one that holds its padded length): small tiles get small LDS footprints
-// and therefore many resident workgroups.  Every thread is busy in every pass, and two butterfly stages (strides j and
-// j/2) are done per LDS round trip on four keys held in registers: half the LDS traffic and barriers of the textbook
-// loop.  Tiles beyond 8192 keys fall back to an in-place global-memory bitonic (rare).
-constexpr int SORT_CAP = 8192;  // 64 KiB of LDS
-__device__ __forceinline__ void cmpx(uint64_t& a, uint64_t& b, bool up) {
-  if ((a > b) == up) {
-    const uint64_t t = a;
-    a = b;
-    b = t;
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in, const int32_t* __restrict__ ids_in,
+                                                         uint32_t* __restrict__ keys_out, int32_t* __restrict__ ids_out,
+                                                         const int32_t* __restrict__ hist, const int32_t* __restrict__ tot, int64_t G, int shift,
+                                                         int nchunks) {
+  __shared__ __attribute__((aligned(16))) uint32_t M[256 * 8];
+  __shared__ int base[256];
+  __shared__ int s_w[4];
+  const int v = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+  // start of digit t in the output = digits below + this digit's keys in earlier chunks
+  const int ex = block_excl_scan(tot[v * 256 + t], s_w, nullptr);
+  base[t] = ex + hist[((int64_t)v * 256 + t) * nchunks + chunk];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) M[t * 8 + i] = 0;
+  const uint32_t* kp = keys_in + (int64_t)v * G;
+  const int32_t* ip = ids_in ? ids_in + (int64_t)v * G : nullptr;
+  uint32_t key[RS_ITEMS];
+  int32_t id[RS_ITEMS];
+#pragma unroll
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const int64_t idx = (int64_t)chunk * RS_CH + i * 256 + t;
+    key[i] = idx < G ? kp[idx] : 0u;
+    id[i] = idx < G ? (ip ? ip[idx] : (int32_t)idx) : 0;
   }
-}
-template <int CAP, int CAP_PREV>
-__global__ __launch_bounds__(256) void sort_kernel(const int32_t* tile_start, uint64_t* keys, int32_t* ids) {
-  __shared__ uint64_t s[CAP];
-  const int tile = blockIdx.x;
-  const int beg = tile_start[tile], n = tile_start[tile + 1] - beg;
-  if (n <= 0) return;
-  int np = 1, lg = 0;
-  while (np < n) {
-    np <<= 1;
-    ++lg;
-  }
-  if (np <= CAP_PREV) return;  // a smaller instantiation owns this tile
-  if (np <= CAP) {
-    for (int i = threadIdx.x; i < np; i += 256) s[i] = i < n ? keys[beg + i] : ~0ull;
+  __syncthreads();
+  const int wi = t >> 5;
+  const uint32_t bit = 1u << (t & 31);
+#pragma unroll
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const int64_t idx = (int64_t)chunk * RS_CH + i * 256 + t;
+    const bool ok = idx < G;
+    const int d = (key[i] >> shift) & 255u;
+    if (ok) atomicOr(&M[d * 8 + wi], bit);
     __syncthreads();
-    for (int lk = 1; lk <= lg; ++lk) {       // merge width k = 1 << lk
-      const int k = 1 << lk;
-      int lj = lk - 1;                        // stride j = 1 << lj
-      for (; lj >= 1; lj -= 2) {              // two stages per pass: strides j and h = j / 2
-        const int j = 1 << lj, h = j >> 1;
-        for (int q = threadIdx.x; q < (np >> 2); q += 256) {
-          const int low = q & (h - 1);
-          const int i0 = ((q >> (lj - 1)) << (lj + 1)) | low;
-          const bool up = (i0 & k) == 0;
-          uint64_t a = s[i0], b = s[i0 + h], c = s[i0 + j], d = s[i0 + j + h];
-          cmpx(a, c, up);
-          cmpx(b, d, up);
-          cmpx(a, b, up);
-          cmpx(c, d, up);
-          s[i0] = a;
-          s[i0 + h] = b;
-          s[i0 + j] = c;
-          s[i0 + j + h] = d;
-        }
-        __syncthreads();
-      }
-      if (lj == 0) {                          // odd number of stages: the stride-1 stage alone
-        for (int q = threadIdx.x; q < (np >> 1); q += 256) {
-          const int i0 = q << 1;
-          const bool up = (i0 & k) == 0;
-          uint64_t a = s[i0], b = s[i0 + 1];
-          cmpx(a, b, up);
-          s[i0] = a;
-          s[i0 + 1] = b;
-        }
-        __syncthreads();
-      }
+    int rank = 0, total = 0;
+    if (ok) {
+      row_rank(&M[d * 8], t, rank, total);
+      const int64_t pos = (int64_t)v * G + base[d] + rank;
+      keys_out[pos] = key[i];
+      ids_out[pos] = id[i];
     }
-    for (int i = threadIdx.x; i < n; i += 256) {
-      keys[beg + i] = s[i];
-      ids[beg + i] = (int32_t)(s[i] & 0xffffffffu);
+    __syncthreads();
+    if (ok) {
+      if (rank == 0) base[d] += total;
+      M[d * 8 + wi] = 0;
     }
-  } else if (CAP == SORT_CAP) {
-    // oversized tile: in-place bitonic on the (virtually padded) global segment; slow path, rare
-    uint64_t* k_ = keys + beg;
-    for (int k = 2; k <= np; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = threadIdx.x; i < np; i += 256) {
-          const int l = i ^ j;
-          if (l > i) {
-            const uint64_t a = i < n ? k_[i] : ~0ull, b = l < n ? k_[l] : ~0ull;
-            const bool up = (i & k) == 0;
-            if ((a > b) == up) {
-              if (i < n) k_[i] = b;
-              if (l < n) k_[l] = a;
-            }
-          }
-        }
-        __threadfence_block();
-        __syncthreads();
-      }
-    for (int i = threadIdx.x; i < n; i += 256) ids[beg + i] = (int32_t)(k_[i] & 0xffffffffu);
+    __syncthreads();
   }
 }
 
-// K2 composite: colour [3,H,W] + depth + accumulated opacity + n_touched
-__global__ __launch_bounds__(256) void composite_rgb_kernel(Cam c, const int32_t* tile_start, const int32_t* ids,
-                                                            const float* mean2d, const float* conic_op, const float* depth,
-                                                            const float* rgb, float* image, float* out_depth,
-                                                            float* out_alpha, int32_t* n_touched) {
-  __shared__ float s_xy[256][2], s_co[256][4], s_rgbd[256][4];
-  __shared__ int s_id[256];
-  const int gw = (c.width + TILE - 1) / TILE;
-  const int tile = blockIdx.x, tx = tile % gw, ty = tile / gw;
-  const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+// ---- coarse bins (cb x cb tiles), filled in depth order ---------------------------------------------------------
+__device__ __forceinline__ void coarse_range(int4 r, int cb, int& cx0, int& cy0, int& cx1, int& cy1) {
+  cx0 = r.x / cb;
+  cy0 = r.y / cb;
+  cx1 = (r.z - 1) / cb;
+  cy1 = (r.w - 1) / cb;
+}
+
+__global__ __launch_bounds__(256) void bin_count_kernel(Geo geo, const uint32_t* __restrict__ keys, const int32_t* __restrict__ ids,
+                                                        const int32_t* __restrict__ rect, int32_t* __restrict__ bin_hist, int64_t G, int nchunks) {
+  __shared__ int h[NB_MAX];
+  const int v = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+  for (int b = t; b < geo.NB; b += 256) h[b] = 0;
+  __syncthreads();
+  const uint32_t* kp = keys + (int64_t)v * G;
+  const int32_t* ip = ids + (int64_t)v * G;
+#pragma unroll
+  for (int i = 0; i < BN_ITEMS; ++i) {
+    const int64_t idx = (int64_t)chunk * BN_CH + i * 256 + t;
+    if (idx < G && kp[idx] != 0xffffffffu) {
+      const int4 r = *(const int4*)(rect + 4 * ((int64_t)v * G + ip[idx]));
+      int cx0, cy0, cx1, cy1;
+      coarse_range(r, geo.cb, cx0, cy0, cx1, cy1);
+      for (int cy = cy0; cy <= cy1; ++cy)
+        for (int cx = cx0; cx <= cx1; ++cx) atomicAdd(&h[cy * geo.nbx + cx], 1);
+    }
+  }
+  __syncthreads();
+  for (int b = t; b < geo.NB; b += 256) bin_hist[((int64_t)v * geo.NB + b) * nchunks + chunk] = h[b];
+}
+
+// entry = (Gaussian id, rect clipped to the bin: x0 | y0 << 5 | x1 << 10 | y1 << 15, each in [0, cb])
+__global__ __launch_bounds__(256) void bin_scatter_kernel(Geo geo, const uint32_t* __restrict__ keys, const int32_t* __restrict__ ids,
+                                                          const int32_t* __restrict__ rect, const int32_t* __restrict__ bin_hist,
+                                                          const int32_t* __restrict__ bin_tot, int32_t* __restrict__ bin_start,
+                                                          uint2* __restrict__ entries, int64_t cap_e, unsigned long long* __restrict__ stats, int64_t G,
+                                                          int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
+  const int NB = geo.NB;
+  uint32_t* M = dyn;                 // [NB][8]: bit t of row b <=> thread t's Gaussian of this slice touches bin b
+  int* base = (int*)(dyn + NB * 8);  // [NB] next free slot of the bin for this workgroup
+  int* add = base + NB;              // [NB] slots consumed by the slice being placed
+  __shared__ int s_w[4];
+  const int v = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+  // bin starts = exclusive scan of the bin totals: thread t owns bins 4 t .. 4 t + 3 (NB <= 1024)
+  int loc[4], sum = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = t * 4 + i;
+    loc[i] = b < NB ? bin_tot[v * NB + b] : 0;
+    sum += loc[i];
+  }
+  int total_e = 0;
+  int run = block_excl_scan(sum, s_w, &total_e);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = t * 4 + i;
+    if (b < NB) {
+      base[b] = run + bin_hist[((int64_t)v * NB + b) * nchunks + chunk];
+      add[b] = 0;
+      if (chunk == 0) bin_start[v * (NB + 1) + b] = run;
+    }
+    run += loc[i];
+  }
+  if (chunk == 0 && t == 0) {
+    bin_start[v * (NB + 1) + NB] = total_e;
+    stats[v * ST_N + ST_E] = (unsigned long long)total_e;
+    if (total_e > cap_e) stats[v * ST_N + ST_FLAGS] = 1ull;
+  }
+  for (int i = t; i < NB * 8; i += 256) M[i] = 0;
+  __syncthreads();
+  const uint32_t* kp = keys + (int64_t)v * G;
+  const int32_t* ip = ids + (int64_t)v * G;
+  const int wi = t >> 5;
+  const uint32_t bit = 1u << (t & 31);
+  const int cb = geo.cb, nbx = geo.nbx;
+  for (int i = 0; i < BN_ITEMS; ++i) {
+    const int64_t idx = (int64_t)chunk * BN_CH + i * 256 + t;
+    const bool ok = idx < G && kp[idx] != 0xffffffffu;
+    int id = 0, cx0 = 0, cy0 = 0, cx1 = -1, cy1 = -1;
+    int4 r = make_int4(0, 0, 0, 0);
+    if (ok) {
+      id = ip[idx];
+      r = *(const int4*)(rect + 4 * ((int64_t)v * G + id));
+      coarse_range(r, cb, cx0, cy0, cx1, cy1);
+      for (int cy = cy0; cy <= cy1; ++cy)
+        for (int cx = cx0; cx <= cx1; ++cx) atomicOr(&M[(cy * nbx + cx) * 8 + wi], bit);
+    }
+    __syncthreads();
+    for (int cy = cy0; cy <= cy1; ++cy)
+      for (int cx = cx0; cx <= cx1; ++cx) {
+        const int b = cy * nbx + cx;
+        int rank, total;
+        row_rank(&M[b * 8], t, rank, total);
+        if (rank == 0) add[b] = total;
+        const int64_t pos = (int64_t)base[b] + rank;
+        if (pos < cap_e) {
+          const int ox = cx * cb, oy = cy * cb;
+          const uint32_t x0 = (uint32_t)(max(r.x, ox) - ox), y0 = (uint32_t)(max(r.y, oy) - oy);
+          const uint32_t x1 = (uint32_t)(min(r.z, ox + cb) - ox), y1 = (uint32_t)(min(r.w, oy + cb) - oy);
+          entries[(int64_t)v * cap_e + pos] = make_uint2((uint32_t)id, x0 | (y0 << 5) | (x1 << 10) | (y1 << 15));
+        }
+      }
+    __syncthreads();
+    for (int cy = cy0; cy <= cy1; ++cy)
+      for (int cx = cx0; cx <= cx1; ++cx) M[(cy * nbx + cx) * 8 + wi] = 0;
+    for (int b = t; b < NB; b += 256) {
+      const int a = add[b];
+      if (a) {
+        base[b] += a;
+        add[b] = 0;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// does the packed bin-relative rect cover tile (rtx, rty) of the bin?
+__device__ __forceinline__ bool entry_covers(uint32_t pr, int rtx, int rty) {
+  const int x0 = pr & 31, y0 = (pr >> 5) & 31, x1 = (pr >> 10) & 31, y1 = (pr >> 15) & 31;
+  return rtx >= x0 && rtx < x1 && rty >= y0 && rty < y1;
+}
+
+// ---- K2 composite: colour [3,H,W] + depth + accumulated opacity (+ n_touched), fused with the per-tile filter -----
+constexpr int STG = 512;  // staging capacity: < 256 carried over + <= 256 new survivors
+template <bool NT>
+__global__ __launch_bounds__(256) void composite_rgb_kernel(const Cam* __restrict__ cams, Geo geo, const int32_t* __restrict__ bin_start,
+                                                            const uint2* __restrict__ entries, int64_t cap_e, const float* __restrict__ mean2d,
+                                                            const float* __restrict__ conic_op, const float* __restrict__ depth,
+                                                            const float* __restrict__ rgb, int64_t G, float* __restrict__ image,
+                                                            float* __restrict__ out_depth, float* __restrict__ out_alpha, int32_t* __restrict__ n_touched) {
+  __shared__ float s_xy[STG][2];
+  __shared__ __attribute__((aligned(16))) float s_co[STG][4];
+  __shared__ __attribute__((aligned(16))) float s_rgbd[STG][4];
+  __shared__ int s_id[STG];
+  __shared__ int s_nt[NT ? STG : 1];
+  __shared__ int s_wcnt[4];
+  const int v = blockIdx.y;
+  const Cam& c = cams[v];
+  const int tile = blockIdx.x, tx = tile % geo.gw, ty = tile / geo.gw;
+  const int bx = tx / geo.cb, by = ty / geo.cb, bin = by * geo.nbx + bx;
+  const int rtx = tx - bx * geo.cb, rty = ty - by * geo.cb;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lx = t & 15, ly = t >> 4;
   const int px = tx * TILE + lx, py = ty * TILE + ly;
   const bool inside = px < c.width && py < c.height;
   const float pxf = (float)px, pyf = (float)py;
-  const int beg = tile_start[tile], end = tile_start[tile + 1];
+  const int64_t ebeg = bin_start[v * (geo.NB + 1) + bin];
+  const int64_t eend = min((int64_t)bin_start[v * (geo.NB + 1) + bin + 1], cap_e);
+  const uint2* ep = entries + (int64_t)v * cap_e;
+  const int64_t vg = (int64_t)v * G;
+  const float alpha_min = c.alpha_min, alpha_max = c.alpha_max, t_min = c.t_min;
+  const bool nt_post = c.nt_post_blend != 0;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, O = 0.f;
   bool done = !inside;
-  for (int base = beg; base < end; base += 256) {
-    if (__syncthreads_count(done) == 256) break;
-    const int i = base + threadIdx.x;
-    if (i < end) {
-      const int g = ids[i];
-      s_id[threadIdx.x] = g;
-      s_xy[threadIdx.x][0] = mean2d[2 * g];
-      s_xy[threadIdx.x][1] = mean2d[2 * g + 1];
-      const float4 co = *(const float4*)(conic_op + 4 * (size_t)g);
-      s_co[threadIdx.x][0] = co.x; s_co[threadIdx.x][1] = co.y; s_co[threadIdx.x][2] = co.z; s_co[threadIdx.x][3] = co.w;
-      s_rgbd[threadIdx.x][0] = rgb[3 * g]; s_rgbd[threadIdx.x][1] = rgb[3 * g + 1]; s_rgbd[threadIdx.x][2] = rgb[3 * g + 2];
-      s_rgbd[threadIdx.x][3] = depth[g];
+  int staged = 0;
+  int64_t base = ebeg;
+  while (true) {
+    if (__syncthreads_count(done) == 256) break;  // also fences the previous round's LDS reads
+    while (staged < 256 && base < eend) {
+      const int64_t i = base + t;
+      bool pass = false;
+      uint2 e = make_uint2(0, 0);
+      if (i < eend) {
+        e = ep[i];
+        pass = entry_covers(e.y, rtx, rty);
+      }
+      const unsigned long long m = __ballot(pass);
+      if (lane == 0) s_wcnt[wave] = __popcll(m);
+      __syncthreads();
+      int off = staged + __popcll(m & ((1ull << lane) - 1ull));
+      for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+      const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+      if (pass) {
+        const int64_t g = vg + e.x;
+        s_id[off] = (int)e.x;
+        *(float2*)s_xy[off] = *(const float2*)(mean2d + 2 * g);
+        *(float4*)s_co[off] = *(const float4*)(conic_op + 4 * g);
+        s_rgbd[off][0] = rgb[3 * g];
+        s_rgbd[off][1] = rgb[3 * g + 1];
+        s_rgbd[off][2] = rgb[3 * g + 2];
+        s_rgbd[off][3] = depth[g];
+        if (NT) s_nt[off] = 0;
+      }
+      staged += tot;
+      base += 256;
+      __syncthreads();
     }
-    __syncthreads();
-    const int cnt = min(256, end - base);
-    for (int j = 0; !done && j < cnt; ++j) {
+    if (staged == 0) break;
+    for (int j = 0; !done && j < staged; ++j) {
       const float dx = s_xy[j][0] - pxf, dy = s_xy[j][1] - pyf;
       const float power = -0.5f * (s_co[j][0] * dx * dx + s_co[j][2] * dy * dy) - s_co[j][1] * dx * dy;
       if (power > 0.0f) continue;
-      const float a = fminf(c.alpha_max, s_co[j][3] * exp_det(power));
-      if (a < c.alpha_min) continue;
+      const float a = fminf(alpha_max, s_co[j][3] * exp_det(power));
+      if (a < alpha_min) continue;
       const float nT = T * (1.0f - a);
-      if (nT < c.t_min) {
+      if (nT < t_min) {
         done = true;
         continue;
       }
@@ -429,35 +605,146 @@ __global__ __launch_bounds__(256) void composite_rgb_kernel(Cam c, const int32_t
       C2 += s_rgbd[j][2] * w;
       D += s_rgbd[j][3] * w;
       O += w;
-      if (T > 0.5f) atomicAdd(&n_touched[s_id[j]], 1);
+      if (NT) {
+        // pixels that count this Gaussian: ballot over the lanes that reached this point, one LDS add per wave
+        const bool cnt = (nt_post ? nT : T) > 0.5f;
+        const unsigned long long mc = __ballot(cnt);
+        if (cnt && lane == (int)__ffsll((long long)mc) - 1) atomicAdd(&s_nt[j], (int)__popcll(mc));
+      }
       T = nT;
     }
+    if (NT) {
+      __syncthreads();
+      for (int j = t; j < staged; j += 256) {
+        const int n = s_nt[j];
+        if (n) atomicAdd(&n_touched[vg + s_id[j]], n);
+      }
+    }
+    staged = 0;
   }
   if (inside) {
-    const size_t pix = (size_t)py * c.width + px, hw = (size_t)c.width * c.height;
-    image[pix] = C0 + T * c.bg[0];
-    image[hw + pix] = C1 + T * c.bg[1];
-    image[2 * hw + pix] = C2 + T * c.bg[2];
-    out_depth[pix] = D;
-    out_alpha[pix] = O;
+    const size_t hw = (size_t)c.width * c.height, pix = (size_t)py * c.width + px;
+    float* img = image + (size_t)v * 3 * hw;
+    img[pix] = C0 + T * c.bg[0];
+    img[hw + pix] = C1 + T * c.bg[1];
+    img[2 * hw + pix] = C2 + T * c.bg[2];
+    out_depth[(size_t)v * hw + pix] = D;
+    out_alpha[(size_t)v * hw + pix] = O;
   }
 }
 
-// K3 composite: one 32-channel chunk of the feature matrix per blockIdx.y; colours [H,W,C]; alpha written by chunk 0
+// ---- per-tile lists (front to back) out of the coarse bins: count, scan, write -------------------------------------
+__global__ __launch_bounds__(256) void tl_count_kernel(Geo geo, const int32_t* __restrict__ bin_start, const uint2* __restrict__ entries,
+                                                       int64_t cap_e, int32_t* __restrict__ tile_count) {
+  __shared__ int s_w[4];
+  const int v = blockIdx.y, tile = blockIdx.x, tx = tile % geo.gw, ty = tile / geo.gw;
+  const int bx = tx / geo.cb, by = ty / geo.cb, bin = by * geo.nbx + bx;
+  const int rtx = tx - bx * geo.cb, rty = ty - by * geo.cb;
+  const int64_t ebeg = bin_start[v * (geo.NB + 1) + bin];
+  const int64_t eend = min((int64_t)bin_start[v * (geo.NB + 1) + bin + 1], cap_e);
+  const uint2* ep = entries + (int64_t)v * cap_e;
+  int n = 0;
+  for (int64_t i = ebeg + threadIdx.x; i < eend; i += 256) n += entry_covers(ep[i].y, rtx, rty) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_count[(int64_t)v * geo.T + tile] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// exclusive scan of the tile counts of a view -> tile_start[T + 2]: [0..T] clamped to cap (so that lists never overrun the
+// id buffer), [T + 1] = the true total; single workgroup of 1024 threads per view
+__global__ __launch_bounds__(1024) void tl_scan_kernel(const int32_t* __restrict__ tile_count, int32_t* __restrict__ tile_start, int T, int64_t cap,
+                                                       unsigned long long* __restrict__ stats) {
+  __shared__ int32_t wsum[16];
+  __shared__ long long carry;
+  const int v = blockIdx.y;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int32_t* cnt = tile_count + (int64_t)v * T;
+  int32_t* ts = tile_start + (int64_t)v * (T + 2);
+  if (t == 0) carry = 0;
+  __syncthreads();
+  for (int b = 0; b < T; b += 1024) {
+    const int i = b + t;
+    const int x = i < T ? cnt[i] : 0;
+    int incl = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int n = __shfl_up(incl, o);
+      if (lane >= o) incl += n;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    long long woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const long long excl = carry + woff + incl - x;
+    if (i < T) ts[i] = (int32_t)min(excl, (long long)cap);
+    __syncthreads();
+    if (t == 1023) carry = excl + x;
+    __syncthreads();
+  }
+  if (t == 0) {
+    ts[T] = (int32_t)min(carry, (long long)cap);
+    ts[T + 1] = (int32_t)min(carry, (long long)0x7fffffff);
+    if (carry > cap) stats[v * ST_N + ST_FLAGS] |= 2ull;
+  }
+}
+
+__global__ __launch_bounds__(256) void tl_write_kernel(Geo geo, const int32_t* __restrict__ bin_start, const uint2* __restrict__ entries,
+                                                       int64_t cap_e, const int32_t* __restrict__ tile_start, int32_t* __restrict__ ids, int64_t cap_d) {
+  __shared__ int s_wcnt[4];
+  const int v = blockIdx.y, tile = blockIdx.x, tx = tile % geo.gw, ty = tile / geo.gw;
+  const int bx = tx / geo.cb, by = ty / geo.cb, bin = by * geo.nbx + bx;
+  const int rtx = tx - bx * geo.cb, rty = ty - by * geo.cb;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t ebeg = bin_start[v * (geo.NB + 1) + bin];
+  const int64_t eend = min((int64_t)bin_start[v * (geo.NB + 1) + bin + 1], cap_e);
+  const uint2* ep = entries + (int64_t)v * cap_e;
+  const int32_t* ts = tile_start + (int64_t)v * (geo.T + 2);
+  const int64_t obeg = ts[tile], oend = ts[tile + 1];  // clamped to cap_d by the scan
+  int32_t* out = ids + (int64_t)v * cap_d;
+  int64_t run = obeg;
+  for (int64_t b = ebeg; b < eend; b += 256) {
+    const int64_t i = b + threadIdx.x;
+    bool pass = false;
+    uint2 e = make_uint2(0, 0);
+    if (i < eend) {
+      e = ep[i];
+      pass = entry_covers(e.y, rtx, rty);
+    }
+    const unsigned long long m = __ballot(pass);
+    if (lane == 0) s_wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int64_t off = run + __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+    if (pass && off < oend) out[off] = (int32_t)e.x;
+    run += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    __syncthreads();
+  }
+}
+
+// ---- K3 composite: one 32-channel chunk of the feature matrix per blockIdx.y; colours [H,W,C]; alpha written by chunk 0
 constexpr int CHUNK = 32;
-__global__ __launch_bounds__(256) void composite_feat_kernel(Cam c, const int32_t* tile_start, const int32_t* ids,
-                                                             const float* mean2d, const float* conic_op,
-                                                             const float* feats, int channels, float* out, float* out_alpha) {
-  __shared__ float s_xy[128][2], s_co[128][4];
+__global__ __launch_bounds__(256) void composite_feat_kernel(const Cam* __restrict__ cams, Geo geo, const int32_t* __restrict__ tile_start,
+                                                             const int32_t* __restrict__ ids, int64_t cap_d, const float* __restrict__ mean2d,
+                                                             const float* __restrict__ conic_op, const float* __restrict__ feats, int channels,
+                                                             int64_t G, float* __restrict__ out, float* __restrict__ out_alpha) {
+  __shared__ float s_xy[128][2];
+  __shared__ __attribute__((aligned(16))) float s_co[128][4];
   __shared__ float s_f[128][CHUNK + 1];
-  const int gw = (c.width + TILE - 1) / TILE;
-  const int tile = blockIdx.x, tx = tile % gw, ty = tile / gw;
+  const int v = blockIdx.z;
+  const Cam& c = cams[v];
+  const int tile = blockIdx.x, tx = tile % geo.gw, ty = tile / geo.gw;
   const int ch0 = blockIdx.y * CHUNK, nch = min(CHUNK, channels - ch0);
   const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
   const int px = tx * TILE + lx, py = ty * TILE + ly;
   const bool inside = px < c.width && py < c.height;
   const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
-  const int beg = tile_start[tile], end = tile_start[tile + 1];
+  const int32_t* ts = tile_start + (int64_t)v * (geo.T + 2);
+  const int32_t* idp = ids + (int64_t)v * cap_d;
+  const int64_t vg = (int64_t)v * G;
+  const int beg = ts[tile], end = ts[tile + 1];
+  const float alpha_min = c.alpha_min, alpha_max = c.alpha_max, t_min = c.t_min;
   float T = 1.0f, O = 0.f;
   float acc[CHUNK];
 #pragma unroll
@@ -467,25 +754,23 @@ __global__ __launch_bounds__(256) void composite_feat_kernel(Cam c, const int32_
     if (__syncthreads_count(done) == 256) break;
     const int cnt = min(128, end - base);
     if (threadIdx.x < cnt) {
-      const int g = ids[base + threadIdx.x];
-      s_xy[threadIdx.x][0] = mean2d[2 * g];
-      s_xy[threadIdx.x][1] = mean2d[2 * g + 1];
-      const float4 co = *(const float4*)(conic_op + 4 * (size_t)g);
-      s_co[threadIdx.x][0] = co.x; s_co[threadIdx.x][1] = co.y; s_co[threadIdx.x][2] = co.z; s_co[threadIdx.x][3] = co.w;
+      const int64_t g = vg + idp[base + threadIdx.x];
+      *(float2*)s_xy[threadIdx.x] = *(const float2*)(mean2d + 2 * g);
+      *(float4*)s_co[threadIdx.x] = *(const float4*)(conic_op + 4 * g);
     }
     for (int e = threadIdx.x; e < cnt * CHUNK; e += 256) {
       const int j = e / CHUNK, k = e - j * CHUNK;
-      s_f[j][k] = k < nch ? feats[(size_t)ids[base + j] * channels + ch0 + k] : 0.f;
+      s_f[j][k] = k < nch ? feats[(size_t)idp[base + j] * channels + ch0 + k] : 0.f;
     }
     __syncthreads();
     for (int j = 0; !done && j < cnt; ++j) {
       const float dx = s_xy[j][0] - pxf, dy = s_xy[j][1] - pyf;
       const float sigma = 0.5f * (s_co[j][0] * dx * dx + s_co[j][2] * dy * dy) + s_co[j][1] * dx * dy;
       if (sigma < 0.0f) continue;
-      const float a = fminf(c.alpha_max, s_co[j][3] * exp_det(-sigma));
-      if (a < c.alpha_min) continue;
+      const float a = fminf(alpha_max, s_co[j][3] * exp_det(-sigma));
+      if (a < alpha_min) continue;
       const float nT = T * (1.0f - a);
-      if (nT <= c.t_min) {
+      if (nT <= t_min) {
         done = true;
         continue;
       }
@@ -497,9 +782,10 @@ __global__ __launch_bounds__(256) void composite_feat_kernel(Cam c, const int32_
     }
   }
   if (inside) {
-    const size_t pix = (size_t)py * c.width + px;
-    for (int k = 0; k < nch; ++k) out[pix * channels + ch0 + k] = acc[k];
-    if (blockIdx.y == 0 && out_alpha) out_alpha[pix] = O;
+    const size_t hw = (size_t)c.width * c.height, pix = (size_t)py * c.width + px;
+    float* o = out + ((size_t)v * hw + pix) * channels + ch0;
+    for (int k = 0; k < nch; ++k) o[k] = acc[k];
+    if (blockIdx.y == 0 && out_alpha) out_alpha[(size_t)v * hw + pix] = O;
   }
 }
 
@@ -510,18 +796,18 @@ __global__ void scale_kernel(float* x, int64_t n, float s) {
 
 inline dim3 g1(int64_t n, int b = 256) { return dim3((unsigned)cdiv64(n, b)); }
 
-void to_cam(const siu3r_raster_cam* in, Cam* c) {
-  c->mode = in->mode; c->width = in->width; c->height = in->height;
-  memcpy(c->w2c, in->w2c, sizeof(c->w2c));
-  memcpy(c->proj, in->proj, sizeof(c->proj));
-  c->tanfovx = in->tanfovx; c->tanfovy = in->tanfovy;
-  memcpy(c->campos, in->campos, sizeof(c->campos));
-  memcpy(c->bg, in->bg, sizeof(c->bg));
-  c->sh_degree = in->sh_degree; c->sh_band4 = in->sh_band4; c->k2_znear_cull = in->k2_znear_cull;
-  c->fx = in->fx; c->fy = in->fy; c->cx = in->cx; c->cy = in->cy;
-  c->near_plane = in->near_plane; c->far_plane = in->far_plane; c->eps2d = in->eps2d; c->radius_clip = in->radius_clip;
-  c->extent_sigma = in->extent_sigma; c->opacity_aware_extent = in->opacity_aware_extent;
-  c->alpha_min = in->alpha_min; c->alpha_max = in->alpha_max; c->t_min = in->t_min; c->dilation = in->dilation;
+// every view of a call shares the frame size and the mode
+int check_views(const Cam* cams, int V, const char* who) {
+  SIU3R_CHECK(cams && V >= 1 && V <= 65535, "%s: bad view array (V = %d)", who, V);
+  for (int v = 0; v < V; ++v) {
+    SIU3R_CHECK(cams[v].mode == cams[0].mode && cams[v].width == cams[0].width && cams[v].height == cams[0].height,
+                "%s: the views of one call must share mode and frame size", who);
+    SIU3R_CHECK(cams[v].mode == 0 || cams[v].mode == 1, "%s: bad mode %d", who, cams[v].mode);
+    SIU3R_CHECK(cams[v].width > 0 && cams[v].height > 0, "%s: empty frame", who);
+    SIU3R_CHECK(cams[v].mode == 0 ? cams[v].k2_znear_cull >= 0.f : cams[v].near_plane > 0.f,
+                "%s: the near cull must be positive (depth keys are the bit patterns of positive floats)", who);
+  }
+  return 0;
 }
 
 }  // namespace
@@ -614,69 +900,129 @@ __global__ void blend_bg_kernel(int64_t n, int C, float* colors, const float* al
 }
 
 // ---- C ABI -------------------------------------------------------------------------------------------------------
-extern "C" int siu3r_raster_bin(const siu3r_raster_cam* cam, int64_t G, const float* means, const float* cov6,
-                                const float* opacities, const float* colors, int channels, float* mean2d, float* conic_op,
-                                float* depth, int32_t* radii, int32_t* rect, int32_t* tiles_touched, float* rgb,
-                                int32_t* tile_count, int32_t* tile_start, int32_t* cursor, int64_t cap, void* stream) {
-  SIU3R_CHECK(cam && tile_count && tile_start && cursor, "raster_bin: null pointer");
-  SIU3R_CHECK(cap > 0 && cap < (1ll << 31), "raster_bin: pair capacity %ld out of range", (long)cap);
-  SIU3R_CHECK(G == 0 || (means && cov6 && opacities && mean2d && conic_op && depth && radii && rect && tiles_touched), "raster_bin: null per-Gaussian pointer");
-  SIU3R_CHECK(cam->mode == 0 || cam->mode == 1, "raster_bin: bad mode %d", cam->mode);
-  SIU3R_CHECK(cam->mode == 1 || G == 0 || (colors && rgb && channels >= (cam->sh_degree + 1) * (cam->sh_degree + 1)), "raster_bin: SH colours missing / too few coefficients");
-  Cam c;
-  to_cam(cam, &c);
+extern "C" int siu3r_raster_geometry(int width, int height, int64_t G, int32_t* out8) {
+  SIU3R_CHECK(out8 && width > 0 && height > 0 && G >= 0, "raster_geometry: bad arguments");
+  const Geo g = make_geo(width, height);
+  out8[0] = g.gw; out8[1] = g.gh; out8[2] = g.T; out8[3] = g.cb; out8[4] = g.NB;
+  out8[5] = (int32_t)cdiv64(G > 0 ? G : 1, RS_CH);   // radix-sort chunks (columns of the [V,256,.] histogram table)
+  out8[6] = (int32_t)cdiv64(G > 0 ? G : 1, BN_CH);   // binning chunks (columns of the [V,NB,.] table)
+  out8[7] = (int32_t)sizeof(siu3r_raster_cam);
+  return 0;
+}
+
+extern "C" int siu3r_raster_project(const siu3r_raster_cam* cams_host, int V, void* cams_dev, int64_t G, const float* means, const float* cov6,
+                                    const float* opacities, const float* colors, int channels, float* mean2d, float* conic_op, float* depth,
+                                    int32_t* radii, int32_t* rect, int32_t* tiles_touched, float* rgb, uint32_t* keys, uint64_t* stats,
+                                    void* stream) {
+  if (int rc = check_views(cams_host, V, "raster_project")) return rc;
+  SIU3R_CHECK(cams_dev && stats, "raster_project: null pointer");
+  SIU3R_CHECK(G >= 0 && G < (1ll << 31), "raster_project: G = %ld out of range", (long)G);
+  SIU3R_CHECK(G == 0 || (means && cov6 && opacities && mean2d && conic_op && depth && radii && rect && tiles_touched && keys), "raster_project: null per-Gaussian pointer");
+  SIU3R_CHECK(cams_host[0].mode == 1 || G == 0 || (colors && rgb), "raster_project: SH colours missing");
+  for (int v = 0; v < V; ++v)
+    SIU3R_CHECK(cams_host[v].mode == 1 || G == 0 || channels >= (cams_host[v].sh_degree + 1) * (cams_host[v].sh_degree + 1), "raster_project: too few SH coefficients");
   hipStream_t s = (hipStream_t)stream;
-  const int T = ((c.width + TILE - 1) / TILE) * ((c.height + TILE - 1) / TILE);
-  if (hipMemsetAsync(tile_count, 0, sizeof(int32_t) * T * NPART, s) != hipSuccess) {
-    siu3r_set_error("raster_bin: memset failed");
+  if (hipMemcpyAsync(cams_dev, cams_host, sizeof(Cam) * V, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemsetAsync(stats, 0, sizeof(uint64_t) * ST_N * V, s) != hipSuccess) {
+    siu3r_set_error("raster_project: camera upload / stats reset failed");
     return 2;
   }
   if (G > 0)
-    hipLaunchKernelGGL(project_kernel, g1(G), dim3(256), 0, s, c, G, means, cov6, opacities, colors, channels, mean2d, conic_op, depth, radii, rect, tiles_touched, rgb, tile_count);
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, tile_count, tile_start, cursor, T, (int)cap);
+    hipLaunchKernelGGL(project_kernel, dim3((unsigned)cdiv64(G, 256), V), dim3(256), 0, s, (const Cam*)cams_dev, G, means, cov6, opacities, colors, channels,
+                       mean2d, conic_op, depth, radii, rect, tiles_touched, rgb, keys, (unsigned long long*)stats);
+  SIU3R_LAUNCH_CHECK("siu3r_raster_project");
+  return 0;
+}
+
+extern "C" int siu3r_raster_sort(int V, int64_t G, uint32_t* keys_a, uint32_t* keys_b, int32_t* ids_a, int32_t* ids_b, int32_t* rs_hist,
+                                 int32_t* rs_tot, void* stream) {
+  SIU3R_CHECK(V >= 1 && G >= 0, "raster_sort: bad sizes");
+  if (G == 0) return 0;
+  SIU3R_CHECK(keys_a && keys_b && ids_a && ids_b && rs_hist && rs_tot, "raster_sort: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int nchunks = (int)cdiv64(G, RS_CH);
+  for (int pass = 0; pass < 4; ++pass) {
+    const uint32_t* kin = (pass & 1) ? keys_b : keys_a;
+    uint32_t* kout = (pass & 1) ? keys_a : keys_b;
+    const int32_t* iin = pass == 0 ? nullptr : ((pass & 1) ? ids_b : ids_a);  // pass 0: the payload is the index itself
+    int32_t* iout = (pass & 1) ? ids_a : ids_b;
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(nchunks, V), dim3(256), 0, s, kin, rs_hist, G, pass * 8, nchunks);
+    hipLaunchKernelGGL(row_scan_kernel, dim3(64, V), dim3(256), 0, s, rs_hist, rs_tot, 256, nchunks);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(nchunks, V), dim3(256), 0, s, kin, iin, kout, iout, rs_hist, rs_tot, G, pass * 8, nchunks);
+  }
+  SIU3R_LAUNCH_CHECK("siu3r_raster_sort");
+  return 0;  // four passes: the sorted keys / ids are back in keys_a / ids_a
+}
+
+extern "C" int siu3r_raster_bin(const siu3r_raster_cam* cams_host, int V, int64_t G, const uint32_t* keys, const int32_t* ids, const int32_t* rect,
+                                int32_t* bin_hist, int32_t* bin_tot, int32_t* bin_start, void* entries, int64_t cap_e, uint64_t* stats,
+                                void* stream) {
+  if (int rc = check_views(cams_host, V, "raster_bin")) return rc;
+  SIU3R_CHECK(bin_hist && bin_tot && bin_start && stats && cap_e > 0 && cap_e < (1ll << 31), "raster_bin: bad arguments");
+  SIU3R_CHECK(G == 0 || (keys && ids && rect && entries), "raster_bin: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const Geo geo = make_geo(cams_host[0].width, cams_host[0].height);
+  SIU3R_CHECK(geo.NB <= NB_MAX, "raster_bin: frame of %d x %d tiles exceeds the coarse-bin table", geo.gw, geo.gh);
+  const int nchunks = (int)cdiv64(G > 0 ? G : 1, BN_CH);
+  if (G == 0) {
+    if (hipMemsetAsync(bin_start, 0, sizeof(int32_t) * (size_t)V * (geo.NB + 1), s) != hipSuccess) {
+      siu3r_set_error("raster_bin: memset failed");
+      return 2;
+    }
+    return 0;
+  }
+  hipLaunchKernelGGL(bin_count_kernel, dim3(nchunks, V), dim3(256), 0, s, geo, keys, ids, rect, bin_hist, G, nchunks);
+  hipLaunchKernelGGL(row_scan_kernel, dim3((geo.NB + 3) / 4, V), dim3(256), 0, s, bin_hist, bin_tot, geo.NB, nchunks);
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(nchunks, V), dim3(256), (size_t)geo.NB * 40, s, geo, keys, ids, rect, bin_hist, bin_tot, bin_start,
+                     (uint2*)entries, cap_e, (unsigned long long*)stats, G, nchunks);
   SIU3R_LAUNCH_CHECK("siu3r_raster_bin");
   return 0;
 }
 
-extern "C" int siu3r_raster_sort(const siu3r_raster_cam* cam, int64_t G, const int32_t* rect, const float* depth,
-                                 const int32_t* tile_start, int32_t* cursor, uint64_t* keys, int32_t* ids, int64_t cap, void* stream) {
-  SIU3R_CHECK(cam && tile_start && cursor && keys && ids && (G == 0 || (rect && depth)), "raster_sort: null pointer");
+extern "C" int siu3r_raster_composite_rgb(const siu3r_raster_cam* cams_host, int V, const void* cams_dev, int64_t G, const int32_t* bin_start,
+                                          const void* entries, int64_t cap_e, const float* mean2d, const float* conic_op, const float* depth,
+                                          const float* rgb, float* image, float* out_depth, float* out_alpha, int32_t* n_touched, void* stream) {
+  if (int rc = check_views(cams_host, V, "raster_composite_rgb")) return rc;
+  SIU3R_CHECK(cams_dev && bin_start && image && out_depth && out_alpha && (G == 0 || (entries && mean2d && conic_op && depth && rgb)), "raster_composite_rgb: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  const int gw = (cam->width + TILE - 1) / TILE, T = gw * ((cam->height + TILE - 1) / TILE);
-  if (G > 0) hipLaunchKernelGGL(fill_kernel, g1(G), dim3(256), 0, s, G, rect, depth, cursor, keys, gw, T, (int)cap);
-  hipLaunchKernelGGL((sort_kernel<1024, 0>), dim3(T), dim3(256), 0, s, tile_start, keys, ids);
-  hipLaunchKernelGGL((sort_kernel<4096, 1024>), dim3(T), dim3(256), 0, s, tile_start, keys, ids);
-  hipLaunchKernelGGL((sort_kernel<SORT_CAP, 4096>), dim3(T), dim3(256), 0, s, tile_start, keys, ids);
-  SIU3R_LAUNCH_CHECK("siu3r_raster_sort");
-  return 0;
-}
-
-extern "C" int siu3r_raster_composite_rgb(const siu3r_raster_cam* cam, const int32_t* tile_start, const int32_t* ids,
-                                          const float* mean2d, const float* conic_op, const float* depth, const float* rgb,
-                                          float* image, float* out_depth, float* out_alpha, int32_t* n_touched, int64_t G,
-                                          void* stream) {
-  SIU3R_CHECK(cam && tile_start && ids && image && out_depth && out_alpha && (G == 0 || (mean2d && conic_op && depth && rgb && n_touched)), "raster_composite_rgb: null pointer");
-  Cam c;
-  to_cam(cam, &c);
-  hipStream_t s = (hipStream_t)stream;
-  const int T = ((c.width + TILE - 1) / TILE) * ((c.height + TILE - 1) / TILE);
-  if (G > 0 && hipMemsetAsync(n_touched, 0, sizeof(int32_t) * G, s) != hipSuccess) {
+  const Geo geo = make_geo(cams_host[0].width, cams_host[0].height);
+  if (n_touched && G > 0 && hipMemsetAsync(n_touched, 0, sizeof(int32_t) * (size_t)V * G, s) != hipSuccess) {
     siu3r_set_error("raster_composite_rgb: memset failed");
     return 2;
   }
-  hipLaunchKernelGGL(composite_rgb_kernel, dim3(T), dim3(256), 0, s, c, tile_start, ids, mean2d, conic_op, depth, rgb, image, out_depth, out_alpha, n_touched);
+  if (n_touched)
+    hipLaunchKernelGGL(composite_rgb_kernel<true>, dim3(geo.T, V), dim3(256), 0, s, (const Cam*)cams_dev, geo, bin_start, (const uint2*)entries, cap_e, mean2d,
+                       conic_op, depth, rgb, G, image, out_depth, out_alpha, n_touched);
+  else
+    hipLaunchKernelGGL(composite_rgb_kernel<false>, dim3(geo.T, V), dim3(256), 0, s, (const Cam*)cams_dev, geo, bin_start, (const uint2*)entries, cap_e, mean2d,
+                       conic_op, depth, rgb, G, image, out_depth, out_alpha, n_touched);
   SIU3R_LAUNCH_CHECK("siu3r_raster_composite_rgb");
   return 0;
 }
 
-extern "C" int siu3r_raster_composite_feat(const siu3r_raster_cam* cam, const int32_t* tile_start, const int32_t* ids,
-                                           const float* mean2d, const float* conic_op, const float* feats, int channels,
-                                           float* out, float* out_alpha, void* stream) {
-  SIU3R_CHECK(cam && tile_start && ids && mean2d && conic_op && feats && out && channels > 0, "raster_composite_feat: bad arguments");
-  Cam c;
-  to_cam(cam, &c);
-  const int T = ((c.width + TILE - 1) / TILE) * ((c.height + TILE - 1) / TILE);
-  hipLaunchKernelGGL(composite_feat_kernel, dim3(T, (channels + CHUNK - 1) / CHUNK), dim3(256), 0, (hipStream_t)stream, c, tile_start, ids, mean2d, conic_op, feats, channels, out, out_alpha);
+extern "C" int siu3r_raster_tile_lists(const siu3r_raster_cam* cams_host, int V, const int32_t* bin_start, const void* entries, int64_t cap_e,
+                                       int32_t* tile_count, int32_t* tile_start, int32_t* ids, int64_t cap_d, uint64_t* stats, void* stream) {
+  if (int rc = check_views(cams_host, V, "raster_tile_lists")) return rc;
+  SIU3R_CHECK(bin_start && entries && tile_count && tile_start && ids && stats && cap_d > 0 && cap_d < (1ll << 31), "raster_tile_lists: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const Geo geo = make_geo(cams_host[0].width, cams_host[0].height);
+  hipLaunchKernelGGL(tl_count_kernel, dim3(geo.T, V), dim3(256), 0, s, geo, bin_start, (const uint2*)entries, cap_e, tile_count);
+  hipLaunchKernelGGL(tl_scan_kernel, dim3(1, V), dim3(1024), 0, s, tile_count, tile_start, geo.T, cap_d, (unsigned long long*)stats);
+  hipLaunchKernelGGL(tl_write_kernel, dim3(geo.T, V), dim3(256), 0, s, geo, bin_start, (const uint2*)entries, cap_e, tile_start, ids, cap_d);
+  SIU3R_LAUNCH_CHECK("siu3r_raster_tile_lists");
+  return 0;
+}
+
+extern "C" int siu3r_raster_composite_feat(const siu3r_raster_cam* cams_host, int V, const void* cams_dev, int64_t G, const int32_t* tile_start,
+                                           const int32_t* ids, int64_t cap_d, const float* mean2d, const float* conic_op, const float* feats,
+                                           int channels, float* out, float* out_alpha, void* stream) {
+  if (int rc = check_views(cams_host, V, "raster_composite_feat")) return rc;
+  SIU3R_CHECK(cams_dev && tile_start && ids && mean2d && conic_op && feats && out && channels > 0, "raster_composite_feat: bad arguments");
+  const Geo geo = make_geo(cams_host[0].width, cams_host[0].height);
+  const int nchunk = (channels + CHUNK - 1) / CHUNK;
+  SIU3R_CHECK(nchunk <= 65535 && V <= 65535, "raster_composite_feat: too many channel chunks / views");
+  hipLaunchKernelGGL(composite_feat_kernel, dim3(geo.T, nchunk, V), dim3(256), 0, (hipStream_t)stream, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, mean2d,
+                     conic_op, feats, channels, G, out, out_alpha);
   SIU3R_LAUNCH_CHECK("siu3r_raster_composite_feat");
   return 0;
 }

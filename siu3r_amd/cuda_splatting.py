@@ -43,8 +43,10 @@ def get_projection_matrix(near, far, fov_x, fov_y) -> torch.Tensor:
 
 def render_cuda(extrinsics, intrinsics, near, far, image_shape, background_color, gaussian_means, gaussian_covariances,
                 gaussian_sh_coefficients, gaussian_opacities, use_sh: bool = True, cam_rot_delta=None, cam_trans_delta=None,
-                sh_band4: bool = False, return_aux: bool = False):
-    """reference signature cuda_splatting.py:46-60 (batch = views).  Returns (images [b,3,h,w], depths [b,h,w])."""
+                sh_band4: bool = False, return_aux: bool = False, entry_capacity=None):
+    """reference signature cuda_splatting.py:46-60 (batch = views).  Returns (images [b,3,h,w], depths [b,h,w]); return_aux adds the
+    per-call outputs (radii, n_touched, opacity, binning state).  entry_capacity: optional size of the coarse-bin entry buffers (an
+    overflow of the default bound is detected and the call repeated with the exact size)."""
     assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
     assert cam_rot_delta is None and cam_trans_delta is None, "pose gradients are training-only (out of scope)"
     b = extrinsics.shape[0]
@@ -58,23 +60,29 @@ def render_cuda(extrinsics, intrinsics, near, far, image_shape, background_color
     proj = get_projection_matrix(near.detach().float().cpu(), far.detach().float().cpu(), fov_x, fov_y)
     w2c = torch.linalg.inv(ext)
     full = proj @ w2c  # column-vector form of the reference's row-vector view @ proj (cuda_splatting.py:74-77)
+    # the reference's callers pass the same Gaussians expanded over the views (gaussian_renderer.py:50-67): consecutive views that
+    # share their Gaussian storage go through the rasterizer as ONE call (blockIdx.y = view), and are repacked (6-entry
+    # covariances, 'g xyz n -> g n xyz' coefficients (:65), a 157 MB copy at 524 288 Gaussians) once, not per view
+    groups, i = [], 0
+    while i < b:
+        key = (gaussian_means[i].data_ptr(), gaussian_covariances[i].data_ptr(), gaussian_sh_coefficients[i].data_ptr(), gaussian_opacities[i].data_ptr())
+        j = i + 1
+        while j < b and key == (gaussian_means[j].data_ptr(), gaussian_covariances[j].data_ptr(), gaussian_sh_coefficients[j].data_ptr(),
+                                gaussian_opacities[j].data_ptr()):
+            j += 1
+        groups.append((i, j))
+        i = j
     images, depths, aux = [], [], []
-    prev = None
-    for i in range(b):
-        means = gaussian_means[i]
-        # the reference's callers pass the same Gaussians expanded over the views: repack them (6-entry covariances, 'g xyz n ->
-        # g n xyz' coefficients (:65), a 157 MB copy at 524 288 Gaussians) once, not per view
-        key = (gaussian_covariances[i].data_ptr(), gaussian_sh_coefficients[i].data_ptr())
-        if prev is None or prev[0] != key:
-            prev = (key, raster.cov6_from_cov3x3(gaussian_covariances[i]), gaussian_sh_coefficients[i].permute(0, 2, 1).contiguous())
-        cov6, shs = prev[1], prev[2]
-        cam = raster.make_cam_k2(w2c[i], full[i], float(tan_x[i]), float(tan_y[i]), ext[i, :3, 3].tolist(),
-                                 background_color[i].detach().float().cpu().tolist(), w, h, sh_degree=degree, sh_band4=sh_band4)
-        out = raster.rasterize_k2(cam, means, cov6, shs, gaussian_opacities[i])
+    for (i0, i1) in groups:
+        cams = [raster.make_cam_k2(w2c[i], full[i], float(tan_x[i]), float(tan_y[i]), ext[i, :3, 3].tolist(),
+                                   background_color[i].detach().float().cpu().tolist(), w, h, sh_degree=degree, sh_band4=sh_band4)
+                for i in range(i0, i1)]
+        cov6 = raster.cov6_from_cov3x3(gaussian_covariances[i0])
+        shs = gaussian_sh_coefficients[i0].permute(0, 2, 1).contiguous()
+        out = raster.rasterize_views_k2(cams, gaussian_means[i0], cov6, shs, gaussian_opacities[i0], want_n_touched=return_aux,
+                                        entry_capacity=entry_capacity)
         images.append(out["image"])
         depths.append(out["depth"])
         aux.append(out)
-    res = (torch.stack(images), torch.stack(depths))
-    for out in aux:  # one synchronisation per call, after every view has been enqueued: the deferred pair-count check
-        out["state"]["D"]
+    res = (torch.cat(images), torch.cat(depths))
     return res + (aux,) if return_aux else res

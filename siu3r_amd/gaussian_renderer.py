@@ -50,28 +50,23 @@ class SplattingCUDA:
             depth = torch.stack(depths)
         if render_qc_logits:
             height, width = image_shape
-            all_qc, states = [], []
+            all_qc = []
             for i in range(b):
                 means, opac = gaussians.means[i], gaussians.opacities[i]
                 cov6 = raster.cov6_from_cov3x3(gaussians.covariances[i])
                 qcl = gaussians.seg_query_class_logits[i]  # [n, q, c]
                 n, q, c = qcl.shape
                 feats = qcl.reshape(n, q * c)
-                views = []
+                cams = []
                 for j in range(v):
                     K = intr[i, j].clone()
                     K[0, :] *= width
                     K[1, :] *= height
                     w2c = torch.linalg.inv(extrinsics[i, j])
-                    cam = raster.make_cam_k3(w2c, K[0, 0], K[1, 1], K[0, 2], K[1, 2], width, height, near_plane=near, far_plane=far)
-                    out = raster.rasterize_k3(cam, means, cov6, opac, feats)
-                    views.append(out["colors"])  # [h, w, q*c]
-                    states.append(out["state"])
-                stacked = torch.stack(views)  # [v, h, w, q*c]
+                    cams.append(raster.make_cam_k3(w2c, K[0, 0], K[1, 1], K[0, 2], K[1, 2], width, height, near_plane=near, far_plane=far))
+                out = raster.rasterize_views_k3(cams, means, cov6, opac, feats)  # all v views in one call: [v, h, w, q*c]
                 # reference layout 'n h w (q c) -> n q c h w' as a view of the channel-last buffer
-                all_qc.append(stacked.view(v, height, width, q, c).permute(0, 3, 4, 1, 2))
-            for st_ in states:  # deferred pair-count check (one synchronisation, after the last view was enqueued)
-                st_["D"]
+                all_qc.append(out["colors"].view(v, height, width, q, c).permute(0, 3, 4, 1, 2))
         return {"render_color": color, "render_depth": depth, "render_qc_logits": all_qc}
 
     __call__ = forward
@@ -130,7 +125,7 @@ def rasterize_splats(splats: dict, camtoworlds: torch.Tensor, Ks: torch.Tensor, 
     coeffs = torch.cat([splats["sh0"], splats["shN"]], 1).float() if "shN" in splats and splats["shN"] is not None else splats["sh0"].float()
     assert coeffs.shape[1] >= (sh_degree + 1) ** 2
     cols, alphas, visible, pairs = [], [], [], []
-    for c2w, K in zip(camtoworlds.cpu().float(), Ks.cpu().float()):
+    for c2w, K in zip(camtoworlds.cpu().float(), Ks.cpu().float()):  # colours are view-dependent (SH): one call per camera
         w2c = torch.linalg.inv(c2w)
         cam = raster.make_cam_k3(w2c, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), width, height, near_plane, far_plane,
                                  radius_clip=radius_clip)
@@ -140,6 +135,5 @@ def rasterize_splats(splats: dict, camtoworlds: torch.Tensor, Ks: torch.Tensor, 
         cols.append(o["colors"])
         alphas.append(o["alphas"][..., None])
         visible.append(o["state"]["tiles_touched"])
-        pairs.append(o["state"])
-    pairs = [st_["D"] for st_ in pairs]  # deferred pair-count read-back / overflow check, after the last view was enqueued
+        pairs.append(o["state"]["D"])
     return torch.stack(cols), torch.stack(alphas), dict(tiles_touched=visible, tile_pairs=pairs)

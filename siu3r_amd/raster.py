@@ -3,11 +3,13 @@
 Two conventions behind one tile-binned HIP renderer (include/siu3r_hip.h, siu3r_raster_cam):
   K2 = diff-gaussian-rasterization-w-pose semantics (reference call site src/models/cuda_splatting.py:90-118)
   K3 = gsplat.rasterization semantics (reference call site src/models/gaussian_renderer.py:92-106)
+All V views of a call travel through every launch together (the reference loops over views in Python,
+cuda_splatting.py:82-121): project -> one stable depth radix sort per view -> depth-ordered coarse bins -> composite.
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Optional
+from typing import Dict, List, Optional, Sequence
 
 import torch
 
@@ -23,7 +25,7 @@ def _set(arr, values):
         arr[i] = float(v)
 
 
-def make_cam_k2(w2c, full_proj, tanfovx, tanfovy, campos, bg, width, height, sh_degree=4, sh_band4=False) -> RasterCam:
+def make_cam_k2(w2c, full_proj, tanfovx, tanfovy, campos, bg, width, height, sh_degree=4, sh_band4=False, nt_post_blend=True) -> RasterCam:
     c = RasterCam()
     c.mode, c.width, c.height = 0, int(width), int(height)
     _set(c.w2c, w2c.reshape(-1).tolist())
@@ -34,6 +36,8 @@ def make_cam_k2(w2c, full_proj, tanfovx, tanfovy, campos, bg, width, height, sh_
     c.sh_degree, c.sh_band4, c.k2_znear_cull = int(sh_degree), int(bool(sh_band4)), 0.2
     c.alpha_min, c.alpha_max, c.t_min, c.dilation = 1.0 / 255.0, 0.99, 1e-4, 0.3
     c.eps2d, c.extent_sigma = 0.3, 3.33
+    c.near_plane = 0.2
+    c.nt_post_blend = int(bool(nt_post_blend))
     return c
 
 
@@ -47,6 +51,7 @@ def make_cam_k3(w2c, fx, fy, cx, cy, width, height, near_plane=0.01, far_plane=1
     c.extent_sigma, c.opacity_aware_extent = 3.33, int(bool(opacity_aware_extent))
     c.alpha_min, c.alpha_max, c.t_min, c.dilation = 1.0 / 255.0, 0.999, 1e-4, 0.3
     c.k2_znear_cull = 0.2
+    c.nt_post_blend = 1
     return c
 
 
@@ -56,79 +61,187 @@ def cov6_from_cov3x3(cov: torch.Tensor) -> torch.Tensor:
     return torch.stack((cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]), dim=-1).contiguous()
 
 
-class _State(dict):
-    """Per-view binning state.  "D" (the number of (tile, Gaussian) pairs) lives on the device until someone asks for it:
-    reading it is the only host synchronisation of a rendered view, and it is deferred to the first access."""
+def geometry(width: int, height: int, G: int) -> Dict[str, int]:
+    out = (C.c_int32 * 8)()
+    check(_lib.lib().siu3r_raster_geometry(int(width), int(height), int(G), out))
+    return dict(gw=out[0], gh=out[1], T=out[2], cb=out[3], NB=out[4], nchunks_sort=out[5], nchunks_bin=out[6], cam_bytes=out[7])
 
-    def __getitem__(self, k):
-        if k == "D" and not dict.__contains__(self, "D"):
-            d = int(dict.__getitem__(self, "D_dev").item())
-            if d > dict.__getitem__(self, "cap"):
-                raise RuntimeError(f"rasterizer pair buffers overflowed: D = {d} > capacity {dict.__getitem__(self, 'cap')} "
-                                   f"(pass a larger pair_capacity)")
-            dict.__setitem__(self, "D", d)
-        return dict.__getitem__(self, k)
+
+def default_entry_capacity(G: int) -> int:
+    """Coarse-bin entries per view (8 B each): a Gaussian lands in one 64 x 64 px bin unless it straddles a bin border;
+    3 per Gaussian covers the 2 M-Gaussian 1080p stress scene (large splats) with margin.  An overflow is detected after
+    the frame (stats) and the call is repeated with the exact count."""
+    return int(min(max(3 * G + 65536, 1 << 18), (1 << 31) - 1024))
 
 
 def default_pair_capacity(G: int) -> int:
-    """Upper bound used to size the key / id buffers without reading the pair count back: 8 pairs per Gaussian (the 2 M-Gaussian
-    1080p stress scene needs 6.7), at least 1 M.  96 B per Gaussian of HBM in the worst case."""
+    """(tile, Gaussian) pairs per view for the materialised tile lists (4 B each): 8 per Gaussian, at least 1 M."""
     return int(min(max(8 * G, 1 << 20), (1 << 31) - 1024))
 
 
-def _bin_and_sort(cam: RasterCam, means, cov6, opac, colors, channels, pair_capacity=None):
-    G = means.shape[0]
-    dev = means.device
-    gw, gh = (cam.width + TILE - 1) // TILE, (cam.height + TILE - 1) // TILE
-    T = gw * gh
-    cap = int(pair_capacity) if pair_capacity else default_pair_capacity(G)
+class RasterOverflow(RuntimeError):
+    pass
+
+
+class _State(dict):
+    """Buffers of one rasterizer call (V views).  The per-tile Gaussian lists are not needed to render an RGB view; they are
+    produced on first access of "tile_start" / "ids" (tests, exports).  "D" / "Gv" / "E" read the device-side totals."""
+
+    def stats(self) -> torch.Tensor:
+        if not dict.__contains__(self, "stats_host"):
+            dict.__setitem__(self, "stats_host", dict.__getitem__(self, "stats").cpu())
+        return dict.__getitem__(self, "stats_host")
+
+    def totals(self, k: int) -> List[int]:
+        return [int(x) for x in self.stats()[:, k].tolist()]
+
+    def verify(self):
+        """Raise when a capacity-bounded buffer overflowed (only needed by callers that passed check=False)."""
+        st = self.stats()
+        e_max, cap_e = int(st[:, 2].max()), dict.__getitem__(self, "cap_e")
+        if e_max > cap_e:
+            raise RasterOverflow(f"rasterizer coarse-bin entries overflowed: E = {e_max} > entry_capacity {cap_e} (pass entry_capacity >= {e_max})")
+
+    def _lists(self):
+        if not dict.__contains__(self, "ids"):
+            V, T = dict.__getitem__(self, "V"), dict.__getitem__(self, "T")
+            dev = dict.__getitem__(self, "stats").device
+            cap_d = dict.__getitem__(self, "cap_d_hint") or max(1, max(self.totals(1)))
+            while True:
+                tcount = torch.empty((V, T), dtype=torch.int32, device=dev)
+                tstart = torch.empty((V, T + 2), dtype=torch.int32, device=dev)
+                ids = torch.empty((V, cap_d), dtype=torch.int32, device=dev)
+                check(_lib.lib().siu3r_raster_tile_lists(dict.__getitem__(self, "cams"), V, _p(dict.__getitem__(self, "bin_start")),
+                                                         _p(dict.__getitem__(self, "entries")), dict.__getitem__(self, "cap_e"), _p(tcount),
+                                                         _p(tstart), _p(ids), cap_d, _p(dict.__getitem__(self, "stats")), _stream()))
+                if dict.__getitem__(self, "defer"):
+                    break
+                d_max = int(tstart[:, T + 1].max())
+                if d_max <= cap_d:
+                    break
+                cap_d = d_max  # the bound was too small: repeat with the exact pair count
+            dict.__setitem__(self, "cap_d", cap_d)
+            dict.__setitem__(self, "tile_start_all", tstart)
+            dict.__setitem__(self, "ids_all", ids)
+            dict.__setitem__(self, "ids", ids[0])
+            dict.__setitem__(self, "tile_start", tstart[0])
+
+    def __getitem__(self, k):
+        if k in ("ids", "tile_start", "ids_all", "tile_start_all", "cap_d"):
+            self._lists()
+        elif k == "D":
+            return self.totals(1)[0]
+        elif k == "Gv":
+            return self.totals(0)[0]
+        elif k == "E":
+            return self.totals(2)[0]
+        return dict.__getitem__(self, k)
+
+
+def _cam_array(cams: Sequence[RasterCam]):
+    arr = (RasterCam * len(cams))()
+    for i, c in enumerate(cams):
+        C.memmove(C.byref(arr, i * C.sizeof(RasterCam)), C.byref(c), C.sizeof(RasterCam))
+    return arr
+
+
+def _project_sort_bin(cams: Sequence[RasterCam], means, cov6, opac, colors, channels, entry_capacity=None, check_overflow=True) -> _State:
+    V, G, dev = len(cams), means.shape[0], means.device
+    arr = _cam_array(cams)
+    geo = geometry(cams[0].width, cams[0].height, G)
     f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
-    st = _State(mean2d=f(G, 2), conic_op=f(G, 4), depth=f(G), radii=i32(G, 2), rect=i32(G, 4), tiles_touched=i32(G),
-                rgb=f(G, 3) if cam.mode == 0 else None, tile_count=i32(8 * T), tile_start=i32(T + 2), cursor=i32(8 * T), cap=cap)
-    check(_lib.lib().siu3r_raster_bin(C.byref(cam), G, _p(means), _p(cov6), _p(opac), _p(colors), channels, _p(st["mean2d"]),
-                                      _p(st["conic_op"]), _p(st["depth"]), _p(st["radii"]), _p(st["rect"]), _p(st["tiles_touched"]),
-                                      _p(st["rgb"]), _p(st["tile_count"]), _p(st["tile_start"]), _p(st["cursor"]), cap, _stream()))
-    # no read-back of D here (the CUDA originals resize their buffers behind one): the buffers are sized by the bound above, the
-    # kernels clamp to it, and D is checked when it is first asked for (SplattingCUDA.forward does so once per call, after the
-    # last view has been enqueued)
-    st["D_dev"] = st["tile_start"][T + 1]
-    st["keys"] = torch.empty((cap,), dtype=torch.int64, device=dev)
-    st["ids"] = i32(cap)
-    check(_lib.lib().siu3r_raster_sort(C.byref(cam), G, _p(st["rect"]), _p(st["depth"]), _p(st["tile_start"]), _p(st["cursor"]),
-                                       _p(st["keys"]), _p(st["ids"]), cap, _stream()))
+    cap_e = int(entry_capacity) if entry_capacity else default_entry_capacity(G)
+    mode0 = cams[0].mode == 0
+    st = _State(V=V, G=G, T=geo["T"], geo=geo, cams=arr, cams_dev=torch.empty((V * geo["cam_bytes"],), dtype=torch.uint8, device=dev),
+                mean2d=f(V, G, 2), conic_op=f(V, G, 4), depth=f(V, G), radii=i32(V, G, 2), rect=i32(V, G, 4), tiles_touched_all=i32(V, G),
+                rgb=f(V, G, 3) if mode0 else None, keys=i32(V, G), keys_b=i32(V, G), sorted_ids=i32(V, G), ids_b=i32(V, G),
+                stats=torch.empty((V, 4), dtype=torch.int64, device=dev), defer=not check_overflow, cap_d_hint=None)
+    st["tiles_touched"] = st["tiles_touched_all"][0]
+    lib = _lib.lib()
+    check(lib.siu3r_raster_project(arr, V, _p(st["cams_dev"]), G, _p(means), _p(cov6), _p(opac), _p(colors), channels, _p(st["mean2d"]),
+                                   _p(st["conic_op"]), _p(st["depth"]), _p(st["radii"]), _p(st["rect"]), _p(st["tiles_touched_all"]),
+                                   _p(st["rgb"]), _p(st["keys"]), _p(st["stats"]), _stream()))
+    rs_hist, rs_tot = i32(V, 256, geo["nchunks_sort"]), i32(V, 256)
+    check(lib.siu3r_raster_sort(V, G, _p(st["keys"]), _p(st["keys_b"]), _p(st["sorted_ids"]), _p(st["ids_b"]), _p(rs_hist), _p(rs_tot), _stream()))
+    bin_hist, bin_tot = i32(V, geo["NB"], geo["nchunks_bin"]), i32(V, geo["NB"])
+    st["bin_start"] = i32(V, geo["NB"] + 1)
+    st["entries"] = torch.empty((V, cap_e, 2), dtype=torch.int32, device=dev)
+    st["cap_e"] = cap_e
+    check(lib.siu3r_raster_bin(arr, V, G, _p(st["keys"]), _p(st["sorted_ids"]), _p(st["rect"]), _p(bin_hist), _p(bin_tot), _p(st["bin_start"]),
+                               _p(st["entries"]), cap_e, _p(st["stats"]), _stream()))
     return st
 
 
-def rasterize_k2(cam: RasterCam, means, cov6, shs, opacities) -> Dict[str, torch.Tensor]:
-    """means [G,3], cov6 [G,6], shs [G,ncoef,3], opacities [G] (fp32, GPU) -> image [3,H,W], radii [G,2] i32,
-    depth [H,W], opacity [H,W], n_touched [G] i32 (+ binning state for parity tests / HBM accounting)."""
+def _with_retry(run, entry_capacity, check_overflow):
+    """run(entry_capacity) -> result dict with "state".  The coarse-bin entries are sized by a bound; when a frame overflows it (the
+    kernels drop the excess and flag it) the whole call is repeated once with the exact count: the CUDA originals resize their
+    buffers behind a device-to-host copy instead."""
+    out = run(entry_capacity)
+    if not check_overflow:
+        return out
+    st = out["state"]
+    e_max = max(st.totals(2))
+    if e_max > st["cap_e"]:
+        out = run(e_max)
+        out["state"].verify()
+    return out
+
+
+def rasterize_views_k2(cams: Sequence[RasterCam], means, cov6, shs, opacities, want_n_touched=True, entry_capacity=None,
+                       check_overflow=True) -> Dict[str, torch.Tensor]:
+    """V views of one Gaussian set.  means [G,3], cov6 [G,6], shs [G,ncoef,3], opacities [G] (fp32, GPU) -> image [V,3,H,W],
+    radii [V,G,2] i32, depth [V,H,W], opacity [V,H,W], n_touched [V,G] i32 (None when not wanted) + the call's state."""
     _gpu(means, cov6, shs, opacities)
     means, cov6, shs, opacities = (t.contiguous().float() for t in (means, cov6, shs, opacities))
-    G, dev = means.shape[0], means.device
-    st = _bin_and_sort(cam, means, cov6, opacities, shs, shs.shape[1])
-    H, W = cam.height, cam.width
-    image = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-    depth = torch.empty((H, W), dtype=torch.float32, device=dev)
-    alpha = torch.empty((H, W), dtype=torch.float32, device=dev)
-    n_touched = torch.empty((G,), dtype=torch.int32, device=dev)
-    check(_lib.lib().siu3r_raster_composite_rgb(C.byref(cam), _p(st["tile_start"]), _p(st["ids"]), _p(st["mean2d"]), _p(st["conic_op"]),
-                                                _p(st["depth"]), _p(st["rgb"]), _p(image), _p(depth), _p(alpha), _p(n_touched), G, _stream()))
-    return dict(image=image, radii=st["radii"], depth=depth, opacity=alpha, n_touched=n_touched, state=st)
+    V, G, dev = len(cams), means.shape[0], means.device
+    H, W = cams[0].height, cams[0].width
+
+    def run(cap):
+        st = _project_sort_bin(cams, means, cov6, opacities, shs, shs.shape[1], cap, check_overflow)
+        image = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
+        depth = torch.empty((V, H, W), dtype=torch.float32, device=dev)
+        alpha = torch.empty((V, H, W), dtype=torch.float32, device=dev)
+        n_touched = torch.empty((V, G), dtype=torch.int32, device=dev) if want_n_touched else None
+        check(_lib.lib().siu3r_raster_composite_rgb(st["cams"], V, _p(st["cams_dev"]), G, _p(st["bin_start"]), _p(st["entries"]), st["cap_e"],
+                                                    _p(st["mean2d"]), _p(st["conic_op"]), _p(st["depth"]), _p(st["rgb"]), _p(image), _p(depth),
+                                                    _p(alpha), _p(n_touched), _stream()))
+        return dict(image=image, radii=st["radii"], depth=depth, opacity=alpha, n_touched=n_touched, state=st)
+
+    return _with_retry(run, entry_capacity, check_overflow)
 
 
-def rasterize_k3(cam: RasterCam, means, cov6, opacities, feats) -> Dict[str, torch.Tensor]:
-    """feats [G,C] -> colors [H,W,C], alphas [H,W] (+ state)."""
+def rasterize_k2(cam: RasterCam, means, cov6, shs, opacities, **kw) -> Dict[str, torch.Tensor]:
+    """single view: image [3,H,W], radii [G,2], depth [H,W], opacity [H,W], n_touched [G] (+ state)."""
+    o = rasterize_views_k2([cam], means, cov6, shs, opacities, **kw)
+    return dict(image=o["image"][0], radii=o["radii"][0], depth=o["depth"][0], opacity=o["opacity"][0],
+                n_touched=None if o["n_touched"] is None else o["n_touched"][0], state=o["state"])
+
+
+def rasterize_views_k3(cams: Sequence[RasterCam], means, cov6, opacities, feats, entry_capacity=None, pair_capacity=None,
+                       check_overflow=True) -> Dict[str, torch.Tensor]:
+    """feats [G,C] -> colors [V,H,W,C], alphas [V,H,W] (+ state).  gsplat semantics: the per-tile lists are materialised once
+    and shared by every 32-channel chunk."""
     _gpu(means, cov6, opacities, feats)
     means, cov6, opacities, feats = (t.contiguous().float() for t in (means, cov6, opacities, feats))
-    dev = means.device
-    st = _bin_and_sort(cam, means, cov6, opacities, None, 0)
-    H, W, Cc = cam.height, cam.width, feats.shape[1]
-    out = torch.empty((H, W, Cc), dtype=torch.float32, device=dev)
-    alpha = torch.empty((H, W), dtype=torch.float32, device=dev)
-    check(_lib.lib().siu3r_raster_composite_feat(C.byref(cam), _p(st["tile_start"]), _p(st["ids"]), _p(st["mean2d"]), _p(st["conic_op"]),
-                                                 _p(feats), Cc, _p(out), _p(alpha), _stream()))
-    return dict(colors=out, alphas=alpha, radii=st["radii"], state=st)
+    V, G, dev = len(cams), means.shape[0], means.device
+    H, W, Cc = cams[0].height, cams[0].width, feats.shape[1]
+
+    def run(cap):
+        st = _project_sort_bin(cams, means, cov6, opacities, None, 0, cap, check_overflow)
+        st["cap_d_hint"] = int(pair_capacity) if pair_capacity else default_pair_capacity(G)
+        out = torch.empty((V, H, W, Cc), dtype=torch.float32, device=dev)
+        alpha = torch.empty((V, H, W), dtype=torch.float32, device=dev)
+        check(_lib.lib().siu3r_raster_composite_feat(st["cams"], V, _p(st["cams_dev"]), G, _p(st["tile_start_all"]), _p(st["ids_all"]), st["cap_d"],
+                                                     _p(st["mean2d"]), _p(st["conic_op"]), _p(feats), Cc, _p(out), _p(alpha), _stream()))
+        return dict(colors=out, alphas=alpha, radii=st["radii"], state=st)
+
+    return _with_retry(run, entry_capacity, check_overflow)
+
+
+def rasterize_k3(cam: RasterCam, means, cov6, opacities, feats, **kw) -> Dict[str, torch.Tensor]:
+    o = rasterize_views_k3([cam], means, cov6, opacities, feats, **kw)
+    return dict(colors=o["colors"][0], alphas=o["alphas"][0], radii=o["radii"][0], state=o["state"])
 
 
 def scale_inplace_(x: torch.Tensor, s: float):

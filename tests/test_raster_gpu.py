@@ -31,9 +31,11 @@ def _k3_cam(H, W, seed, near=1.0, far=1000.0):
 
 
 def _check_lists(st, ref):
+    """per-tile ranges and front-to-back Gaussian lists (materialised by siu3r_raster_tile_lists: wave ballot + prefix popcount over the
+    depth-ordered coarse bins) against the oracle's (tile, depth, id) sort"""
     T1 = ref["tile_start"].shape[0]
-    assert np.array_equal(st["tile_start"].cpu().numpy()[:T1], ref["tile_start"]), "tile ranges differ"
     assert st["D"] == ref["D"]
+    assert np.array_equal(st["tile_start"].cpu().numpy()[:T1], ref["tile_start"]), "tile ranges differ"
     assert np.array_equal(st["ids"].cpu().numpy()[: ref["D"]], ref["ids"]), "per-tile sorted Gaussian lists differ"
 
 
@@ -165,8 +167,9 @@ def test_viewer_render_semantics(degree):
     assert float(colors.min()) >= 0.0 and ref["D"] > 1000
 
 
-def test_pair_capacity_overflow_is_detected():
-    """The pair buffers are sized by a bound and D is read back late: an undersized bound must raise, never write out of bounds."""
+def test_capacity_overflow_is_detected_and_retried():
+    """The coarse-bin entry buffers and the tile-list buffers are sized by bounds and checked after the frame: an undersized bound
+    never writes out of range, is reported (check_overflow=False + verify()), and by default the call is repeated with the exact size."""
     from siu3r_amd import raster
 
     G, H, W = 4000, 96, 128
@@ -174,12 +177,127 @@ def test_pair_capacity_overflow_is_detected():
     cam = _k3_cam(H, W, 2)
     args = (cam, means.cuda(), raster.cov6_from_cov3x3(cov.cuda()), opac.cuda(), torch.rand(G, 5).cuda())
     full = raster.rasterize_k3(*args)
-    D = full["state"]["D"]
-    assert D > 2000
-    st = raster._bin_and_sort(cam, args[1].contiguous(), args[2], args[3], None, 0, pair_capacity=D // 2)
+    D, E = full["state"]["D"], full["state"]["E"]
+    assert D > 2000 and E >= full["state"]["Gv"] > 0
+    # undersized entry buffer, no check: flagged, nothing written beyond the buffer (the guard element stays intact)
+    small = raster.rasterize_k3(*args, entry_capacity=E // 2, check_overflow=False)
     torch.cuda.synchronize()
-    assert int(st["tile_start"][:-1].max()) <= D // 2          # every range was clamped to the capacity
-    with pytest.raises(RuntimeError, match="overflowed"):
-        st["D"]
-    exact = raster._bin_and_sort(cam, args[1].contiguous(), args[2], args[3], None, 0, pair_capacity=D)
-    assert exact["D"] == D and torch.equal(exact["ids"][:D], full["state"]["ids"][:D])
+    with pytest.raises(raster.RasterOverflow, match="overflowed"):
+        small["state"].verify()
+    # default: the call is repeated with the exact count and gives the same answer, lists included
+    retry = raster.rasterize_k3(*args, entry_capacity=E // 2, pair_capacity=D // 3)
+    assert retry["state"]["cap_e"] == E and retry["state"]["cap_d"] == D
+    assert torch.equal(retry["colors"], full["colors"]) and torch.equal(retry["alphas"], full["alphas"])
+    assert torch.equal(retry["state"]["ids"][:D], full["state"]["ids"][:D])
+    k2 = _k2_cam(H, W, seed=2)
+    shs = sh.permute(0, 2, 1).contiguous().cuda()
+    a = raster.rasterize_k2(k2, args[1], args[2], shs, args[3])
+    b = raster.rasterize_k2(k2, args[1], args[2], shs, args[3], entry_capacity=a["state"]["E"] // 3)
+    assert torch.equal(a["image"], b["image"]) and torch.equal(a["n_touched"], b["n_touched"])
+
+
+def test_views_batched_equals_view_by_view():
+    """V cameras in one call (blockIdx.y = view) == V single-view calls, bit for bit (K2 and K3)."""
+    from siu3r_amd import raster
+
+    G, H, W = 9000, 112, 144
+    means, cov, opac, sh = random_scene(G, seed=21)
+    cov6 = raster.cov6_from_cov3x3(cov).cuda()
+    shs = sh.permute(0, 2, 1).contiguous().cuda()
+    cams = [_k2_cam(H, W, seed=s_) for s_ in range(3)]
+    allv = raster.rasterize_views_k2(cams, means.cuda(), cov6, shs, opac.cuda())
+    for i, cam in enumerate(cams):
+        one = raster.rasterize_k2(cam, means.cuda(), cov6, shs, opac.cuda())
+        for k in ("image", "depth", "opacity", "radii", "n_touched"):
+            assert torch.equal(allv[k][i], one[k]), (k, i)
+    feats = torch.rand(G, 40, generator=torch.Generator().manual_seed(4)).cuda()
+    cams3 = [_k3_cam(H, W, seed=s_, near=0.5, far=50.0) for s_ in range(3)]
+    allv = raster.rasterize_views_k3(cams3, means.cuda(), cov6, opac.cuda(), feats)
+    for i, cam in enumerate(cams3):
+        one = raster.rasterize_k3(cam, means.cuda(), cov6, opac.cuda(), feats)
+        assert torch.equal(allv["colors"][i], one["colors"]) and torch.equal(allv["alphas"][i], one["alphas"])
+        D = one["state"]["D"]
+        assert torch.equal(allv["state"]["ids_all"][i, :D], one["state"]["ids"][:D])
+
+
+def test_crowded_tile_and_equal_depths():
+    """More than 8192 Gaussians on one tile (the old per-tile LDS sort's limit) and many exactly equal depths (ties are broken by
+    the Gaussian index): lists, n_touched and maps against the oracle."""
+    from oracle import raster_oracle as RO
+    from siu3r_amd import raster
+
+    G, H, W = 12000, 64, 80
+    g = torch.Generator().manual_seed(5)
+    means = torch.stack(((torch.rand(G, generator=g) - 0.5) * 0.05, (torch.rand(G, generator=g) - 0.5) * 0.05,
+                         2.0 + torch.randint(0, 40, (G,), generator=g).float() * 0.25), -1)  # 40 distinct depths -> ~300-way ties
+    s = 0.002 + 0.004 * torch.rand(G, 3, generator=g)
+    cov = torch.diag_embed(s * s)
+    opac = 0.01 + 0.05 * torch.rand(G, generator=g)  # faint: pixels do not saturate, the whole list is blended
+    sh = (torch.rand(G, 3, 25, generator=g) - 0.5)
+    c2w = torch.eye(4)
+    from siu3r_amd import cuda_splatting as cs
+
+    K = default_K()[None]
+    fov = cs.get_fov(K)
+    tan = (0.5 * fov).tan()[0]
+    proj = cs.get_projection_matrix(torch.tensor([1.0]), torch.tensor([1000.0]), fov[:, 0], fov[:, 1])[0]
+    cam = raster.make_cam_k2(torch.eye(4), proj, float(tan[0]), float(tan[1]), [0, 0, 0], [0, 0, 0], W, H, sh_degree=4)
+    cov6 = raster.cov6_from_cov3x3(cov)
+    shs = sh.permute(0, 2, 1).contiguous()
+    ref = RO.forward(cam, means.numpy(), cov6.numpy(), opac.numpy(), shs.numpy())
+    assert int(np.diff(ref["tile_start"]).max()) > 8192, "scene is not crowded enough"
+    out = raster.rasterize_k2(cam, means.cuda(), cov6.cuda(), shs.cuda(), opac.cuda())
+    _check_lists(out["state"], ref)
+    assert np.array_equal(out["n_touched"].cpu().numpy(), ref["n_touched"])
+    assert float(np.abs(out["image"].cpu().numpy() - ref["image"]).max()) <= 5e-6
+    assert float(np.abs(out["opacity"].cpu().numpy() - ref["alpha"]).max()) <= 5e-6
+
+
+@pytest.mark.parametrize("post", [True, False], ids=["post_blend", "pre_blend"])
+def test_n_touched_gate_is_a_parameter(post):
+    """n_touched counts a pixel while the transmittance after (MonoGS fork: `test_T > 0.5f`) or before the blend exceeds 0.5:
+    an unpinned constant of the fork, exposed as raster_cam.nt_post_blend on both sides."""
+    from oracle import raster_oracle as RO
+    from siu3r_amd import raster
+
+    means, cov, opac, sh = random_scene(8000, seed=13)
+    cam = _k2_cam(96, 128, seed=4)
+    cam.nt_post_blend = int(post)
+    cov6 = raster.cov6_from_cov3x3(cov)
+    shs = sh.permute(0, 2, 1).contiguous()
+    ref = RO.forward(cam, means.numpy(), cov6.numpy(), opac.numpy(), shs.numpy())
+    out = raster.rasterize_k2(cam, means.cuda(), cov6.cuda(), shs.cuda(), opac.cuda())
+    assert np.array_equal(out["n_touched"].cpu().numpy(), ref["n_touched"])
+    assert int(ref["n_touched"].sum()) > 0
+
+
+def test_splatting_cuda_colour_against_oracle():
+    """SplattingCUDA.forward (reference gaussian_renderer.py:29-116) end to end: x10 in-place rescale, near = 1, fov / projection from the
+    normalised intrinsics, all views of a batch item in one rasterizer call, clamp -- rendered colour and depth against the C oracle fed
+    with independently prepared cameras."""
+    from oracle import raster_oracle as RO
+    from siu3r_amd import cuda_splatting as cs, raster
+    from siu3r_amd.gaussian_renderer import SplattingCUDA
+    from siu3r_amd.gaussians_types import Gaussians
+
+    H, W, G, V = 96, 128, 6000, 3
+    means, cov, opac, sh = random_scene(G, seed=17, spread=0.15, depth=(0.15, 0.8), scale=(0.001, 0.01))
+    g = Gaussians(means=means[None].cuda(), covariances=cov[None].cuda(), harmonics=sh[None].cuda(), opacities=opac[None].cuda(), scales=None, rotations=None)
+    ext = torch.stack([look_at_camera(s_, 0.02) for s_ in range(V)])[None]
+    K = default_K()[None, None].repeat(1, V, 1, 1)
+    out = SplattingCUDA().forward(g, ext, K, (H, W), render_color=True)
+    col, dep = out["render_color"][0].cpu().numpy(), out["render_depth"][0].cpu().numpy()
+    cov6 = raster.cov6_from_cov3x3(cov * 100.0).numpy()
+    shs = sh.permute(0, 2, 1).contiguous().numpy()
+    for v in range(V):
+        e = ext[0, v].clone()
+        e[:3, 3] *= 10.0
+        fov = cs.get_fov(K[0, v][None])
+        tan = (0.5 * fov).tan()[0]
+        proj = cs.get_projection_matrix(torch.tensor([1.0]), torch.tensor([1000.0]), fov[:, 0], fov[:, 1])[0]
+        w2c = torch.linalg.inv(e)
+        cam = raster.make_cam_k2(w2c, proj @ w2c, float(tan[0]), float(tan[1]), e[:3, 3].tolist(), [0, 0, 0], W, H, sh_degree=4)
+        ref = RO.forward(cam, (means * 10.0).numpy(), cov6, opac.numpy(), shs, want_lists=False)
+        assert ref["D"] > 1000
+        assert float(np.abs(col[v] - np.clip(ref["image"], 0.0, 1.0)).max()) <= 5e-6
+        assert float(np.abs(dep[v] - ref["depth"]).max()) <= 5e-5 * max(1.0, float(ref["depth"].max()))
