@@ -186,15 +186,16 @@ typedef struct {
 /* frame geometry / workspace sizes: out8 = {gw, gh, T = tiles, cb = coarse-bin edge in tiles, NB = coarse bins,
  * nchunks_sort (columns of rs_hist), nchunks_bin (columns of bin_hist), sizeof(siu3r_raster_cam)} */
 int siu3r_raster_geometry(int width, int height, int64_t G, int32_t* out8);
-/* stage 1: project G Gaussians (means [G,3], cov6 [G,6] upper-triangular, opacities [G], colors: mode 0 SH [G,channels,3],
- * mode 1 unused; shared by the V views) for every view.  cams_host: V structs in HOST memory, copied to cams_dev (device,
- * V * sizeof(siu3r_raster_cam) bytes) on the stream.  Outputs, all [V, G, ...]: mean2d [.,2], conic_op [.,4], depth, radii [.,2] i32,
- * rect [.,4] i32 (tile rect [min,max)), tiles_touched i32, rgb [.,3] (mode 0), keys u32 (depth bits; 0xffffffff = culled).
- * stats: u64 [V,4] = {visible Gaussians, tile pairs D, coarse entries E (stage 3), flags: bit 0 entries overflowed cap_e,
- * bit 1 tile lists overflowed cap_d}; zeroed here. */
-int siu3r_raster_project(const siu3r_raster_cam* cams_host, int V, void* cams_dev, int64_t G, const float* means, const float* cov6,
-                         const float* opacities, const float* colors, int channels, float* mean2d, float* conic_op, float* depth,
-                         int32_t* radii, int32_t* rect, int32_t* tiles_touched, float* rgb, uint32_t* keys, uint64_t* stats, void* stream);
+/* stage 1: project G Gaussians (means [G,3]; cov: cov_stride 6 = upper-triangular (xx,xy,xz,yy,yz,zz), 9 = row-major 3x3;
+ * opacities [G]; colors: mode 0 SH coefficients, sh_planar 0 = [G,channels,3] (the layout of cuda_splatting.py:65), 1 = [G,3,25]
+ * (Gaussians.harmonics as stored), mode 1 unused; all shared by the V views) for every view.  cams_host: V structs in HOST memory,
+ * copied to cams_dev (device, V * sizeof(siu3r_raster_cam) bytes) on the stream.  Outputs, all [V, G, ...]: rec fp32 [.,12] = {mean2d x, y,
+ * depth, 0 | conic a, b, c, opacity | r, g, b, 0} (16-byte aligned), radii [.,2] i32, rect [.,4] i32 (tile rect [min,max)),
+ * tiles_touched i32, keys u32 (depth bits; 0xffffffff = culled).  stats: u64 [V,4] = {visible Gaussians, tile pairs D, coarse
+ * entries E (stage 3), flags: bit 0 entries overflowed cap_e, bit 1 tile lists overflowed cap_d}; zeroed here. */
+int siu3r_raster_project(const siu3r_raster_cam* cams_host, int V, void* cams_dev, int64_t G, const float* means, const float* cov,
+                         int cov_stride, const float* opacities, const float* colors, int channels, int sh_planar, float* rec,
+                         int32_t* radii, int32_t* rect, int32_t* tiles_touched, uint32_t* keys, uint64_t* stats, void* stream);
 /* stage 2: per view, stable LSD radix sort (4 x 8 bits) of keys_a [V,G] with the Gaussian index as payload; keys_b / ids_a / ids_b
  * [V,G] ping-pong buffers; rs_hist i32 [V,256,nchunks_sort], rs_tot i32 [V,256].  Result (depth, id)-ordered in keys_a / ids_a. */
 int siu3r_raster_sort(int V, int64_t G, uint32_t* keys_a, uint32_t* keys_b, int32_t* ids_a, int32_t* ids_b, int32_t* rs_hist,
@@ -206,16 +207,16 @@ int siu3r_raster_bin(const siu3r_raster_cam* cams_host, int V, int64_t G, const 
                      int32_t* bin_hist, int32_t* bin_tot, int32_t* bin_start, void* entries, int64_t cap_e, uint64_t* stats, void* stream);
 /* stage 4 (mode 0): image [V,3,H,W], depth [V,H,W], accumulated opacity [V,H,W], n_touched [V,G] i32 (NULL = not wanted) */
 int siu3r_raster_composite_rgb(const siu3r_raster_cam* cams_host, int V, const void* cams_dev, int64_t G, const int32_t* bin_start,
-                               const void* entries, int64_t cap_e, const float* mean2d, const float* conic_op, const float* depth,
-                               const float* rgb, float* image, float* out_depth, float* out_alpha, int32_t* n_touched, void* stream);
+                               const void* entries, int64_t cap_e, const float* rec, float* image, float* out_depth, float* out_alpha,
+                               int32_t* n_touched, void* stream);
 /* per-tile Gaussian lists, front to back (wave ballot + prefix popcount over the coarse bins): tile_count i32 [V,T] workspace,
  * tile_start i32 [V,T+2] ([0..T] clamped to cap_d, [T+1] = true pair count), ids i32 [V,cap_d] */
 int siu3r_raster_tile_lists(const siu3r_raster_cam* cams_host, int V, const int32_t* bin_start, const void* entries, int64_t cap_e,
                             int32_t* tile_count, int32_t* tile_start, int32_t* ids, int64_t cap_d, uint64_t* stats, void* stream);
 /* stage 4 (mode 1): feats [G,channels] -> out [V,H,W,channels] (+ alphas [V,H,W]), 32 channels per pass over the tile lists */
 int siu3r_raster_composite_feat(const siu3r_raster_cam* cams_host, int V, const void* cams_dev, int64_t G, const int32_t* tile_start,
-                                const int32_t* ids, int64_t cap_d, const float* mean2d, const float* conic_op, const float* feats,
-                                int channels, float* out, float* out_alpha, void* stream);
+                                const int32_t* ids, int64_t cap_d, const float* rec, const float* feats, int channels, float* out,
+                                float* out_alpha, void* stream);
 /* x *= s in place (the reference rescales the scene x10 in place, src/models/gaussian_renderer.py:43-46) */
 int siu3r_scale_inplace(float* x, int64_t n, float s, void* stream);
 /* query-class-logit lifting (reference src/pipeline.py:137-193): rendered [V,H,W,q*C] -> sem_id, ins_id int64 [V,H,W];

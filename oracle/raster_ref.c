@@ -100,22 +100,28 @@ static void sh_to_rgb(const raster_cam* c, const float* mean, const float* sh, f
   }
 }
 
-/* exp(x) for x <= 0 from plain fp32 operations only (the HIP renderer uses the very same sequence, so alpha, the
- * transmittance chain and hence n_touched are bit-identical on both sides): 2^(x*log2e), degree-7 Taylor of 2^f. */
+/* exp(x) for x <= 0 from correctly rounded fp32 operations only (fmaf: one rounding, like the GPU's v_fma_f32; the HIP renderer
+ * uses the very same sequence, so alpha, the transmittance chain and hence n_touched are bit-identical on both sides):
+ * 2^(x*log2e), degree-7 Taylor of 2^f as a Horner chain of fused multiply-adds. */
 static float exp_det(float x) {
   if (x < -87.0f) return 0.0f;
   const float y = x * 1.4426950408889634f;
   const float n = floorf(y + 0.5f);
   const float f = y - n;
   float p = 1.52527338e-5f;
-  p = p * f + 1.54035304e-4f;
-  p = p * f + 1.33335581e-3f;
-  p = p * f + 9.61812911e-3f;
-  p = p * f + 5.55041087e-2f;
-  p = p * f + 2.40226507e-1f;
-  p = p * f + 6.93147181e-1f;
-  p = p * f + 1.0f;
+  p = fmaf(p, f, 1.54035304e-4f);
+  p = fmaf(p, f, 1.33335581e-3f);
+  p = fmaf(p, f, 9.61812911e-3f);
+  p = fmaf(p, f, 5.55041087e-2f);
+  p = fmaf(p, f, 2.40226507e-1f);
+  p = fmaf(p, f, 6.93147181e-1f);
+  p = fmaf(p, f, 1.0f);
   return ldexpf(p, (int)n);
+}
+/* q = 0.5 (a dx^2 + c dy^2) + b dx dy in the fused order shared with the HIP renderer */
+static float conic_sigma(float ca, float cb, float cc, float dx, float dy) {
+  const float q = fmaf(cc * dy, dy, (ca * dx) * dx);
+  return fmaf(cb * dx, dy, 0.5f * q);
 }
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -298,21 +304,21 @@ int64_t raster_ref_forward(const raster_cam* c, int64_t G, const float* means, c
           const float dx = q->mx - pxf, dy = q->my - pyf;
           float a;
           if (c->mode == 0) {
-            const float power = -0.5f * (q->ca * dx * dx + q->cc * dy * dy) - q->cb * dx * dy;
+            const float power = -conic_sigma(q->ca, q->cb, q->cc, dx, dy);
             if (power > 0.0f) continue;
             a = fminf(c->alpha_max, q->opacity * exp_det(power));
           } else {
-            const float sigma = 0.5f * (q->ca * dx * dx + q->cc * dy * dy) + q->cb * dx * dy;
+            const float sigma = conic_sigma(q->ca, q->cb, q->cc, dx, dy);
             if (sigma < 0.0f) continue;
             a = fminf(c->alpha_max, q->opacity * exp_det(-sigma));
           }
           if (a < c->alpha_min) continue;
-          const float nT = Tr * (1.0f - a);
+          const float nT = fmaf(-Tr, a, Tr); /* T (1 - a) */
           if (c->mode == 0 ? (nT < c->t_min) : (nT <= c->t_min)) break;
           const float wgt = a * Tr;
           if (c->mode == 0) {
-            for (int k = 0; k < 3; ++k) acc[k] += rgb[3 * g + k] * wgt;
-            dacc += q->depth * wgt;
+            for (int k = 0; k < 3; ++k) acc[k] = fmaf(rgb[3 * g + k], wgt, acc[k]);
+            dacc = fmaf(q->depth, wgt, dacc);
             oacc += wgt;
             if (n_touched && (c->nt_post_blend ? nT : Tr) > 0.5f) {
 #ifdef _OPENMP
@@ -322,7 +328,7 @@ int64_t raster_ref_forward(const raster_cam* c, int64_t G, const float* means, c
             }
           } else {
             const float* f = colors + (size_t)g * channels;
-            for (int k = 0; k < C; ++k) acc[k] += f[k] * wgt;
+            for (int k = 0; k < C; ++k) acc[k] = fmaf(f[k], wgt, acc[k]);
             oacc += wgt;
           }
           Tr = nT;
@@ -330,7 +336,7 @@ int64_t raster_ref_forward(const raster_cam* c, int64_t G, const float* means, c
         const size_t pix = (size_t)py * W + px;
         if (image) {
           if (c->mode == 0)
-            for (int k = 0; k < 3; ++k) image[(size_t)k * H * W + pix] = acc[k] + Tr * c->bg[k];
+            for (int k = 0; k < 3; ++k) image[(size_t)k * H * W + pix] = fmaf(Tr, c->bg[k], acc[k]);
           else
             for (int k = 0; k < C; ++k) image[pix * C + k] = acc[k];
         }

@@ -91,12 +91,12 @@ SIGNATURES = {
     "siu3r_m2f_attn_mask": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "siu3r_split_bf16": [_P, _P, _P, _L, _I, _I, _L, _P],
     "siu3r_raster_geometry": [_I, _I, _L, C.POINTER(C.c_int32)],
-    "siu3r_raster_project": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "siu3r_raster_project": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "siu3r_raster_sort": [_I, _L, _P, _P, _P, _P, _P, _P, _P],
     "siu3r_raster_bin": [C.POINTER(RasterCam), _I, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
-    "siu3r_raster_composite_rgb": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "siu3r_raster_composite_rgb": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _P],
     "siu3r_raster_tile_lists": [C.POINTER(RasterCam), _I, _P, _P, _L, _P, _P, _P, _L, _P, _P],
-    "siu3r_raster_composite_feat": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _L, _P, _P, _P, _I, _P, _P, _P],
+    "siu3r_raster_composite_feat": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _L, _P, _P, _I, _P, _P, _P],
     "siu3r_scale_inplace": [_P, _L, _F, _P],
     "siu3r_quat_scale_to_cov6": [_P, _P, _P, _L, _P],
     "siu3r_sh_eval": [_P, _P, _P, _I, _I, _P, _L, _P],

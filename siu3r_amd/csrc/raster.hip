@@ -28,8 +28,9 @@
 //               (entry, wave) -> one global add per staged entry
 //   tile lists  (K3, and on request) the same ballot / prefix-popcount filter writes the per-tile id lists
 //               (tile_start + ids, front to back): gsplat semantics re-use one list for every 32-channel chunk
-// Arithmetic matches oracle/raster_ref.c operation for operation (same expression order, contraction off, and a
-// shared polynomial exp) so that integer outputs are bit-exact and the maps agree to fp32 rounding.
+// Arithmetic matches oracle/raster_ref.c operation for operation (same expression order, contraction off, explicit fused
+// multiply-adds in the blend loop on both sides, and a shared polynomial exp) so that integer outputs are bit-exact and the
+// maps agree to fp32 rounding.
 #include "common.h"
 
 namespace {
@@ -37,22 +38,28 @@ namespace {
 constexpr int TILE = 16;
 typedef siu3r_raster_cam Cam;
 
-// exp(x) for x <= 0 with plain fp32 operations only (identical in oracle/raster_ref.c): 2^(x*log2e), argument
-// reduced to [-0.5, 0.5], degree-7 Taylor of 2^f (|err| < 1e-7 rel), exact scaling by 2^n.
+// exp(x) for x <= 0 from correctly rounded fp32 operations only (fmaf == v_fma_f32; the same sequence in oracle/raster_ref.c, so
+// alpha, the transmittance chain and n_touched are bit-identical on both sides): 2^(x*log2e), argument reduced to [-0.5, 0.5],
+// degree-7 Taylor of 2^f as a Horner chain of 7 fused multiply-adds (|err| < 1e-7 rel), exact scaling by 2^n.
 __device__ __forceinline__ float exp_det(float x) {
   if (x < -87.0f) return 0.0f;
   const float y = x * 1.4426950408889634f;
   const float n = floorf(y + 0.5f);
   const float f = y - n;
   float p = 1.52527338e-5f;
-  p = p * f + 1.54035304e-4f;
-  p = p * f + 1.33335581e-3f;
-  p = p * f + 9.61812911e-3f;
-  p = p * f + 5.55041087e-2f;
-  p = p * f + 2.40226507e-1f;
-  p = p * f + 6.93147181e-1f;
-  p = p * f + 1.0f;
+  p = __builtin_fmaf(p, f, 1.54035304e-4f);
+  p = __builtin_fmaf(p, f, 1.33335581e-3f);
+  p = __builtin_fmaf(p, f, 9.61812911e-3f);
+  p = __builtin_fmaf(p, f, 5.55041087e-2f);
+  p = __builtin_fmaf(p, f, 2.40226507e-1f);
+  p = __builtin_fmaf(p, f, 6.93147181e-1f);
+  p = __builtin_fmaf(p, f, 1.0f);
   return ldexpf(p, (int)n);
+}
+// Mahalanobis half-form q = 0.5 (a dx^2 + c dy^2) + b dx dy of a pixel offset, in the shared fused order
+__device__ __forceinline__ float conic_sigma(float ca, float cb, float cc, float dx, float dy) {
+  const float q = __builtin_fmaf(cc * dy, dy, (ca * dx) * dx);
+  return __builtin_fmaf(cb * dx, dy, 0.5f * q);
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -87,11 +94,15 @@ __constant__ float c_SH_C4[9] = {2.5033429417967046f, -1.7701307697799304f, 0.94
 // stats[v] = {visible Gaussians, tile pairs D, coarse entries E, overflow flags}
 enum { ST_GV = 0, ST_D = 1, ST_E = 2, ST_FLAGS = 3, ST_N = 4 };
 
+// rec: one 48-byte record per (view, Gaussian) = {mx, my, depth, 0 | conic a, b, c, opacity | r, g, b, 0}: what the composite gathers
+// for a surviving list entry sits in one or two cache lines instead of four arrays.
+// cov_stride 6: upper-triangular covariances (xx,xy,xz,yy,yz,zz); 9: full row-major 3x3 (Gaussians.covariances as stored).
+// sh_planar 0: colors [G, ncoef, 3] (the layout the reference hands to the CUDA rasterizer, cuda_splatting.py:65); 1: [G, 3, ncoef]
+// (Gaussians.harmonics as stored: no repacking copy in front of the renderer).
 __global__ __launch_bounds__(256) void project_kernel(const Cam* __restrict__ cams, int64_t G, const float* __restrict__ means,
-                                                      const float* __restrict__ cov6, const float* __restrict__ opac,
-                                                      const float* __restrict__ colors, int channels, float* __restrict__ mean2d,
-                                                      float* __restrict__ conic_op, float* __restrict__ depth, int32_t* __restrict__ radii,
-                                                      int32_t* __restrict__ rect, int32_t* __restrict__ tiles_touched, float* __restrict__ rgb,
+                                                      const float* __restrict__ cov, int cov_stride, const float* __restrict__ opac,
+                                                      const float* __restrict__ colors, int channels, int sh_planar, float* __restrict__ rec,
+                                                      int32_t* __restrict__ radii, int32_t* __restrict__ rect, int32_t* __restrict__ tiles_touched,
                                                       uint32_t* __restrict__ keys, unsigned long long* __restrict__ stats) {
   const int v = blockIdx.y;
   const Cam& c = cams[v];
@@ -139,7 +150,9 @@ __global__ __launch_bounds__(256) void project_kernel(const Cam* __restrict__ ca
       const float j00 = fx * rz, j02 = -(fx * ctx) * rz * rz, j11 = fy * rz, j12 = -(fy * cty) * rz * rz;
       const float m00 = j00 * V[0] + j02 * V[8], m01 = j00 * V[1] + j02 * V[9], m02 = j00 * V[2] + j02 * V[10];
       const float m10 = j11 * V[4] + j12 * V[8], m11 = j11 * V[5] + j12 * V[9], m12 = j11 * V[6] + j12 * V[10];
-      const float sxx = cov6[6 * g], sxy = cov6[6 * g + 1], sxz = cov6[6 * g + 2], syy = cov6[6 * g + 3], syz = cov6[6 * g + 4], szz = cov6[6 * g + 5];
+      const float* cg = cov + (size_t)g * cov_stride;
+      const bool tri = cov_stride == 6;
+      const float sxx = cg[0], sxy = cg[1], sxz = cg[2], syy = cg[tri ? 3 : 4], syz = cg[tri ? 4 : 5], szz = cg[tri ? 5 : 8];
       const float a0 = m00 * sxx + m01 * sxy + m02 * sxz, a1 = m00 * sxy + m01 * syy + m02 * syz, a2 = m00 * sxz + m01 * syz + m02 * szz;
       const float b0 = m10 * sxx + m11 * sxy + m12 * sxz, b1 = m10 * sxy + m11 * syy + m12 * syz, b2 = m10 * sxz + m11 * syz + m12 * szz;
       float c00 = a0 * m00 + a1 * m01 + a2 * m02;
@@ -200,9 +213,9 @@ __global__ __launch_bounds__(256) void project_kernel(const Cam* __restrict__ ca
     radii[2 * o + 1] = ry_i;
     tiles_touched[o] = ntiles;
     *(int4*)(rect + 4 * o) = valid ? make_int4(tx0, ty0, tx1, ty1) : make_int4(0, 0, 0, 0);
-    *(float2*)(mean2d + 2 * o) = make_float2(mx, my);
-    *(float4*)(conic_op + 4 * o) = make_float4(ca, cb, cc, opacity);
-    depth[o] = tz;
+    float4* rp = (float4*)(rec + 12 * o);
+    rp[0] = make_float4(mx, my, tz, 0.f);
+    rp[1] = make_float4(ca, cb, cc, opacity);
     // positive floats order like their bit patterns; culled Gaussians sort behind every visible one
     keys[o] = valid ? __float_as_uint(tz) : 0xffffffffu;
     if (valid && c.mode == 0) {
@@ -214,17 +227,40 @@ __global__ __launch_bounds__(256) void project_kernel(const Cam* __restrict__ ca
       // block is contiguous, so 12 (19 with band 4) wide loads replace 48 (75) scalar ones that each touched 64 cache lines
       struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
       const float* shp = colors + (size_t)g * channels * 3;
-      float sh[76];
-      const int nf = ((deg > 3 && c.sh_band4) ? 25 : (deg > 2 ? 16 : (deg > 1 ? 9 : (deg > 0 ? 4 : 1)))) * 3;
+      float sh[76], col[3];
+      const int ncf = (deg > 3 && c.sh_band4) ? 25 : (deg > 2 ? 16 : (deg > 1 ? 9 : (deg > 0 ? 4 : 1)));
+      const int nf = ncf * 3;
+      if (!sh_planar) {
 #pragma unroll
-      for (int q = 0; q < 19; ++q) {
-        if (4 * q < nf) {
-          if (4 * q + 4 <= channels * 3) {
-            const f4u t4 = *(const f4u*)(shp + 4 * q);
-            sh[4 * q] = t4.v[0]; sh[4 * q + 1] = t4.v[1]; sh[4 * q + 2] = t4.v[2]; sh[4 * q + 3] = t4.v[3];
+        for (int q = 0; q < 19; ++q) {
+          if (4 * q < nf) {
+            if (4 * q + 4 <= channels * 3) {
+              const f4u t4 = *(const f4u*)(shp + 4 * q);
+              sh[4 * q] = t4.v[0]; sh[4 * q + 1] = t4.v[1]; sh[4 * q + 2] = t4.v[2]; sh[4 * q + 3] = t4.v[3];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sh[4 * q + e] = (4 * q + e < channels * 3) ? shp[4 * q + e] : 0.f;
+            }
+          }
+        }
+      } else {
+        // planar block [rgb][25 coefficients] (channels == 25, checked by the launcher): the same 16-byte loads over the lane's
+        // contiguous 300 bytes, written to the interleaved register order the polynomial below indexes (all indices compile-time)
+#pragma unroll
+        for (int q = 0; q < 19; ++q) {
+          float t4[4];
+          if (4 * q + 4 <= 75) {
+            const f4u ld = *(const f4u*)(shp + 4 * q);
+            t4[0] = ld.v[0]; t4[1] = ld.v[1]; t4[2] = ld.v[2]; t4[3] = ld.v[3];
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sh[4 * q + e] = (4 * q + e < channels * 3) ? shp[4 * q + e] : 0.f;
+            for (int e = 0; e < 4; ++e) t4[e] = (4 * q + e < 75) ? shp[4 * q + e] : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            constexpr int NCO = 25;
+            const int idx = 4 * q + e;  // = ch * 25 + coef
+            if (idx < 75) sh[(idx % NCO) * 3 + idx / NCO] = t4[e];
           }
         }
       }
@@ -252,8 +288,9 @@ __global__ __launch_bounds__(256) void project_kernel(const Cam* __restrict__ ca
         }
 #undef S
         r += 0.5f;
-        rgb[3 * o + ch] = r < 0.0f ? 0.0f : r;
+        col[ch] = r < 0.0f ? 0.0f : r;
       }
+      rp[2] = make_float4(col[0], col[1], col[2], 0.f);
     }
   }
   // per-view totals: wave reduction, then one atomic pair per workgroup
@@ -523,26 +560,31 @@ __device__ __forceinline__ bool entry_covers(uint32_t pr, int rtx, int rty) {
 }
 
 // ---- K2 composite: colour [3,H,W] + depth + accumulated opacity (+ n_touched), fused with the per-tile filter -----
-constexpr int STG = 512;  // staging capacity: < 256 carried over + <= 256 new survivors
+constexpr int STG = 512;       // staging capacity (survivors awaiting the blend)
+constexpr int STG_PULL = 192;  // refill while fewer than this are staged (<= STG - 256: one more slice always fits)
+constexpr int FK = 4;          // slices of 256 entries tested per refill round
 template <bool NT>
 __global__ __launch_bounds__(256) void composite_rgb_kernel(const Cam* __restrict__ cams, Geo geo, const int32_t* __restrict__ bin_start,
-                                                            const uint2* __restrict__ entries, int64_t cap_e, const float* __restrict__ mean2d,
-                                                            const float* __restrict__ conic_op, const float* __restrict__ depth,
-                                                            const float* __restrict__ rgb, int64_t G, float* __restrict__ image,
-                                                            float* __restrict__ out_depth, float* __restrict__ out_alpha, int32_t* __restrict__ n_touched) {
-  __shared__ float s_xy[STG][2];
+                                                            const uint2* __restrict__ entries, int64_t cap_e, const float* __restrict__ rec, int64_t G,
+                                                            float* __restrict__ image, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+                                                            int32_t* __restrict__ n_touched) {
+  // staged survivors, 52 B each: {mx, my, depth, id} {conic a, b, c, opacity} {r, g, b, n_touched partial} + quadrant mask.
+  // A wave owns one 8x8 quadrant of the tile; a survivor's mask says which quadrants its alpha >= alpha_min footprint can reach
+  // (bounding box of the ellipse sigma <= ln(opacity / alpha_min), padded), so that the other waves skip it after one LDS read:
+  // pixel-aligned splats are a few pixels wide, and three of four waves would otherwise evaluate them for nothing.
+  __shared__ int s_m[STG];
+  __shared__ __attribute__((aligned(16))) float s_a[STG][4];
   __shared__ __attribute__((aligned(16))) float s_co[STG][4];
-  __shared__ __attribute__((aligned(16))) float s_rgbd[STG][4];
-  __shared__ int s_id[STG];
-  __shared__ int s_nt[NT ? STG : 1];
-  __shared__ int s_wcnt[4];
+  __shared__ __attribute__((aligned(16))) float s_c[STG][4];
+  __shared__ int s_wcnt[4][FK];
+  __shared__ unsigned short s_list[4][STG];
   const int v = blockIdx.y;
   const Cam& c = cams[v];
   const int tile = blockIdx.x, tx = tile % geo.gw, ty = tile / geo.gw;
   const int bx = tx / geo.cb, by = ty / geo.cb, bin = by * geo.nbx + bx;
   const int rtx = tx - bx * geo.cb, rty = ty - by * geo.cb;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int lx = t & 15, ly = t >> 4;
+  const int lx = (lane & 7) + 8 * (wave & 1), ly = (lane >> 3) + 8 * (wave >> 1);  // wave = 8x8 quadrant
   const int px = tx * TILE + lx, py = ty * TILE + ly;
   const bool inside = px < c.width && py < c.height;
   const float pxf = (float)px, pyf = (float)py;
@@ -552,72 +594,125 @@ __global__ __launch_bounds__(256) void composite_rgb_kernel(const Cam* __restric
   const int64_t vg = (int64_t)v * G;
   const float alpha_min = c.alpha_min, alpha_max = c.alpha_max, t_min = c.t_min;
   const bool nt_post = c.nt_post_blend != 0;
+  const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
+  const int wbit = 1 << wave;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, O = 0.f;
   bool done = !inside;
   int staged = 0;
   int64_t base = ebeg;
   while (true) {
     if (__syncthreads_count(done) == 256) break;  // also fences the previous round's LDS reads
-    while (staged < 256 && base < eend) {
-      const int64_t i = base + t;
-      bool pass = false;
-      uint2 e = make_uint2(0, 0);
-      if (i < eend) {
-        e = ep[i];
-        pass = entry_covers(e.y, rtx, rty);
+    // Refill: up to FK slices of 256 entries per round -- their loads, and then the survivors' record gathers, are in flight
+    // together, and one barrier pair covers all of them (the walk is otherwise two dependent memory latencies and two barriers per
+    // 256 entries, of which typically a tenth survive).  Slices are committed in order while they fit the staging area; the rest
+    // is simply read again in the next round.
+    while (staged < STG_PULL && base < eend) {
+      uint2 e[FK];
+      bool pass[FK];
+      unsigned long long m[FK];
+#pragma unroll
+      for (int k = 0; k < FK; ++k) {
+        const int64_t i = base + k * 256 + t;
+        e[k] = i < eend ? ep[i] : make_uint2(0, 0);
       }
-      const unsigned long long m = __ballot(pass);
-      if (lane == 0) s_wcnt[wave] = __popcll(m);
+#pragma unroll
+      for (int k = 0; k < FK; ++k) {
+        pass[k] = (base + k * 256 + t < eend) && entry_covers(e[k].y, rtx, rty);
+        m[k] = __ballot(pass[k]);
+        if (lane == 0) s_wcnt[wave][k] = __popcll(m[k]);
+      }
       __syncthreads();
-      int off = staged + __popcll(m & ((1ull << lane) - 1ull));
-      for (int w = 0; w < wave; ++w) off += s_wcnt[w];
-      const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-      if (pass) {
-        const int64_t g = vg + e.x;
-        s_id[off] = (int)e.x;
-        *(float2*)s_xy[off] = *(const float2*)(mean2d + 2 * g);
-        *(float4*)s_co[off] = *(const float4*)(conic_op + 4 * g);
-        s_rgbd[off][0] = rgb[3 * g];
-        s_rgbd[off][1] = rgb[3 * g + 1];
-        s_rgbd[off][2] = rgb[3 * g + 2];
-        s_rgbd[off][3] = depth[g];
-        if (NT) s_nt[off] = 0;
+      int kk = 0, off_k[FK], run = staged;
+#pragma unroll
+      for (int k = 0; k < FK; ++k) {
+        const int tk = s_wcnt[0][k] + s_wcnt[1][k] + s_wcnt[2][k] + s_wcnt[3][k];
+        int o = run;
+        for (int w = 0; w < wave; ++w) o += s_wcnt[w][k];
+        off_k[k] = o + __popcll(m[k] & ((1ull << lane) - 1ull));
+        if (kk == k && run + tk <= STG) {  // slice k fits (slice 0 always does: staged < STG_PULL <= STG - 256)
+          kk = k + 1;
+          run += tk;
+        }
       }
-      staged += tot;
-      base += 256;
+#pragma unroll
+      for (int k = 0; k < FK; ++k) {
+        if (k < kk && pass[k]) {
+          const int off = off_k[k];
+          const float4* rp = (const float4*)(rec + 12 * (vg + e[k].x));
+          float4 r0 = rp[0];
+          const float4 r1 = rp[1];
+          float4 r2 = rp[2];
+          r0.w = __int_as_float((int)e[k].x);
+          r2.w = __int_as_float(0);
+          *(float4*)s_a[off] = r0;
+          *(float4*)s_co[off] = r1;
+          *(float4*)s_c[off] = r2;
+          // footprint box: alpha >= alpha_min  =>  sigma <= L = ln(opacity / alpha_min)  =>  |dx| <= sqrt(2 L cov_xx), cov = conic^-1.
+          // Padded by 1 % + 0.05 px (the exact per-pixel tests below still decide; the box only has to be conservative)
+          int mk = 15;  // NaN / degenerate conics: no culling, the exact tests decide
+          const float L = __logf(r1.w / alpha_min);
+          const float det = r1.x * r1.z - r1.y * r1.y;
+          if (L <= 0.f) {
+            mk = 0;  // opacity below alpha_min: alpha = min(alpha_max, opacity * exp(<= 0)) can never reach it
+          } else if (det > 0.f) {
+            const float ex = sqrtf(2.f * L * r1.z / det) * 1.01f + 0.05f, ey = sqrtf(2.f * L * r1.x / det) * 1.01f + 0.05f;
+            const float x0 = r0.x - ex - tile_x0, x1 = r0.x + ex - tile_x0, y0 = r0.y - ey - tile_y0, y1 = r0.y + ey - tile_y0;
+            const int cx = (x0 <= 7.f && x1 >= 0.f ? 1 : 0) | (x0 <= 15.f && x1 >= 8.f ? 2 : 0);
+            const int cy = (y0 <= 7.f && y1 >= 0.f ? 1 : 0) | (y0 <= 15.f && y1 >= 8.f ? 2 : 0);
+            mk = ((cy & 1) ? cx : 0) | ((cy & 2) ? (cx << 2) : 0);
+          }
+          s_m[off] = mk;
+        }
+      }
+      staged = run;
+      base += 256 * kk;
       __syncthreads();
     }
     if (staged == 0) break;
-    for (int j = 0; !done && j < staged; ++j) {
-      const float dx = s_xy[j][0] - pxf, dy = s_xy[j][1] - pyf;
-      const float power = -0.5f * (s_co[j][0] * dx * dx + s_co[j][2] * dy * dy) - s_co[j][1] * dx * dy;
+    // this wave's own list (order kept) of the staged survivors that can reach its quadrant: ballot + prefix popcount again, wave-local
+    // (LDS operations of one wave complete in order: no barrier)
+    int nq = 0;
+    for (int b = 0; b < staged; b += 64) {
+      const int i = b + lane;
+      const bool hit = i < staged && (s_m[i] & wbit);
+      const unsigned long long mh = __ballot(hit);
+      if (hit) s_list[wave][nq + __popcll(mh & ((1ull << lane) - 1ull))] = (unsigned short)i;
+      nq += __popcll(mh);
+    }
+    for (int ii = 0; !done && ii < nq; ++ii) {
+      const int j = s_list[wave][ii];
+      const float4 A = *(const float4*)s_a[j];
+      const float4 Q = *(const float4*)s_co[j];
+      const float dx = A.x - pxf, dy = A.y - pyf;
+      const float power = -conic_sigma(Q.x, Q.y, Q.z, dx, dy);
       if (power > 0.0f) continue;
-      const float a = fminf(alpha_max, s_co[j][3] * exp_det(power));
+      const float a = fminf(alpha_max, Q.w * exp_det(power));
       if (a < alpha_min) continue;
-      const float nT = T * (1.0f - a);
+      const float nT = __builtin_fmaf(-T, a, T);  // T (1 - a)
       if (nT < t_min) {
         done = true;
         continue;
       }
       const float w = a * T;
-      C0 += s_rgbd[j][0] * w;
-      C1 += s_rgbd[j][1] * w;
-      C2 += s_rgbd[j][2] * w;
-      D += s_rgbd[j][3] * w;
+      const float4 Cj = *(const float4*)s_c[j];
+      C0 = __builtin_fmaf(Cj.x, w, C0);
+      C1 = __builtin_fmaf(Cj.y, w, C1);
+      C2 = __builtin_fmaf(Cj.z, w, C2);
+      D = __builtin_fmaf(A.z, w, D);
       O += w;
       if (NT) {
         // pixels that count this Gaussian: ballot over the lanes that reached this point, one LDS add per wave
         const bool cnt = (nt_post ? nT : T) > 0.5f;
         const unsigned long long mc = __ballot(cnt);
-        if (cnt && lane == (int)__ffsll((long long)mc) - 1) atomicAdd(&s_nt[j], (int)__popcll(mc));
+        if (cnt && lane == (int)__ffsll((long long)mc) - 1) atomicAdd((int*)&s_c[j][3], (int)__popcll(mc));
       }
       T = nT;
     }
     if (NT) {
       __syncthreads();
       for (int j = t; j < staged; j += 256) {
-        const int n = s_nt[j];
-        if (n) atomicAdd(&n_touched[vg + s_id[j]], n);
+        const int n = __float_as_int(s_c[j][3]);
+        if (n) atomicAdd(&n_touched[vg + __float_as_int(s_a[j][3])], n);
       }
     }
     staged = 0;
@@ -625,9 +720,9 @@ __global__ __launch_bounds__(256) void composite_rgb_kernel(const Cam* __restric
   if (inside) {
     const size_t hw = (size_t)c.width * c.height, pix = (size_t)py * c.width + px;
     float* img = image + (size_t)v * 3 * hw;
-    img[pix] = C0 + T * c.bg[0];
-    img[hw + pix] = C1 + T * c.bg[1];
-    img[2 * hw + pix] = C2 + T * c.bg[2];
+    img[pix] = __builtin_fmaf(T, c.bg[0], C0);
+    img[hw + pix] = __builtin_fmaf(T, c.bg[1], C1);
+    img[2 * hw + pix] = __builtin_fmaf(T, c.bg[2], C2);
     out_depth[(size_t)v * hw + pix] = D;
     out_alpha[(size_t)v * hw + pix] = O;
   }
@@ -726,9 +821,9 @@ __global__ __launch_bounds__(256) void tl_write_kernel(Geo geo, const int32_t* _
 // ---- K3 composite: one 32-channel chunk of the feature matrix per blockIdx.y; colours [H,W,C]; alpha written by chunk 0
 constexpr int CHUNK = 32;
 __global__ __launch_bounds__(256) void composite_feat_kernel(const Cam* __restrict__ cams, Geo geo, const int32_t* __restrict__ tile_start,
-                                                             const int32_t* __restrict__ ids, int64_t cap_d, const float* __restrict__ mean2d,
-                                                             const float* __restrict__ conic_op, const float* __restrict__ feats, int channels,
-                                                             int64_t G, float* __restrict__ out, float* __restrict__ out_alpha) {
+                                                             const int32_t* __restrict__ ids, int64_t cap_d, const float* __restrict__ rec,
+                                                             const float* __restrict__ feats, int channels, int64_t G, float* __restrict__ out,
+                                                             float* __restrict__ out_alpha) {
   __shared__ float s_xy[128][2];
   __shared__ __attribute__((aligned(16))) float s_co[128][4];
   __shared__ float s_f[128][CHUNK + 1];
@@ -754,9 +849,10 @@ __global__ __launch_bounds__(256) void composite_feat_kernel(const Cam* __restri
     if (__syncthreads_count(done) == 256) break;
     const int cnt = min(128, end - base);
     if (threadIdx.x < cnt) {
-      const int64_t g = vg + idp[base + threadIdx.x];
-      *(float2*)s_xy[threadIdx.x] = *(const float2*)(mean2d + 2 * g);
-      *(float4*)s_co[threadIdx.x] = *(const float4*)(conic_op + 4 * g);
+      const float4* rp = (const float4*)(rec + 12 * (vg + idp[base + threadIdx.x]));
+      const float4 r0 = rp[0];
+      *(float2*)s_xy[threadIdx.x] = make_float2(r0.x, r0.y);
+      *(float4*)s_co[threadIdx.x] = rp[1];
     }
     for (int e = threadIdx.x; e < cnt * CHUNK; e += 256) {
       const int j = e / CHUNK, k = e - j * CHUNK;
@@ -765,18 +861,18 @@ __global__ __launch_bounds__(256) void composite_feat_kernel(const Cam* __restri
     __syncthreads();
     for (int j = 0; !done && j < cnt; ++j) {
       const float dx = s_xy[j][0] - pxf, dy = s_xy[j][1] - pyf;
-      const float sigma = 0.5f * (s_co[j][0] * dx * dx + s_co[j][2] * dy * dy) + s_co[j][1] * dx * dy;
+      const float sigma = conic_sigma(s_co[j][0], s_co[j][1], s_co[j][2], dx, dy);
       if (sigma < 0.0f) continue;
       const float a = fminf(alpha_max, s_co[j][3] * exp_det(-sigma));
       if (a < alpha_min) continue;
-      const float nT = T * (1.0f - a);
+      const float nT = __builtin_fmaf(-T, a, T);
       if (nT <= t_min) {
         done = true;
         continue;
       }
       const float w = a * T;
 #pragma unroll
-      for (int k = 0; k < CHUNK; ++k) acc[k] += s_f[j][k] * w;
+      for (int k = 0; k < CHUNK; ++k) acc[k] = __builtin_fmaf(s_f[j][k], w, acc[k]);
       O += w;
       T = nT;
     }
@@ -910,15 +1006,17 @@ extern "C" int siu3r_raster_geometry(int width, int height, int64_t G, int32_t* 
   return 0;
 }
 
-extern "C" int siu3r_raster_project(const siu3r_raster_cam* cams_host, int V, void* cams_dev, int64_t G, const float* means, const float* cov6,
-                                    const float* opacities, const float* colors, int channels, float* mean2d, float* conic_op, float* depth,
-                                    int32_t* radii, int32_t* rect, int32_t* tiles_touched, float* rgb, uint32_t* keys, uint64_t* stats,
-                                    void* stream) {
+extern "C" int siu3r_raster_project(const siu3r_raster_cam* cams_host, int V, void* cams_dev, int64_t G, const float* means, const float* cov,
+                                    int cov_stride, const float* opacities, const float* colors, int channels, int sh_planar, float* rec,
+                                    int32_t* radii, int32_t* rect, int32_t* tiles_touched, uint32_t* keys, uint64_t* stats, void* stream) {
   if (int rc = check_views(cams_host, V, "raster_project")) return rc;
   SIU3R_CHECK(cams_dev && stats, "raster_project: null pointer");
   SIU3R_CHECK(G >= 0 && G < (1ll << 31), "raster_project: G = %ld out of range", (long)G);
-  SIU3R_CHECK(G == 0 || (means && cov6 && opacities && mean2d && conic_op && depth && radii && rect && tiles_touched && keys), "raster_project: null per-Gaussian pointer");
-  SIU3R_CHECK(cams_host[0].mode == 1 || G == 0 || (colors && rgb), "raster_project: SH colours missing");
+  SIU3R_CHECK(G == 0 || (means && cov && opacities && rec && radii && rect && tiles_touched && keys), "raster_project: null per-Gaussian pointer");
+  SIU3R_CHECK(cov_stride == 6 || cov_stride == 9, "raster_project: cov_stride must be 6 (upper triangle) or 9 (3x3)");
+  SIU3R_CHECK(cams_host[0].mode == 1 || G == 0 || colors, "raster_project: SH colours missing");
+  SIU3R_CHECK(!sh_planar || channels == 25, "raster_project: the planar SH layout [G,3,25] needs 25 coefficients (got %d)", channels);
+  SIU3R_CHECK(((uintptr_t)rec & 15) == 0, "raster_project: rec must be 16-byte aligned");
   for (int v = 0; v < V; ++v)
     SIU3R_CHECK(cams_host[v].mode == 1 || G == 0 || channels >= (cams_host[v].sh_degree + 1) * (cams_host[v].sh_degree + 1), "raster_project: too few SH coefficients");
   hipStream_t s = (hipStream_t)stream;
@@ -928,8 +1026,8 @@ extern "C" int siu3r_raster_project(const siu3r_raster_cam* cams_host, int V, vo
     return 2;
   }
   if (G > 0)
-    hipLaunchKernelGGL(project_kernel, dim3((unsigned)cdiv64(G, 256), V), dim3(256), 0, s, (const Cam*)cams_dev, G, means, cov6, opacities, colors, channels,
-                       mean2d, conic_op, depth, radii, rect, tiles_touched, rgb, keys, (unsigned long long*)stats);
+    hipLaunchKernelGGL(project_kernel, dim3((unsigned)cdiv64(G, 256), V), dim3(256), 0, s, (const Cam*)cams_dev, G, means, cov, cov_stride, opacities, colors,
+                       channels, sh_planar, rec, radii, rect, tiles_touched, keys, (unsigned long long*)stats);
   SIU3R_LAUNCH_CHECK("siu3r_raster_project");
   return 0;
 }
@@ -980,10 +1078,10 @@ extern "C" int siu3r_raster_bin(const siu3r_raster_cam* cams_host, int V, int64_
 }
 
 extern "C" int siu3r_raster_composite_rgb(const siu3r_raster_cam* cams_host, int V, const void* cams_dev, int64_t G, const int32_t* bin_start,
-                                          const void* entries, int64_t cap_e, const float* mean2d, const float* conic_op, const float* depth,
-                                          const float* rgb, float* image, float* out_depth, float* out_alpha, int32_t* n_touched, void* stream) {
+                                          const void* entries, int64_t cap_e, const float* rec, float* image, float* out_depth, float* out_alpha,
+                                          int32_t* n_touched, void* stream) {
   if (int rc = check_views(cams_host, V, "raster_composite_rgb")) return rc;
-  SIU3R_CHECK(cams_dev && bin_start && image && out_depth && out_alpha && (G == 0 || (entries && mean2d && conic_op && depth && rgb)), "raster_composite_rgb: null pointer");
+  SIU3R_CHECK(cams_dev && bin_start && image && out_depth && out_alpha && (G == 0 || (entries && rec)), "raster_composite_rgb: null pointer");
   hipStream_t s = (hipStream_t)stream;
   const Geo geo = make_geo(cams_host[0].width, cams_host[0].height);
   if (n_touched && G > 0 && hipMemsetAsync(n_touched, 0, sizeof(int32_t) * (size_t)V * G, s) != hipSuccess) {
@@ -991,11 +1089,11 @@ extern "C" int siu3r_raster_composite_rgb(const siu3r_raster_cam* cams_host, int
     return 2;
   }
   if (n_touched)
-    hipLaunchKernelGGL(composite_rgb_kernel<true>, dim3(geo.T, V), dim3(256), 0, s, (const Cam*)cams_dev, geo, bin_start, (const uint2*)entries, cap_e, mean2d,
-                       conic_op, depth, rgb, G, image, out_depth, out_alpha, n_touched);
+    hipLaunchKernelGGL(composite_rgb_kernel<true>, dim3(geo.T, V), dim3(256), 0, s, (const Cam*)cams_dev, geo, bin_start, (const uint2*)entries, cap_e, rec, G,
+                       image, out_depth, out_alpha, n_touched);
   else
-    hipLaunchKernelGGL(composite_rgb_kernel<false>, dim3(geo.T, V), dim3(256), 0, s, (const Cam*)cams_dev, geo, bin_start, (const uint2*)entries, cap_e, mean2d,
-                       conic_op, depth, rgb, G, image, out_depth, out_alpha, n_touched);
+    hipLaunchKernelGGL(composite_rgb_kernel<false>, dim3(geo.T, V), dim3(256), 0, s, (const Cam*)cams_dev, geo, bin_start, (const uint2*)entries, cap_e, rec, G,
+                       image, out_depth, out_alpha, n_touched);
   SIU3R_LAUNCH_CHECK("siu3r_raster_composite_rgb");
   return 0;
 }
@@ -1014,15 +1112,15 @@ extern "C" int siu3r_raster_tile_lists(const siu3r_raster_cam* cams_host, int V,
 }
 
 extern "C" int siu3r_raster_composite_feat(const siu3r_raster_cam* cams_host, int V, const void* cams_dev, int64_t G, const int32_t* tile_start,
-                                           const int32_t* ids, int64_t cap_d, const float* mean2d, const float* conic_op, const float* feats,
-                                           int channels, float* out, float* out_alpha, void* stream) {
+                                           const int32_t* ids, int64_t cap_d, const float* rec, const float* feats, int channels, float* out,
+                                           float* out_alpha, void* stream) {
   if (int rc = check_views(cams_host, V, "raster_composite_feat")) return rc;
-  SIU3R_CHECK(cams_dev && tile_start && ids && mean2d && conic_op && feats && out && channels > 0, "raster_composite_feat: bad arguments");
+  SIU3R_CHECK(cams_dev && tile_start && ids && rec && feats && out && channels > 0, "raster_composite_feat: bad arguments");
   const Geo geo = make_geo(cams_host[0].width, cams_host[0].height);
   const int nchunk = (channels + CHUNK - 1) / CHUNK;
   SIU3R_CHECK(nchunk <= 65535 && V <= 65535, "raster_composite_feat: too many channel chunks / views");
-  hipLaunchKernelGGL(composite_feat_kernel, dim3(geo.T, nchunk, V), dim3(256), 0, (hipStream_t)stream, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, mean2d,
-                     conic_op, feats, channels, G, out, out_alpha);
+  hipLaunchKernelGGL(composite_feat_kernel, dim3(geo.T, nchunk, V), dim3(256), 0, (hipStream_t)stream, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, rec, feats,
+                     channels, G, out, out_alpha);
   SIU3R_LAUNCH_CHECK("siu3r_raster_composite_feat");
   return 0;
 }

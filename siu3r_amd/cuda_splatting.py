@@ -61,8 +61,7 @@ def render_cuda(extrinsics, intrinsics, near, far, image_shape, background_color
     w2c = torch.linalg.inv(ext)
     full = proj @ w2c  # column-vector form of the reference's row-vector view @ proj (cuda_splatting.py:74-77)
     # the reference's callers pass the same Gaussians expanded over the views (gaussian_renderer.py:50-67): consecutive views that
-    # share their Gaussian storage go through the rasterizer as ONE call (blockIdx.y = view), and are repacked (6-entry
-    # covariances, 'g xyz n -> g n xyz' coefficients (:65), a 157 MB copy at 524 288 Gaussians) once, not per view
+    # share their Gaussian storage go through the rasterizer as ONE call (blockIdx.y = view)
     groups, i = [], 0
     while i < b:
         key = (gaussian_means[i].data_ptr(), gaussian_covariances[i].data_ptr(), gaussian_sh_coefficients[i].data_ptr(), gaussian_opacities[i].data_ptr())
@@ -77,10 +76,12 @@ def render_cuda(extrinsics, intrinsics, near, far, image_shape, background_color
         cams = [raster.make_cam_k2(w2c[i], full[i], float(tan_x[i]), float(tan_y[i]), ext[i, :3, 3].tolist(),
                                    background_color[i].detach().float().cpu().tolist(), w, h, sh_degree=degree, sh_band4=sh_band4)
                 for i in range(i0, i1)]
-        cov6 = raster.cov6_from_cov3x3(gaussian_covariances[i0])
-        shs = gaussian_sh_coefficients[i0].permute(0, 2, 1).contiguous()
-        out = raster.rasterize_views_k2(cams, gaussian_means[i0], cov6, shs, gaussian_opacities[i0], want_n_touched=return_aux,
-                                        entry_capacity=entry_capacity)
+        # the projection kernel reads the 3x3 covariances and the [g, xyz, n] coefficients as stored: neither the 6-entry
+        # repacking (:107,115) nor the 'g xyz n -> g n xyz' rearrangement (:65) is materialised
+        sh_i = gaussian_sh_coefficients[i0]
+        planar = sh_i.shape[-1] == 25
+        out = raster.rasterize_views_k2(cams, gaussian_means[i0], gaussian_covariances[i0], sh_i if planar else sh_i.permute(0, 2, 1).contiguous(),
+                                        gaussian_opacities[i0], want_n_touched=return_aux, entry_capacity=entry_capacity, sh_planar=planar)
         images.append(out["image"])
         depths.append(out["depth"])
         aux.append(out)

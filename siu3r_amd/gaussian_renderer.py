@@ -53,7 +53,7 @@ class SplattingCUDA:
             all_qc = []
             for i in range(b):
                 means, opac = gaussians.means[i], gaussians.opacities[i]
-                cov6 = raster.cov6_from_cov3x3(gaussians.covariances[i])
+                cov6 = gaussians.covariances[i]  # [G,3,3], read in place
                 qcl = gaussians.seg_query_class_logits[i]  # [n, q, c]
                 n, q, c = qcl.shape
                 feats = qcl.reshape(n, q * c)

@@ -145,23 +145,31 @@ def _cam_array(cams: Sequence[RasterCam]):
     return arr
 
 
-def _project_sort_bin(cams: Sequence[RasterCam], means, cov6, opac, colors, channels, entry_capacity=None, check_overflow=True) -> _State:
+def _cov_stride(cov: torch.Tensor) -> int:
+    """[G,6] upper-triangular or [G,3,3] full covariances (read in place by the projection kernel)."""
+    if cov.dim() == 2 and cov.shape[1] == 6:
+        return 6
+    if cov.dim() == 3 and cov.shape[1:] == (3, 3):
+        return 9
+    raise RuntimeError(f"covariances must be [G,6] or [G,3,3], got {tuple(cov.shape)}")
+
+
+def _project_sort_bin(cams: Sequence[RasterCam], means, cov, opac, colors, channels, entry_capacity=None, check_overflow=True,
+                      sh_planar=False) -> _State:
     V, G, dev = len(cams), means.shape[0], means.device
     arr = _cam_array(cams)
     geo = geometry(cams[0].width, cams[0].height, G)
     f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
     cap_e = int(entry_capacity) if entry_capacity else default_entry_capacity(G)
-    mode0 = cams[0].mode == 0
     st = _State(V=V, G=G, T=geo["T"], geo=geo, cams=arr, cams_dev=torch.empty((V * geo["cam_bytes"],), dtype=torch.uint8, device=dev),
-                mean2d=f(V, G, 2), conic_op=f(V, G, 4), depth=f(V, G), radii=i32(V, G, 2), rect=i32(V, G, 4), tiles_touched_all=i32(V, G),
-                rgb=f(V, G, 3) if mode0 else None, keys=i32(V, G), keys_b=i32(V, G), sorted_ids=i32(V, G), ids_b=i32(V, G),
+                rec=f(V, G, 12), radii=i32(V, G, 2), rect=i32(V, G, 4), tiles_touched_all=i32(V, G), keys=i32(V, G), keys_b=i32(V, G), sorted_ids=i32(V, G), ids_b=i32(V, G),
                 stats=torch.empty((V, 4), dtype=torch.int64, device=dev), defer=not check_overflow, cap_d_hint=None)
     st["tiles_touched"] = st["tiles_touched_all"][0]
     lib = _lib.lib()
-    check(lib.siu3r_raster_project(arr, V, _p(st["cams_dev"]), G, _p(means), _p(cov6), _p(opac), _p(colors), channels, _p(st["mean2d"]),
-                                   _p(st["conic_op"]), _p(st["depth"]), _p(st["radii"]), _p(st["rect"]), _p(st["tiles_touched_all"]),
-                                   _p(st["rgb"]), _p(st["keys"]), _p(st["stats"]), _stream()))
+    check(lib.siu3r_raster_project(arr, V, _p(st["cams_dev"]), G, _p(means), _p(cov), _cov_stride(cov), _p(opac), _p(colors), channels,
+                                   int(bool(sh_planar)), _p(st["rec"]), _p(st["radii"]), _p(st["rect"]), _p(st["tiles_touched_all"]),
+                                   _p(st["keys"]), _p(st["stats"]), _stream()))
     rs_hist, rs_tot = i32(V, 256, geo["nchunks_sort"]), i32(V, 256)
     check(lib.siu3r_raster_sort(V, G, _p(st["keys"]), _p(st["keys_b"]), _p(st["sorted_ids"]), _p(st["ids_b"]), _p(rs_hist), _p(rs_tot), _stream()))
     bin_hist, bin_tot = i32(V, geo["NB"], geo["nchunks_bin"]), i32(V, geo["NB"])
@@ -189,23 +197,24 @@ def _with_retry(run, entry_capacity, check_overflow):
 
 
 def rasterize_views_k2(cams: Sequence[RasterCam], means, cov6, shs, opacities, want_n_touched=True, entry_capacity=None,
-                       check_overflow=True) -> Dict[str, torch.Tensor]:
-    """V views of one Gaussian set.  means [G,3], cov6 [G,6], shs [G,ncoef,3], opacities [G] (fp32, GPU) -> image [V,3,H,W],
-    radii [V,G,2] i32, depth [V,H,W], opacity [V,H,W], n_touched [V,G] i32 (None when not wanted) + the call's state."""
+                       check_overflow=True, sh_planar=False) -> Dict[str, torch.Tensor]:
+    """V views of one Gaussian set.  means [G,3]; cov6 [G,6] (upper triangle) or [G,3,3]; shs [G,ncoef,3], or with sh_planar
+    [G,3,25] (Gaussians.harmonics as stored); opacities [G] (fp32, GPU) -> image [V,3,H,W], radii [V,G,2] i32, depth [V,H,W],
+    opacity [V,H,W], n_touched [V,G] i32 (None when not wanted) + the call's state."""
     _gpu(means, cov6, shs, opacities)
     means, cov6, shs, opacities = (t.contiguous().float() for t in (means, cov6, shs, opacities))
     V, G, dev = len(cams), means.shape[0], means.device
     H, W = cams[0].height, cams[0].width
+    ncoef = shs.shape[2] if sh_planar else shs.shape[1]
 
     def run(cap):
-        st = _project_sort_bin(cams, means, cov6, opacities, shs, shs.shape[1], cap, check_overflow)
+        st = _project_sort_bin(cams, means, cov6, opacities, shs, ncoef, cap, check_overflow, sh_planar)
         image = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
         depth = torch.empty((V, H, W), dtype=torch.float32, device=dev)
         alpha = torch.empty((V, H, W), dtype=torch.float32, device=dev)
         n_touched = torch.empty((V, G), dtype=torch.int32, device=dev) if want_n_touched else None
         check(_lib.lib().siu3r_raster_composite_rgb(st["cams"], V, _p(st["cams_dev"]), G, _p(st["bin_start"]), _p(st["entries"]), st["cap_e"],
-                                                    _p(st["mean2d"]), _p(st["conic_op"]), _p(st["depth"]), _p(st["rgb"]), _p(image), _p(depth),
-                                                    _p(alpha), _p(n_touched), _stream()))
+                                                    _p(st["rec"]), _p(image), _p(depth), _p(alpha), _p(n_touched), _stream()))
         return dict(image=image, radii=st["radii"], depth=depth, opacity=alpha, n_touched=n_touched, state=st)
 
     return _with_retry(run, entry_capacity, check_overflow)
@@ -233,7 +242,7 @@ def rasterize_views_k3(cams: Sequence[RasterCam], means, cov6, opacities, feats,
         out = torch.empty((V, H, W, Cc), dtype=torch.float32, device=dev)
         alpha = torch.empty((V, H, W), dtype=torch.float32, device=dev)
         check(_lib.lib().siu3r_raster_composite_feat(st["cams"], V, _p(st["cams_dev"]), G, _p(st["tile_start_all"]), _p(st["ids_all"]), st["cap_d"],
-                                                     _p(st["mean2d"]), _p(st["conic_op"]), _p(feats), Cc, _p(out), _p(alpha), _stream()))
+                                                     _p(st["rec"]), _p(feats), Cc, _p(out), _p(alpha), _stream()))
         return dict(colors=out, alphas=alpha, radii=st["radii"], state=st)
 
     return _with_retry(run, entry_capacity, check_overflow)
