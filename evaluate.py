@@ -1,0 +1,114 @@
+#!/usr/bin/env python
+"""Evaluation driver of the MI355X path: one process per GPU over ScanNet validation pairs (BASELINE.json configs[2] / [3]).
+
+Counterpart of the reference's validation loop (src/pipeline.py:286-326: `validation_step` -> `Visualizer` files -> rank-0
+`Evaluator.evaluate`): per batch of pairs
+    SIU3RModel.forward(context views, lift)  ->  SplattingCUDA.forward(target poses: colour, depth, query x class logit maps)
+    ->  lifting (pipeline.py:132-193)  ->  files in the reference's on-disk layout (siu3r_amd/eval_io.py)
+and at the end ONE all-gather of every rank's additive metric vector (siu3r_amd/metrics.py) instead of the reference's
+two barriers around a rank-0 pass over a shared filesystem; rank 0 writes results.json.  Pair i goes to rank i mod world.
+
+    python evaluate.py --data_root /data/scannet --model_path siu3r_epoch100.ckpt --output_path outputs/val
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 evaluate.py --data_root ... --batch 8
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def context_positions(context_ids, target_ids):
+    """positions of the context views inside each target list (pipeline.py:101-108)"""
+    return [[pos for pos, idx in enumerate(t) if idx in c] for c, t in zip(context_ids, target_ids)]
+
+
+def run_batch(model, renderer, batch, image_size, dev):
+    """pipeline.py:76-215 `step_w_query_class_logit_lift`"""
+    from siu3r_amd.gaussian_renderer import lift_query_class_logits
+
+    imgs = batch["context_views_images"].to(dev)
+    Kc = batch["context_views_intrinsics"][:, :, :3, :3].to(dev)
+    Kt = batch["target_views_intrinsics"][:, :, :3, :3]
+    ext_t = batch["target_views_extrinsics"]
+    with torch.no_grad():
+        gaussians, seg_out, seg_masks, seg_infos, q_scores = model(imgs, Kc, enable_query_class_logit_lift=True)
+        rend = renderer.forward(gaussians, ext_t, Kt, image_size, render_color=True, render_qc_logits=True)
+        sem, ins, infos = lift_query_class_logits(rend["render_qc_logits"], q_scores, num_queries=model.mask2former.num_queries,
+                                                  label_ids_to_fuse=sorted(model.label_ids_to_fuse))
+    pos = context_positions(batch["context_views_id"], batch["target_views_id"])
+    csem = torch.stack([sem[i, p] for i, p in enumerate(pos)])
+    cins = torch.stack([ins[i, p] for i, p in enumerate(pos)])
+    return dict(render=rend, target_sem=sem, target_ins=ins, context_sem=csem, context_ins=cins, seg_infos=infos, gaussians=gaussians)
+
+
+def write_batch(out_dir, batch, res):
+    """what Visualizer.write_file stores for the evaluator (visualizer.py:136-270)"""
+    from siu3r_amd import eval_io as E
+
+    names, cids, tids = batch["scene_names"], batch["context_views_id"], batch["target_views_id"]
+    E.save_recon_images(res["render"]["render_color"], res["render"]["render_depth"], batch["target_views_images"], batch["target_views_depths"],
+                        out_dir, names, cids, tids)
+    E.save_seg_ids("context", res["context_sem"], res["context_ins"], out_dir, names, cids, tids, res["seg_infos"])
+    E.save_seg_ids("target", res["target_sem"], res["target_ins"], out_dir, names, cids, tids, res["seg_infos"])
+    E.save_gt_seg_masks("context", batch["context_mask_labels"], batch["context_class_labels"], out_dir, names, cids, tids)
+    E.save_gt_seg_masks("target", batch["target_mask_labels"], batch["target_class_labels"], out_dir, names, cids, tids)
+    return [E.scene_dir(out_dir, n, c).name for n, c in zip(names, cids)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--data_root", required=True, help="ScanNet root holding val_pair.json and val/<scan>/{color,depth,panoptic,extrinsic}")
+    ap.add_argument("--val_pair_json", default="val_pair.json")
+    ap.add_argument("--model_path", default=None, help="Lightning .ckpt / state dict; default: seeded synthetic weights (plumbing only)")
+    ap.add_argument("--output_path", default="outputs/val")
+    ap.add_argument("--batch", type=int, default=8, help="pairs per forward (configs[2]: 8)")
+    ap.add_argument("--limit", type=int, default=0, help="evaluate only the first N pairs")
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16", "bf16x3"])
+    a = ap.parse_args()
+
+    from siu3r_amd import distributed as D, eval_io as E, metrics as M, scannet
+    from siu3r_amd.cli_common import load_weights
+    from siu3r_amd.gaussian_renderer import SplattingCUDA
+    from siu3r_amd.model import SIU3RModel
+
+    rank, local, world = D.init_from_env()
+    if not torch.cuda.is_available():
+        raise RuntimeError("evaluate.py needs an MI355X: the HIP path has no CPU fallback")
+    local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    data = scannet.ScanNetValPairs(a.data_root, a.val_pair_json)
+    n = min(len(data), a.limit) if a.limit else len(data)
+    mine = scannet.shard(n, rank, world)
+    size = (data.image_size, data.image_size)
+    model = SIU3RModel(load_weights(a.model_path), image_size=size, precision=a.precision, device=dev)
+    renderer = SplattingCUDA()
+    out_dir = Path(a.output_path)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    acc, my_scenes, t0 = M.MetricAccumulator(), [], time.perf_counter()
+    for s in range(0, len(mine), a.batch):
+        batch = scannet.collate([data[i] for i in mine[s:s + a.batch]])
+        res = run_batch(model, renderer, batch, size, dev)
+        my_scenes += write_batch(out_dir, batch, res)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    E.accumulate_dir(out_dir, acc, scenes=my_scenes)  # this rank's shard, read back from the files it wrote (PNG truncation included)
+    gathered = D.all_gather_stats(torch.from_numpy(acc.to_vector()), device=dev)  # the path's single collective
+    if rank == 0:
+        result = M.MetricAccumulator.from_vectors(gathered.numpy()).compute()
+        with open(out_dir / "results.json", "w") as fh:
+            json.dump(result, fh, indent=4)
+        print(json.dumps({"pairs": n, "world": world, "pairs_per_s_rank0": len(mine) / max(elapsed, 1e-9),
+                          **{k: v for k, v in result.items() if not k.endswith("per_class")}}))
+    D.barrier()
+
+
+if __name__ == "__main__":
+    main()
