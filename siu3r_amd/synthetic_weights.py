@@ -233,12 +233,45 @@ def _hash_uniform(key: int, n: int) -> np.ndarray:
     return out
 
 
+# ---- panoptic shaping ---------------------------------------------------------------------------------------------------
+# With plainly random weights the 100 object queries of the masked-attention decoder collapse onto one vector after a few layers
+# (every sub-layer output swamps the query's own features), every query then predicts the same class with a near-uniform
+# distribution, nothing passes `score > 0.5` and the panoptic post-process only ever runs its empty branch -- no segment ids, no
+# query x class logit maps to lift, an all-zero integer output to "compare".  These few seeded rules keep the generator a pure
+# function of (name, shape, seed) but give the segmentation path something to do, like a trained checkpoint would:
+#   * queries_features: unit-scale per-query features (the residual stream the decoder starts from);
+#   * the three write-back projections of each decoder layer (cross_attn.out_proj, self_attn.out_proj, fc2) are damped, so a
+#     query keeps its identity through the nine post-norm layers;
+#   * class_predictor: a sharp classifier (weights x CLASS_GAIN) with a void prior (bias[20] += VOID_BIAS) that lets roughly one
+#     query in ten beat "no object" with probability > 0.5;
+#   * constant offsets on the mask embedding and on the per-pixel mask features, whose product shifts all mask logits negative:
+#     masks become small and mostly disjoint, so that several kept queries pass the `area / original_area > 0.8` test.
+PANOPTIC_DAMP = 0.15
+CLASS_GAIN = 12.0
+VOID_BIAS = 34.0
+STUFF_BIAS = 10.0           # a prior for the two stuff classes (wall, floor): exercises the `label_ids_to_fuse` id sharing
+MASK_EMBED_BIAS = 0.105     # mask logit = <mask_embed(query), mask_feature(pixel)>: the two constant offsets add
+MASK_FEATURE_BIAS = 0.105   # -256 * 0.105 * 0.105 = -2.8 to every logit, so a query is "on" for a small, mostly exclusive set of pixels
+_TM = "mask2former.model.transformer_module"
+
+
 def make_tensor(name: str, shape: tuple, seed: int = 0) -> torch.Tensor:
     if name.endswith("num_batches_tracked"):
         return torch.zeros((), dtype=torch.int64)
     n = int(np.prod(shape)) if len(shape) else 1
     key = zlib.crc32(name.encode()) ^ (seed * 0x9E3779B9 & 0xFFFFFFFF)
     u = _hash_uniform(key, n)
+    if name == _TM + ".queries_features.weight":
+        return torch.from_numpy(u.reshape(shape))
+    if name == "mask2former.class_predictor.bias":
+        v = np.float32(0.1) * u
+        v[-1] += np.float32(VOID_BIAS)
+        v[:2] += np.float32(STUFF_BIAS)
+        return torch.from_numpy(v.reshape(shape))
+    if name == _TM + ".decoder.mask_predictor.mask_embedder.2.0.bias":
+        return torch.from_numpy((np.float32(0.1) * u + np.float32(MASK_EMBED_BIAS)).reshape(shape))
+    if name == "mask2former.model.pixel_decoder.mask_projection.bias":
+        return torch.from_numpy((np.float32(0.1) * u - np.float32(MASK_FEATURE_BIAS)).reshape(shape))
     if name.endswith("empty_weight"):
         v = np.ones(n, dtype=np.float32)
     elif name.endswith("running_var"):
@@ -252,6 +285,10 @@ def make_tensor(name: str, shape: tuple, seed: int = 0) -> torch.Tensor:
     elif len(shape) >= 2:
         fan_in = n // shape[0]
         a = np.float32(0.8 * np.sqrt(3.0 / fan_in))
+        if name.startswith(_TM + ".decoder.layers.") and name.endswith(("cross_attn.out_proj.weight", "self_attn.out_proj.weight", "fc2.weight")):
+            a = a * np.float32(PANOPTIC_DAMP)
+        if name == "mask2former.class_predictor.weight":
+            a = a * np.float32(CLASS_GAIN)
         v = a * u
     elif name.endswith(".weight"):  # 1-d: norm scales
         v = np.float32(1.0) + np.float32(0.1) * u

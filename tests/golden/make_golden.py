@@ -28,6 +28,7 @@ from crafted import crafted_panoptic_inputs, permuted  # noqa: E402
 from oracle import weights as OW  # noqa: E402
 
 STRIDE = 4093  # prime stride for the sampled tensors
+ISTRIDE = 97    # stride for the integer id maps
 
 
 def summarize(t: torch.Tensor):
@@ -68,6 +69,17 @@ def model_fixture(size, sd):
     out["instance_labels.sum"] = np.asarray(int(g.instance_labels.sum()))
     out["seg_mask.dtype"] = np.asarray(str(masks[0].dtype))
     out["seg_mask.unique"] = masks[0].unique().numpy()
+    # integer outputs of the (non-empty) panoptic branch: strided samples + histograms of the id maps, samples of the query x class
+    # logit volume the lifting consumes
+    out["seg_mask.sample"] = masks[0].reshape(-1)[::ISTRIDE].numpy()
+    out["seg_mask.hist"] = torch.bincount(masks[0].reshape(-1).long().clamp_min(0), minlength=8).numpy()
+    out["semantic_labels.sample"] = g.semantic_labels.reshape(-1)[::ISTRIDE].numpy()
+    out["instance_labels.sample"] = g.instance_labels.reshape(-1)[::ISTRIDE].numpy()
+    out["semantic_labels.hist"] = torch.bincount(g.semantic_labels.reshape(-1).long(), minlength=22).numpy()
+    qcl = g.seg_query_class_logits[0]
+    out["qcl.shape"] = np.asarray(qcl.shape)
+    out["qcl.sample"] = qcl.reshape(-1)[::STRIDE].numpy()
+    out["qcl.l2"] = np.asarray(float(qcl.double().norm()))
     out["image.small"] = torch.nn.functional.interpolate(img[0], size=(32, 32), mode="area").numpy()  # input checksum aid
     np.savez_compressed(os.path.join(HERE, f"model_{size}.npz"), **out)
     with open(os.path.join(HERE, f"model_{size}.json"), "w") as fh:

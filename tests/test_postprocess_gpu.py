@@ -42,3 +42,40 @@ def test_panoptic_postprocess_exact(order, target):
     g, masks, infos, qcl, qs = post_process_gaussians(g, res, B, 2, H, W, True)
     assert torch.equal(g.semantic_labels.cpu(), sem_ref) and torch.equal(g.instance_labels.cpu(), ins_ref)
     assert g.semantic_labels.dtype == torch.int32 and g.means.shape == (B, 2 * H * W, 3)
+
+
+def _network_like_logits(Q=100, T=2, h=128, w=128, C=21, kept=14, seed=0):
+    """class / mask logits with the statistics of the network's own output at 2 x 512^2 (mask size 128^2): `kept` confident non-void
+    queries (two stuff classes among them), smooth mask logits around -2.8 with unit-scale variation, so that segments border each other."""
+    g = torch.Generator().manual_seed(seed)
+    cls = torch.randn(1, Q, C, generator=g)
+    cls[:, :, C - 1] += 9.0
+    lab = [1, 1, 0, 5, 12, 19, 13, 1, 10, 3, 19, 7, 4, 15][:kept]
+    for i, c in enumerate(lab):
+        cls[0, 7 * i + 2, c] += 14.0
+    coarse = torch.randn(1 * Q * T, 1, h // 8, w // 8, generator=g)
+    msk = torch.nn.functional.interpolate(coarse, size=(h, w), mode="bilinear", align_corners=False).view(1, Q, T, h, w) * 2.2 - 2.8
+    return cls, msk + 0.05 * torch.randn(1, Q, T, h, w, generator=g)
+
+
+@pytest.mark.parametrize("target", [(512, 512), (256, 256)], ids=["512", "256"])
+def test_panoptic_postprocess_full_size(target):
+    """The kept-query kernels (argmax over kept queries at the target size, area / original-area counts, stuff fusing, the
+    [T*H*W, q, 21] query x class logit volume) at the benchmark's size on network-like logits: integer outputs bit-exact against the
+    oracle ON IDENTICAL INPUT LOGITS."""
+    from oracle import siu3r_oracle as O
+    from siu3r_amd.postprocess import VideoMask2FormerImageProcessor
+
+    cls, msk = _network_like_logits()
+    ref = O.panoptic_postprocess(cls, msk, target)[0]
+    assert len(ref["segments_info"]) >= 5 and any(s_["was_fused"] for s_ in ref["segments_info"])
+    out = dict(class_queries_logits=cls.cuda(), masks_queries_logits=msk.cuda())
+    res = VideoMask2FormerImageProcessor().post_process_panoptic_segmentation(out, threshold=0.5, target_sizes=[target], label_ids_to_fuse={0, 1})[0]
+    strip = lambda segs: [(s_["id"], s_["label_id"], s_["was_fused"]) for s_ in segs]
+    assert strip(res["segments_info"]) == strip(ref["segments_info"])
+    assert all(abs(x["score"] - y["score"]) <= 2e-6 for x, y in zip(res["segments_info"], ref["segments_info"]))
+    same = float((res["segmentation"].cpu() == ref["segmentation"]).float().mean())
+    print(f"[parity] full-size segmentation {target}: {len(ref['segments_info'])} segments, identical pixels {same:.7f}")
+    assert torch.equal(res["segmentation"].cpu(), ref["segmentation"]), f"segmentation differs on {1 - same:.2e} of the pixels"
+    err = float((res["query_class_logits"].cpu() - ref["query_class_logits"]).abs().max())
+    assert tuple(res["query_class_logits"].shape) == tuple(ref["query_class_logits"].shape) and err <= 2e-6, err

