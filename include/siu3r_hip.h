@@ -73,6 +73,30 @@ typedef struct {
   int32_t rope_ncols;
   int32_t map_gx, map_rm, map_rn; /* filled by the launcher (XCD-aware tile map); callers leave them 0 */
   uint64_t* trace;                /* tuning aid, normally NULL: 8 shader-clock stamps per workgroup (tools/gemm_trace.py) */
+  const void* w_x3;               /* bf16x3 on the LDS-DMA path: both planes interleaved per 32-deep K tile, bf16 [N, Kpad/32, 2, 32]
+                                     (hi 32 | lo 32); NULL = use w_hi / w_lo with the register-staged kernel */
+  /* two-level batching (bmod > 0): blockIdx.z = zo * bmod + zi; element offsets A: zo*sa + zi*sa_i, C: zo*sc + zi*sc_i, residual:
+     zo*sr + zi*sr_i; the weight set is zi (offset zi*sw); bias / ln_c1 / ln_c2 advance by zi*sbias floats.  This is how the two
+     decoder sides (dec_blocks / dec_blocks2, reference backbone_croco.py:231-255) run as ONE launch: zi = side, zo = batch item,
+     and a side's cross-attention memory is the OTHER view (a negative sa_i).  bmod == 0: single level (z*sa, z*sw, z*sc, z*sr). */
+  int32_t bmod;
+  int64_t sa_i, sc_i, sr_i, sbias;
+  /* LayerNorm folded into this GEMM (reference croco/blocks.py:127-130,186-191: x + f(LN(x))): A holds the UN-normalised rows, the
+     packed weight is W diag(gamma), and the epilogue computes rstd_m * (acc - mean_m * ln_c1[n]) + ln_c2[n] with
+     ln_c1[n] = sum_k W'[n,k], ln_c2[n] = sum_k beta_k W[n,k] + b[n] (bias must be NULL).  mean / rstd of row m come from ln_stats:
+     ln_tiles (mean, M2) partials of 64 columns each (the last one of K - 64*(ln_tiles-1)), written by the GEMM that produced A
+     (stats_out below), row (zo, zi, m) at float2 index ((zo*ln_sz + zi*ln_sz_i + m*ln_ldm) * ln_tiles). */
+  const float* ln_stats;
+  const float* ln_c1;
+  const float* ln_c2;
+  int32_t ln_tiles;
+  float ln_eps;
+  int64_t ln_ldm, ln_sz, ln_sz_i;
+  /* row statistics of THIS GEMM's output (out_mode 0, after bias / activation / residual): per 64-column tile the mean and the
+     centred sum of squares (Welford partials; merged by the consumer), float2 index ((zo*st_sz + zi*st_sz_i + m*st_ldm) * tiles_n + tile_n) */
+  float* stats_out;
+  int64_t st_ldm, st_sz, st_sz_i;
+  void* c_aux;                    /* optional bf16 copy of the output (same indexing as c): the next GEMM's A operand in bf16 mode */
 } siu3r_gemm_params;
 int siu3r_gemm(const siu3r_gemm_params* p, void* stream);
 

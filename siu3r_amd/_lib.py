@@ -31,7 +31,12 @@ class GemmParams(C.Structure):
         ("up_src", C.c_void_p), ("up_dtype", C.c_int32),
         ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("rope_pos", C.c_void_p), ("rope_ncols", C.c_int32),
         ("map_gx", C.c_int32), ("map_rm", C.c_int32), ("map_rn", C.c_int32),
-        ("trace", C.c_void_p),
+        ("trace", C.c_void_p), ("w_x3", C.c_void_p),
+        ("bmod", C.c_int32), ("sa_i", C.c_int64), ("sc_i", C.c_int64), ("sr_i", C.c_int64), ("sbias", C.c_int64),
+        ("ln_stats", C.c_void_p), ("ln_c1", C.c_void_p), ("ln_c2", C.c_void_p), ("ln_tiles", C.c_int32), ("ln_eps", C.c_float),
+        ("ln_ldm", C.c_int64), ("ln_sz", C.c_int64), ("ln_sz_i", C.c_int64),
+        ("stats_out", C.c_void_p), ("st_ldm", C.c_int64), ("st_sz", C.c_int64), ("st_sz_i", C.c_int64),
+        ("c_aux", C.c_void_p),
     ]
 
 

@@ -144,3 +144,30 @@ __device__ inline bf16x8 as_bf16x8(uint4 u) {
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// blockIdx.z -> (outer, inner) batch index and the operand offsets of siu3r_gemm_params' two-level batching
+struct siu3r_zoff {
+  int zo, zi;
+  int64_t a, w, c, r, bias;
+};
+__device__ __forceinline__ siu3r_zoff siu3r_batch_offsets(const siu3r_gemm_params& p, int z) {
+  siu3r_zoff o;
+  if (p.bmod > 0) {
+    o.zo = z / p.bmod;
+    o.zi = z - o.zo * p.bmod;
+    o.a = (int64_t)o.zo * p.sa + (int64_t)o.zi * p.sa_i;
+    o.c = (int64_t)o.zo * p.sc + (int64_t)o.zi * p.sc_i;
+    o.r = (int64_t)o.zo * p.sr + (int64_t)o.zi * p.sr_i;
+    o.w = (int64_t)o.zi * p.sw;
+    o.bias = (int64_t)o.zi * p.sbias;
+  } else {
+    o.zo = z;
+    o.zi = 0;
+    o.a = (int64_t)z * p.sa;
+    o.c = (int64_t)z * p.sc;
+    o.r = (int64_t)z * p.sr;
+    o.w = (int64_t)z * p.sw;
+    o.bias = 0;
+  }
+  return o;
+}

@@ -18,6 +18,7 @@
 #include "gemm_epilogue.h"
 
 int siu3r_gemm_dma_launch(const siu3r_gemm_params& p, int ni, void* stream);  // gemm_dma.hip (bf16 LDS-DMA fast path)
+int siu3r_gemm_dma_x3_launch(const siu3r_gemm_params& p, void* stream);       // gemm_dma.hip (bf16x3 LDS-DMA path, fp32 A)
 static const bool g_disable_dma = getenv("SIU3R_GEMM_NO_DMA") != nullptr;     // debugging / A-B switch
 // 128x64 tiles (two workgroups per CU) beat 128x128 (one per CU: 96 KiB ring) at every size measured on gfx950 --
 // finer wave quantisation and a second workgroup to overlap prologue/epilogue; 128x128 stays reachable for A/B runs
@@ -69,9 +70,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
   const int z = blockIdx.z;
 
   const int esz_a = A_F32 ? 4 : 2;
-  const unsigned char* Ab = (const unsigned char*)p.a + (int64_t)z * p.sa * esz_a;
-  const u16* Wh = (const u16*)p.w_hi + (int64_t)z * p.sw;
-  const u16* Wl = SPLIT ? (const u16*)p.w_lo + (int64_t)z * p.sw : nullptr;
+  const siu3r_zoff zof = siu3r_batch_offsets(p, z);
+  const unsigned char* Ab = (const unsigned char*)p.a + zof.a * esz_a;
+  const u16* Wh = (const u16*)p.w_hi + zof.w;
+  const u16* Wl = SPLIT ? (const u16*)p.w_lo + zof.w : nullptr;
 
   // ---- per-thread load geometry: chunk (8 k-elements) x 4 A rows, x WROWS weight rows
   const int chunk = t & 7, row0 = t >> 3;
@@ -306,6 +308,10 @@ int launch(const siu3r_gemm_params& pin, hipStream_t s) {
     const int rc = siu3r_gemm_dma_launch(p, NI, s);
     if (rc <= 0) return rc;  // 1: outside the buffer-addressed kernels' range -> register-staged kernel below
   }
+  if (p.w_x3 && NI == 1 && !g_disable_dma) {
+    const int rc = siu3r_gemm_dma_x3_launch(p, s);
+    if (rc <= 0) return rc;  // 1: outside the kernel's range -> register-staged bf16x3 below
+  }
   if (p.w_lo) {
     hipLaunchKernelGGL((gemm_kernel<1, 1, NI>), grid, block, 0, s, p);
   } else if (p.a_dtype == SIU3R_F32) {
@@ -342,9 +348,15 @@ extern "C" int siu3r_gemm(const siu3r_gemm_params* pp, void* stream) {
   if (p.rope_cos) SIU3R_CHECK(p.rope_sin && p.rope_pos && p.rope_ncols % 64 == 0 && p.rope_ncols <= p.n && p.act == 0 && p.out_mode == 0,
                               "siu3r_gemm: bad RoPE epilogue arguments");
   if (p.up_src) SIU3R_CHECK(p.a_mode == 1 && p.out_mode == 0 && p.oh % 2 == 0 && p.ow % 2 == 0, "siu3r_gemm: up_src needs conv mode with even output size");
+  if (p.ln_stats)
+    SIU3R_CHECK(p.ln_c1 && p.ln_c2 && !p.bias && p.a_mode == 0 && p.ln_tiles == (p.k + 63) / 64 && p.ln_tiles <= 16 && !p.relu_in,
+                "siu3r_gemm: folded LayerNorm needs c1/c2, no bias, dense A and ln_tiles == ceil(k/64) <= 16 (k=%d, ln_tiles=%d)", p.k, p.ln_tiles);
+  if (p.stats_out) SIU3R_CHECK(p.out_mode == 0 && !p.up_src, "siu3r_gemm: stats_out needs a plain row-major output");
+  if (p.c_aux) SIU3R_CHECK(p.out_mode == 0, "siu3r_gemm: c_aux needs a plain row-major output");
+  if (p.bmod > 0) SIU3R_CHECK(p.batch > 0 && p.batch % p.bmod == 0, "siu3r_gemm: batch %d is not a multiple of bmod %d", p.batch, p.bmod);
   // narrow tiles when 128x128 tiling would leave most of the 256 CUs without a workgroup, or N <= 64
   const int64_t tiles128 = (int64_t)((p.m + BM - 1) / BM) * ((p.n + 127) / 128) * (p.batch > 0 ? p.batch : 1);
-  const bool narrow = (p.n <= 64) || (tiles128 < g_narrow_max && p.n > 64);
+  const bool narrow = (p.n <= 64) || (tiles128 < g_narrow_max && p.n > 64) || p.w_x3 != nullptr;
   hipStream_t s = (hipStream_t)stream;
   return narrow ? launch<1>(p, s) : launch<2>(p, s);
 }

@@ -76,8 +76,9 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
   };
   stamp(0);
 
-  const u16* Ab = (const u16*)p.a + (int64_t)z * p.sa;
-  const u16* Wb = (const u16*)p.w_hi + (int64_t)z * p.sw;
+  const siu3r_zoff zof = siu3r_batch_offsets(p, z);
+  const u16* Ab = (const u16*)p.a + zof.a;
+  const u16* Wb = (const u16*)p.w_hi + zof.w;
 
   // ---- DMA geometry.  Piece g (8 rows x 128 B) of a tile; lane -> (row = 8 g + lane/8, physical chunk = lane%8);
   // the lane fetches the LOGICAL chunk that the swizzle stores there.
@@ -419,6 +420,272 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
 #endif
 }
 
+
+// ---- bf16x3 on the LDS-DMA path -------------------------------------------------------------------------------------------------
+// The 1e-3 parity mode multiplies fp32 activations: C = A_hi W_hi + A_lo W_hi + A_hi W_lo with A = A_hi + A_lo split into two bf16
+// halves (16 mantissa bits survive).  Here A travels as fp32 straight from HBM into LDS (same LDS-DMA ring, same 128-byte rows: a K
+// tile is 32 fp32 = 128 B) and is split in REGISTERS after the fragment read (hi = the upper 16 bits, lo = bf16(a - hi): two ands,
+// two subtractions, one byte permute and one v_cvt_pk_bf16_f32 per pair -- ~24 VALU per 8-element fragment, issued under the
+// 3 MFMAs it feeds); W is pre-split and pre-INTERLEAVED at load time as [n][k / 32][hi 32 | lo 32], so that one 128-byte row of the
+// W tile carries both planes of a K tile and the tile / piece / swizzle geometry is byte for byte that of the bf16 kernel.
+// Per K tile and workgroup the ring moves the same 24 KiB as the bf16 kernel does per 64-deep tile, for 3/2 the MFMA work at half
+// the depth: the mode costs about two bf16 launches instead of the 3.2 of the register-staged kernel (gemm.hip), and activations
+// need no second representation in HBM.  NI = 1 (128 x 64 tiles); MODE 0 (dense) and MODE 1 (conv, cin % 32 == 0).
+template <int MODE, bool RELU, int KSPL>
+__global__ __launch_bounds__(256 * KSPL) void gemm_dma_x3_kernel(const siu3r_gemm_params p) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int BN = 64, BKE = 32;
+  constexpr int B_TILE_BYTES = BN * 128;
+  constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
+  constexpr int A_DMA = 4 / KSPL, W_DMA = 2 / KSPL, LP = A_DMA + W_DMA;
+  constexpr int KSW = 2 / KSPL;  // k-substeps (of 16) of a K tile handled by one wave
+  static_assert(STAGES * STAGE_BYTES >= siu3r_epi::staging_bytes<1, KSPL>(), "epilogue staging must fit the ring");
+  __shared__ __attribute__((aligned(128))) unsigned char smem[STAGES * STAGE_BYTES];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int khalf = wave >> 2, wq = wave & 3;
+  const int wm = wq >> 1, wn = wq & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int M = p.m, N = p.n, K = p.k, kpad = p.kpad;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+  const int map_gx = p.map_gx;
+  const int ry = xcd / map_gx, rx = xcd - ry * map_gx;
+  const int lm = li / p.map_rn, ln = li - lm * p.map_rn;
+  const int tile_m = ry * p.map_rm + lm, tile_n = rx * p.map_rn + ln;
+  if (lm >= p.map_rm || tile_m >= tiles_m || tile_n >= tiles_n) return;
+  const int z = blockIdx.z;
+  const int nkt = kpad / BKE;
+
+  const siu3r_zoff zof = siu3r_batch_offsets(p, z);
+  const float* Ab = (const float*)p.a + zof.a;
+  const u16* Wb = (const u16*)p.w_x3 + zof.w * 2;  // interleaved planes: 2 * kpad bf16 per row
+
+  const int prow = lane >> 3, pchunk = lane & 7;
+  const int cin = p.cin, iw = p.iw, ih = p.ih, kw = p.kw, kh = p.kh;
+  const int pad_bias = (MODE != 0) ? (p.pad * iw + p.pad) * cin * 4 : 0;
+  __amdgpu_buffer_rsrc_t rA, rW;
+  if (MODE == 0)
+    rA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, (short)0, (int)(((int64_t)(M - 1) * p.lda + K) * 4), RSRC_FLAGS);
+  else
+    rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Ab - pad_bias), (short)0, (int)OOB, RSRC_FLAGS);
+  rW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, (short)0, (int)((int64_t)N * kpad * 4), RSRC_FLAGS);
+
+  unsigned a_voff[A_DMA], a_mask[A_DMA];
+  int a_c[A_DMA];
+#pragma unroll
+  for (int i = 0; i < A_DMA; ++i) {
+    const int r = (wave * A_DMA + i) * 8 + prow;
+    a_c[i] = pchunk ^ ((r >> 1) & 7);  // logical 16-byte chunk (4 fp32) of the row's K-tile slice
+    int m = tile_m * BM + r;
+    const bool row_ok = m < M;
+    if (!row_ok) m = M - 1;
+    a_voff[i] = a_mask[i] = 0;
+    if (MODE == 0) {
+      a_voff[i] = row_ok ? (unsigned)(((int64_t)m * p.lda) * 4 + a_c[i] * 16) : OOB;
+    } else {
+      const int ohw = p.oh * p.ow;
+      const int b = m / ohw, rr = m - b * ohw;
+      const int oy = rr / p.ow, ox = rr - oy * p.ow;
+      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+      a_voff[i] = (unsigned)((((b * ih + iy0) * iw + ix0) * cin) * 4 + a_c[i] * 16 + pad_bias);
+      unsigned mk = 0;
+      for (int ky = 0; ky < kh; ++ky)
+        for (int kx = 0; kx < kw; ++kx)
+          if (iy0 + ky >= 0 && iy0 + ky < ih && ix0 + kx >= 0 && ix0 + kx < iw) mk |= 1u << (ky * kw + kx);
+      a_mask[i] = row_ok ? mk : 0u;
+    }
+  }
+  unsigned w_voff[W_DMA];
+#pragma unroll
+  for (int i = 0; i < W_DMA; ++i) {
+    const int r = (wave * W_DMA + i) * 8 + prow;
+    const int c = pchunk ^ ((r >> 1) & 7);
+    int n = tile_n * BN + r;
+    if (n > N - 1) n = N - 1;
+    w_voff[i] = (unsigned)(((int64_t)n * kpad) * 4 + c * 16);
+  }
+  const bool ktail = (K & (BKE - 1)) != 0;
+
+  int cur_c0 = 0, cur_kx = 0, cur_toff = 0, cur_row = 0;
+  unsigned cur_bit = 1u;
+  auto cursor_advance = [&]() {
+    cur_c0 += BKE;
+    cur_toff += BKE * 4;
+    if (cur_c0 == cin) {
+      cur_c0 = 0;
+      cur_bit <<= 1;
+      if (++cur_kx == kw) {
+        cur_kx = 0;
+        cur_row += iw * cin * 4;
+      }
+      cur_toff = cur_row + cur_kx * cin * 4;
+    }
+  };
+  auto issue_a = [&](int kt, int stage, int i) {
+    unsigned char* dst = smem + stage * STAGE_BYTES + (wave * A_DMA + i) * 1024;
+    if (MODE == 0) {
+      unsigned voff = a_voff[i];
+      if (ktail && kt == nkt - 1) voff = (kt * BKE + a_c[i] * 4 < K) ? voff : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, voff, kt * (BKE * 4), 0, 0);
+    } else {
+      const unsigned voff = (a_mask[i] & cur_bit) ? a_voff[i] : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, voff, cur_toff, 0, 0);
+    }
+  };
+  auto issue_w = [&](int kt, int stage, int i) {
+    unsigned char* dst = smem + stage * STAGE_BYTES + A_TILE_BYTES + (wave * W_DMA + i) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr)dst, 16, w_voff[i], kt * 128, 0, 0);
+  };
+  auto issue = [&](int kt, int stage) {
+#pragma unroll
+    for (int i = 0; i < A_DMA; ++i) issue_a(kt, stage, i);
+#pragma unroll
+    for (int i = 0; i < W_DMA; ++i) issue_w(kt, stage, i);
+    if (MODE == 1) cursor_advance();
+  };
+
+  f32x16 acc[2][1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+  // A row r, k-substep ks (16 k = 64 B), lane half lh: fp32 chunks c = 4 ks + 2 lh and c + 1  ->  (r*128 | (((2 lh) ^ swz) << 4)) ^ (ks << 6)
+  // and that ^ 16;  W row n: hi chunk 2 ks + lh, lo chunk 4 + 2 ks + lh  ->  (n*128 | ((lh ^ swz) << 4)) ^ (ks << 5) and that ^ 64
+  const unsigned int lds_base = (unsigned int)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned int offA[2], offB;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wm * 64 + i * 32 + l31;
+    offA[i] = row * 128 + ((((lh << 1)) ^ ((row >> 1) & 7)) << 4);
+  }
+  {
+    const int row = wn * 32 + l31;
+    offB = A_TILE_BYTES + row * 128 + ((lh ^ ((row >> 1) & 7)) << 4);
+  }
+  // per k-substep: A fragments of the two 32-row blocks (2 x 2 reads) and the W hi / lo fragments (2 reads)
+  struct Frag {
+    u32x4 a[2][2], bh, bl;
+  };
+  auto read_sub = [&](unsigned int sbase, int ks, Frag& f) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned int ad = (sbase + offA[i]) ^ (ks << 6);
+      asm volatile("ds_read_b128 %0, %1" : "=v"(f.a[i][0]) : "v"(ad) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(f.a[i][1]) : "v"(ad ^ 16u) : "memory");
+    }
+    const unsigned int adb = (sbase + offB) ^ (ks << 5);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(f.bh) : "v"(adb) : "memory");
+    asm volatile("ds_read_b128 %0, %1" : "=v"(f.bl) : "v"(adb ^ 64u) : "memory");
+  };
+  auto issue_tile_reads = [&](int stage, Frag (&f)[KSW]) {
+    const unsigned int sbase = lds_base + stage * STAGE_BYTES;
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) read_sub(sbase, khalf * KSW + j, f[j]);
+  };
+  // hi = upper 16 bits (truncation), lo = bf16_rne(a - hi): a = hi + lo up to 2^-17 |a|
+  auto split8 = [&](const u32x4& v0, const u32x4& v1, bf16x8& hi, bf16x8& lo) {
+    unsigned int w[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    union { u32x4 u; bf16x8 h; } H, L;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned int x0 = w[2 * q], x1 = w[2 * q + 1];
+      if (RELU) {
+        x0 = (x0 & 0x80000000u) ? 0u : x0;
+        x1 = (x1 & 0x80000000u) ? 0u : x1;
+      }
+      const unsigned int h0 = x0 & 0xffff0000u, h1 = x1 & 0xffff0000u;
+      const float l0 = __uint_as_float(x0) - __uint_as_float(h0), l1 = __uint_as_float(x1) - __uint_as_float(h1);
+      H.u[q] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+      L.u[q] = pack_bf16x2(l0, l1);
+    }
+    hi = H.h;
+    lo = L.h;
+  };
+#define SIU3R_X3_WAIT(CNT) asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(f[j].a[0][0]), "+v"(f[j].a[0][1]), "+v"(f[j].a[1][0]), "+v"(f[j].a[1][1]), "+v"(f[j].bh), "+v"(f[j].bl)::"memory")
+  auto tile_body = [&](int kt, int st, Frag (&f)[KSW], Frag (&nf)[KSW]) {
+    const int kt_next = (kt + 2 < nkt) ? kt + 2 : -1;
+    int stage_next = st + 2;
+    if (stage_next >= STAGES) stage_next -= STAGES;
+    int stage_read = st + 1;
+    if (stage_read >= STAGES) stage_read -= STAGES;
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+      if (KSW == 2 && j == 0) SIU3R_X3_WAIT(6);
+      else SIU3R_X3_WAIT(0);
+      if (KSW == 1 && kt_next >= 0) {
+        // one k-substep per wave: the pieces of tile kt+2 go out BEFORE the counted wait below, so that "LP pieces may remain
+        // in flight" means tile kt+2's and tile kt+1 has landed (their stage was last read before the previous barrier)
+#pragma unroll
+        for (int i = 0; i < A_DMA; ++i) issue_a(kt_next, stage_next, i);
+#pragma unroll
+        for (int i = 0; i < W_DMA; ++i) issue_w(kt_next, stage_next, i);
+      }
+      if (j == KSW - 1 && kt + 1 < nkt) {
+        if (kt_next >= 0) {
+          if (LP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_tile_reads(stage_read, nf);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      union { u32x4 u; bf16x8 h; } bh, bl;
+      bh.u = f[j].bh;
+      bl.u = f[j].bl;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        bf16x8 ah, al;
+        split8(f[j].a[i][0], f[j].a[i][1], ah, al);
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh.h, acc[i][0], 0, 0, 0);
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl.h, acc[i][0], 0, 0, 0);
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh.h, acc[i][0], 0, 0, 0);
+      }
+      if (KSW == 2 && kt_next >= 0 && j == 0) {
+#pragma unroll
+        for (int i = 0; i < A_DMA; ++i) issue_a(kt_next, stage_next, i);
+#pragma unroll
+        for (int i = 0; i < W_DMA; ++i) issue_w(kt_next, stage_next, i);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MODE == 1 && kt_next >= 0) cursor_advance();
+  };
+
+  issue(0, 0);
+  if (nkt > 1) issue(1, 1);
+  if (nkt > 1) {
+    if (LP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  Frag f0[KSW], f1[KSW];
+  issue_tile_reads(0, f0);
+  int st = 0;
+  for (int kt = 0; kt < nkt; kt += 2) {
+    tile_body(kt, st, f0, f1);
+    st = (st + 1 == STAGES) ? 0 : st + 1;
+    if (kt + 1 < nkt) {
+      tile_body(kt + 1, st, f1, f0);
+      st = (st + 1 == STAGES) ? 0 : st + 1;
+    }
+  }
+#undef SIU3R_X3_WAIT
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  siu3r_epi::run<1, KSPL>(p, acc, smem, tile_m, tile_n, z, t);
+#endif
+}
+
 }  // namespace siu3r_gemm_dma
 
 // Called by siu3r_gemm() (gemm.hip) for bf16 activations without the bf16x3 split, dense or conv gather.
@@ -459,5 +726,39 @@ int siu3r_gemm_dma_launch(const siu3r_gemm_params& p, int ni, void* stream) {
 #undef SIU3R_DMA_MODES
 #undef SIU3R_DMA_LAUNCH
   SIU3R_LAUNCH_CHECK("siu3r_gemm(dma)");
+  return 0;
+}
+
+// bf16x3 with fp32 activations on the LDS-DMA path (p.w_x3 = interleaved hi/lo planes).  Returns 1 when the problem is outside
+// what the kernel covers (the caller falls back to the register-staged bf16x3 kernel of gemm.hip).
+int siu3r_gemm_dma_x3_launch(const siu3r_gemm_params& p, void* stream) {
+  using namespace siu3r_gemm_dma;
+  const int64_t lim = 0xfffff000ll;
+  if (!p.w_x3 || p.a_dtype != SIU3R_F32 || (int64_t)p.n * p.kpad * 4 >= lim) return 1;
+  int mode;
+  if (p.a_mode == 0) {
+    mode = 0;
+    if (((int64_t)(p.m - 1) * p.lda + p.k) * 4 >= lim || p.relu_in) return 1;
+  } else if (p.a_mode == 1) {
+    const int64_t img = (int64_t)(p.m / (p.oh * p.ow)) * p.ih * p.iw * p.cin * 4 + (int64_t)(p.pad * p.iw + p.pad) * p.cin * 4;
+    if (img >= lim || p.cin % 32 != 0 || p.kh * p.kw > 32 || p.kpad != p.k) return 1;
+    mode = 1;
+  } else {
+    return 1;
+  }
+  const int tiles = 8 * p.map_rm * p.map_rn;
+  dim3 grid(tiles, 1, p.batch > 0 ? p.batch : 1);
+  hipStream_t s = (hipStream_t)stream;
+  static const bool no_ksplit = getenv("SIU3R_GEMM_NO_KSPLIT") != nullptr;
+  if (no_ksplit) {
+    if (mode == 0) hipLaunchKernelGGL((gemm_dma_x3_kernel<0, false, 1>), grid, dim3(256), 0, s, p);
+    else if (p.relu_in) hipLaunchKernelGGL((gemm_dma_x3_kernel<1, true, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_dma_x3_kernel<1, false, 1>), grid, dim3(256), 0, s, p);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((gemm_dma_x3_kernel<0, false, 2>), grid, dim3(512), 0, s, p);
+    else if (p.relu_in) hipLaunchKernelGGL((gemm_dma_x3_kernel<1, true, 2>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((gemm_dma_x3_kernel<1, false, 2>), grid, dim3(512), 0, s, p);
+  }
+  SIU3R_LAUNCH_CHECK("siu3r_gemm(dma x3)");
   return 0;
 }

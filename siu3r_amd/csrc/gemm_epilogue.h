@@ -33,7 +33,7 @@ __device__ __forceinline__ float gelu_fast(float x) {
 }
 
 template <int NI, int KSPL = 1>
-constexpr int staging_bytes() { return 128 * (64 * NI + 4) * 4; }
+constexpr int staging_bytes() { return 128 * (64 * NI + 4) * 4 + 1024; }  // tile + per-row (mean, rstd) of a folded LayerNorm
 
 // The whole 128 x BN accumulator tile is staged once (two raw barriers); every thread then owns ONE 8-column chunk
 // (t % CHUNKS, so its bias / RoPE axis are loop invariants) of NTASK rows.  All global reads of a group of 4 rows --
@@ -58,7 +58,14 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
   const int l31 = lane & 31, lh = lane >> 5;
   unsigned char* Cb = (unsigned char*)p.c;
   const unsigned char* Rb = (const unsigned char*)p.residual;
-  const int64_t c_boff = (int64_t)z * p.sc, r_boff = (int64_t)z * p.sr;
+  const siu3r_zoff zof = siu3r_batch_offsets(p, z);
+  const int64_t c_boff = zof.c, r_boff = zof.r;
+  const float* biasp = p.bias ? p.bias + zof.bias : nullptr;
+  // ---- LayerNorm folded into this GEMM: rstd_m * (acc - mean_m * c1[n]) + c2[n]
+  const bool ln = p.ln_stats != nullptr;
+  const float* c1p = ln ? p.ln_c1 + zof.bias : nullptr;
+  const float* c2p = ln ? p.ln_c2 + zof.bias : nullptr;
+  float* s_ln = cs + BM * LDC;  // [BM][2] behind the staged tile
   const int c_esz = p.c_dtype == SIU3R_F32 ? 4 : 2;
   const int r_esz = p.r_dtype == SIU3R_F32 ? 4 : 2;
   const int M = p.m, N = p.n;
@@ -82,18 +89,46 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
   float bias[8], pbias[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias[e] = pbias[e] = 0.f;
-  if (p.bias && col_ok) {
-    if (nv == 8 && (((uintptr_t)(p.bias + co0)) & 15) == 0) {
-      const float4 a = *(const float4*)(p.bias + co0), b = *(const float4*)(p.bias + co0 + 4);
+  const float* addp = ln ? c2p : biasp;  // the additive per-column term: bias, or the folded LayerNorm's c2
+  if (addp && col_ok) {
+    if (nv == 8 && (((uintptr_t)(addp + co0)) & 15) == 0) {
+      const float4 a = *(const float4*)(addp + co0), b = *(const float4*)(addp + co0 + 4);
       bias[0] = a.x; bias[1] = a.y; bias[2] = a.z; bias[3] = a.w; bias[4] = b.x; bias[5] = b.y; bias[6] = b.z; bias[7] = b.w;
     } else {
       _Pragma("unroll") for (int e = 0; e < 8; ++e)
-        if (e < nv) bias[e] = p.bias[co0 + e];
+        if (e < nv) bias[e] = addp[co0 + e];
     }
     if (rope) {
       const int pn0 = tile_n * BN + pc * 8;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) pbias[e] = p.bias[pn0 + e];
+      for (int e = 0; e < 8; ++e) pbias[e] = addp[pn0 + e];
+    }
+  }
+  float c1[8], pc1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) c1[e] = pc1[e] = 0.f;
+  if (ln && col_ok) {
+    _Pragma("unroll") for (int e = 0; e < 8; ++e)
+      if (e < nv) c1[e] = c1p[co0 + e];
+    if (rope) {
+      const int pn0 = tile_n * BN + pc * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pc1[e] = c1p[pn0 + e];
+    }
+  }
+  // statistics of the tile's rows: thread r < 128 merges the 64-column (mean, M2) partials of row r (Chan's formula; counts are 64
+  // except for the last partial).  The loads go out here, the merge runs behind the first barrier (the ring is then free)
+  constexpr int LN_TMAX = 16;
+  float2 lnp[LN_TMAX];
+  const bool ln_row = ln && t < BM && tile_m * BM + t < M;
+  if (ln) {
+#pragma unroll
+    for (int i = 0; i < LN_TMAX; ++i) lnp[i] = make_float2(0.f, 0.f);
+    if (ln_row) {
+      const float2* sp = (const float2*)p.ln_stats + ((int64_t)zof.zo * p.ln_sz + (int64_t)zof.zi * p.ln_sz_i + (int64_t)(tile_m * BM + t) * p.ln_ldm) * p.ln_tiles;
+#pragma unroll
+      for (int i = 0; i < LN_TMAX; ++i)
+        if (i < p.ln_tiles) lnp[i] = sp[i];
     }
   }
 
@@ -130,6 +165,27 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
     asm volatile("" ::: "memory");
   };
   lds_barrier();  // main loop no longer reads the ring
+  if (ln && t < BM) {
+    float mu = 0.f, rs = 0.f;
+    if (ln_row) {
+      const int Cn = p.k, last = Cn - 64 * (p.ln_tiles - 1);
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < LN_TMAX; ++i)
+        if (i < p.ln_tiles) sum += lnp[i].x * (float)(i == p.ln_tiles - 1 ? last : 64);
+      mu = sum / (float)Cn;
+      float m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < LN_TMAX; ++i)
+        if (i < p.ln_tiles) {
+          const float d = lnp[i].x - mu;
+          m2 += lnp[i].y + d * d * (float)(i == p.ln_tiles - 1 ? last : 64);
+        }
+      rs = rsqrtf(m2 / (float)Cn + p.ln_eps);
+    }
+    s_ln[2 * t] = mu;
+    s_ln[2 * t + 1] = rs;
+  }
   if (KSPL == 2) {
     if (kh == 1) {
 #pragma unroll
@@ -185,15 +241,24 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
     for (int k = 0; k < G; ++k) {
       const int lr = row0 + (g * G + k) * RPP;
       const int m = tile_m * BM + lr;
-      if (!col_ok || m >= M) continue;
+      if (m >= M) continue;                       // (uniform over the 8 / 16 threads of a row)
+      if (!col_ok && !p.stats_out) continue;
       float v[8];
       {
         const float4 a = *(const float4*)(cs + lr * LDC + chunk * 8);
         const float4 b = *(const float4*)(cs + lr * LDC + chunk * 8 + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
       }
+      float ln_mu = 0.f, ln_rs = 1.f;
+      if (ln) {
+        ln_mu = s_ln[2 * lr];
+        ln_rs = s_ln[2 * lr + 1];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += bias[e];
+        for (int e = 0; e < 8; ++e) v[e] = ln_rs * (v[e] - ln_mu * c1[e]) + bias[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bias[e];
+      }
       // ---- RoPE2D on q|k columns
       if (rope) {
         float4 a = *(const float4*)(cs + lr * LDC + pc * 8);
@@ -203,7 +268,7 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
         const float ss[8] = {rs[k][0].x, rs[k][0].y, rs[k][0].z, rs[k][0].w, rs[k][1].x, rs[k][1].y, rs[k][1].z, rs[k][1].w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float o = pv[e] + pbias[e];
+          const float o = ln ? ln_rs * (pv[e] - ln_mu * pc1[e]) + pbias[e] : pv[e] + pbias[e];
           v[e] = upper ? (v[e] * cc[e] + o * ss[e]) : (v[e] * cc[e] - o * ss[e]);
         }
       }
@@ -227,7 +292,7 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
         oidx = (((int64_t)b * (p.ih * p.up) + iy * p.up + ky) * (p.iw * p.up) + ix * p.up + kx) * p.cout + co0;
       }
       // ---- fused bilinear x2 (align_corners=True) upsample-add of a low-res NHWC map with n channels
-      if (p.up_src) {
+      if (p.up_src && col_ok) {
         const int ohw = p.oh * p.ow;
         const int b = m / ohw, rr = m - b * ohw;
         const int oy = rr / p.ow, ox = rr - oy * p.ow;
@@ -262,6 +327,32 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
             if (e < nv) v[e] += load_as_f32(Rb, p.r_dtype, r_boff + oidx + e);
         }
       }
+      // ---- row statistics of the output for the LayerNorm folded into the NEXT GEMM: (mean, centred sum of squares) of this
+      // row's 64-column group, reduced over the group's 8 threads (consecutive lanes), written by the first of them
+      if (p.stats_out) {
+        const int n64 = min(64, N - (n0 & ~63));   // valid columns of the group (> 0 for the group's first chunk)
+        float s1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1 += e < nv ? v[e] : 0.f;
+        s1 += __shfl_xor(s1, 1);
+        s1 += __shfl_xor(s1, 2);
+        s1 += __shfl_xor(s1, 4);
+        const float mean = s1 / (float)max(n64, 1);
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[e] - mean;
+          s2 += e < nv ? d * d : 0.f;
+        }
+        s2 += __shfl_xor(s2, 1);
+        s2 += __shfl_xor(s2, 2);
+        s2 += __shfl_xor(s2, 4);
+        if ((chunk & 7) == 0 && n64 > 0) {
+          const int64_t row = (int64_t)zof.zo * p.st_sz + (int64_t)zof.zi * p.st_sz_i + (int64_t)m * p.st_ldm;
+          ((float2*)p.stats_out)[row * ((N + 63) >> 6) + (n0 >> 6)] = make_float2(mean, s2);
+        }
+        if (!col_ok) continue;
+      }
       // ---- store
       const int64_t cidx = c_boff + oidx;
       if (full && (((uintptr_t)Cb + cidx * c_esz) & 15) == 0) {
@@ -269,9 +360,13 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.v[e] = v[e];
         store8_from_f32(Cb, p.c_dtype, cidx, o);
+        if (p.c_aux) store8_from_f32(p.c_aux, SIU3R_BF16, cidx, o);
       } else {
         _Pragma("unroll") for (int e = 0; e < 8; ++e)
-          if (e < nv) store_from_f32(Cb, p.c_dtype, cidx + e, v[e]);  // cout % 8 == 0: no straddling
+          if (e < nv) {
+            store_from_f32(Cb, p.c_dtype, cidx + e, v[e]);  // cout % 8 == 0: no straddling
+            if (p.c_aux) store_from_f32(p.c_aux, SIU3R_BF16, cidx + e, v[e]);
+          }
       }
     }
   }

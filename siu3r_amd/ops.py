@@ -49,11 +49,12 @@ def _p(t: Optional[torch.Tensor]):
 class PackedWeight:
     hi: torch.Tensor                 # bf16 [N, Kpad]
     lo: Optional[torch.Tensor]       # bf16 [N, Kpad] (bf16x3 mode) or None
-    bias: Optional[torch.Tensor]     # fp32
-    n: int
-    k: int
-    kpad: int
-    meta: dict
+    bias: Optional[torch.Tensor] = None  # fp32
+    x3: Optional[torch.Tensor] = None    # bf16 [N, Kpad/32, 2, 32]: hi | lo interleaved per 32-deep K tile (bf16x3 on the LDS-DMA path)
+    n: int = 0
+    k: int = 0
+    kpad: int = 0
+    meta: dict = None
 
 
 def split_bf16(x2d: torch.Tensor, want_lo: bool, kpad: Optional[int] = None):
@@ -72,11 +73,65 @@ def pack_matrix(w2d: torch.Tensor, bias: Optional[torch.Tensor], split: bool, **
     w2d = w2d.contiguous().float()
     hi, lo, kpad = split_bf16(w2d, split)
     b = None if bias is None else bias.detach().float().contiguous()
-    return PackedWeight(hi, lo, b, w2d.shape[0], w2d.shape[1], kpad, meta)
+    x3 = None
+    if lo is not None:  # load-time layout plumbing: one 128-byte row segment per K tile = [hi 32 | lo 32]
+        n_ = w2d.shape[0]
+        x3 = torch.stack((hi.view(n_, kpad // 32, 32), lo.view(n_, kpad // 32, 32)), dim=2).contiguous()
+    return PackedWeight(hi=hi, lo=lo, bias=b, x3=x3, n=w2d.shape[0], k=w2d.shape[1], kpad=kpad, meta=meta)
 
 
 def pack_linear(weight, bias, split):
     return pack_matrix(weight, bias, split)
+
+
+def pack_linear_ln(weight, bias, gamma, beta, split) -> PackedWeight:
+    """A Linear behind a LayerNorm, folded:  LN(x) W^T + b = rstd (x W'^T - mean c1) + c2  with W' = W diag(gamma),
+    c1[n] = sum_k W'[n,k] (of the ROUNDED operand the MFMA multiplies) and c2 = W beta + b.  The GEMM then reads the un-normalised
+    rows and applies the row statistics in its epilogue (siu3r_gemm_params.ln_*)."""
+    w = weight.float()
+    pw = pack_matrix(w * gamma.float()[None, :], None, split)
+    rounded = pw.hi.float() if pw.lo is None else pw.hi.float() + pw.lo.float()
+    c2 = w @ beta.float()
+    if bias is not None:
+        c2 = c2 + bias.float()
+    pw.meta = dict(pw.meta or {}, ln_c1=rounded.sum(1).contiguous(), ln_c2=c2.contiguous())
+    return pw
+
+
+def stack_packed(pws: Sequence[PackedWeight]) -> PackedWeight:
+    """Weight sets of equal shape as ONE packed tensor with a leading group axis (the two decoder sides in one launch)."""
+    st = lambda k: None if getattr(pws[0], k) is None else torch.stack([getattr(w, k) for w in pws]).contiguous()
+    meta = dict(pws[0].meta or {})
+    for k in ("ln_c1", "ln_c2"):
+        if k in meta:
+            meta[k] = torch.stack([w.meta[k] for w in pws]).contiguous()
+    meta["groups"] = len(pws)
+    return PackedWeight(hi=st("hi"), lo=st("lo"), bias=st("bias"), x3=st("x3"), n=pws[0].n, k=pws[0].k, kpad=pws[0].kpad, meta=meta)
+
+
+class RowStats:
+    """Per-row LayerNorm statistics of an activation tensor [..., C] (C <= 1024): fp32 [rows, ceil(C/64), 2] = (mean, centred sum
+    of squares) of every 64-column group, written by the epilogue of the GEMM that produced the tensor (stats_out) and merged by
+    the epilogue of the GEMM that consumes its LayerNorm (ln).  `base` is the full tensor the row numbering refers to."""
+
+    def __init__(self, base: torch.Tensor):
+        assert base.is_contiguous()
+        self.base, self.C = base, base.shape[-1]
+        self.tiles = (self.C + 63) // 64
+        assert self.tiles <= 16, "folded LayerNorm supports up to 1024 channels"
+        self.buf = torch.empty((base.numel() // self.C, self.tiles, 2), dtype=torch.float32, device=base.device)
+
+    def row_of(self, view: torch.Tensor) -> int:
+        off = view.storage_offset() - self.base.storage_offset()
+        assert off % self.C == 0 and view.shape[-1] == self.C
+        return off // self.C
+
+    def ptr(self, row: int) -> int:
+        return self.buf.data_ptr() + row * self.tiles * 8
+
+    def div(self, stride: int) -> int:
+        assert stride % self.C == 0, (stride, self.C)
+        return stride // self.C
 
 
 def pack_conv(weight: torch.Tensor, bias, split, cin_pad: Optional[int] = None) -> PackedWeight:
@@ -145,7 +200,9 @@ def _gemm_launch(p: GemmParams):
         return
     # label with the kernel the launcher will pick (mirrors gemm.hip / gemm_dma.hip dispatch) so that the event
     # averages line up with rocprofv3's per-kernel rows
-    if p.w_lo:
+    if p.w_x3 and p.a_mode in (0, 1) and not (p.a_mode == 0 and p.relu_in) and not (p.a_mode == 1 and (p.cin % 32 or p.kpad != p.k)):
+        variant = "gemm_dma_x3_kernel (bf16x3, fp32 A)"
+    elif p.w_lo:
         variant = "gemm_kernel<1,1,1> (bf16x3)"
     elif p.a_dtype == F32 or p.a_mode == 2:
         variant = "gemm_kernel<1,0,1> (fp32 A)"
@@ -173,6 +230,7 @@ def set_gemm_trace(buf: Optional[torch.Tensor]):
 
 def _fill_common(p: GemmParams, a, pw: PackedWeight, out, act, residual, relu_in):
     p.a, p.w_hi, p.w_lo, p.c = _p(a), _p(pw.hi), _p(pw.lo), _p(out)
+    p.w_x3 = _p(pw.x3)
     p.trace = _p(_trace_buf)
     p.bias = _p(pw.bias)
     p.residual = _p(residual)
@@ -212,12 +270,34 @@ def _rows_layout(t: torch.Tensor):
     raise RuntimeError(f"unsupported strided layout {tuple(t.shape)} / {tuple(t.stride())}")
 
 
+def _apply_ln_stats_aux(p: GemmParams, pw: PackedWeight, x, out, lda, ldc, strides, ln, stats_out, aux_out, x_first=None):
+    """strides = (sa, sa_i, sc, sc_i): batch strides of A and C in elements (0 when absent); x_first: the view whose storage offset
+    locates A's first row (differs from x for a flipped group order)."""
+    sa, sa_i, sc, sc_i = strides
+    if ln is not None:
+        assert isinstance(ln, RowStats) and "ln_c1" in (pw.meta or {}), "ln= needs a weight packed with pack_linear_ln"
+        assert pw.bias is None and ln.C == pw.k
+        p.ln_stats = ln.ptr(ln.row_of(x_first if x_first is not None else x))
+        p.ln_c1, p.ln_c2 = _p(pw.meta["ln_c1"]), _p(pw.meta["ln_c2"])
+        p.ln_tiles, p.ln_eps = ln.tiles, float(pw.meta.get("ln_eps", 1e-6))
+        p.ln_ldm, p.ln_sz, p.ln_sz_i = ln.div(lda), (ln.div(abs(sa)) if sa else 0), (ln.div(abs(sa_i)) * (1 if sa_i >= 0 else -1) if sa_i else 0)
+    if stats_out is not None:
+        assert isinstance(stats_out, RowStats) and stats_out.C == pw.n and out.dtype == torch.float32
+        p.stats_out = stats_out.ptr(stats_out.row_of(out))
+        p.st_ldm, p.st_sz, p.st_sz_i = stats_out.div(ldc), (stats_out.div(sc) if sc else 0), (stats_out.div(sc_i) if sc_i else 0)
+    if aux_out is not None:
+        assert aux_out.dtype == torch.bfloat16 and aux_out.shape == out.shape and aux_out.stride() == out.stride()
+        p.c_aux = _p(aux_out)
+
+
 def linear(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=ACT_NONE,
            residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, relu_in=False,
-           rope=None):
+           rope=None, ln: Optional[RowStats] = None, stats_out: Optional[RowStats] = None, aux_out: Optional[torch.Tensor] = None):
     """y[..., N] = act(x[..., K] @ W^T + b) (+ residual).  x / out / residual may be strided views whose last
     dim is contiguous and which decompose into Z batches of M rows (e.g. tokens[:, :-1]).
-    rope = (cos, sin, positions int64 [rows, 2] contiguous, ncols): fused RoPE2D on output columns [0, ncols)."""
+    rope = (cos, sin, positions int64 [rows, 2] contiguous, ncols): fused RoPE2D on output columns [0, ncols).
+    ln: x holds UN-normalised rows and pw was packed by pack_linear_ln: the LayerNorm is applied in the epilogue from these row
+    statistics.  stats_out: write the row statistics of the (fp32) output for a later ln=.  aux_out: a bf16 copy of the output."""
     _gpu(x, residual, out)
     assert x.shape[-1] == pw.k, (x.shape, pw.k)
     if out is None:
@@ -234,6 +314,7 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=AC
     assert all(z * m == total for z, m in layouts), layouts
     p = GemmParams()
     _fill_common(p, x, pw, out, act, residual, relu_in)
+    bsa = bsc = 0
     if Z == 1:
         p.m, p.lda, p.ldc, p.ldr = total, lda, ldc, ldr
     else:
@@ -242,12 +323,48 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=AC
             return s if z == Z else M * ld
         assert all(z in (1, Z) for z, _ in layouts)
         p.m, p.lda, p.ldc, p.ldr = M, lda, ldc, ldr
-        p.batch, p.sa, p.sw, p.sc = Z, bs(zx, mx, lda, sa), 0, bs(zo, mo, ldc, sc)
+        bsa, bsc = bs(zx, mx, lda, sa), bs(zo, mo, ldc, sc)
+        p.batch, p.sa, p.sw, p.sc = Z, bsa, 0, bsc
         p.sr = bs(zr, mr, ldr, sr) if residual is not None else 0
     if rope is not None:
         cos, sin, pos, ncols = rope
         assert pos.dtype == torch.int64 and pos.is_contiguous() and pos.numel() == 2 * total and cos.shape[1] == 16
         p.rope_cos, p.rope_sin, p.rope_pos, p.rope_ncols = _p(cos), _p(sin), _p(pos), ncols
+    _apply_ln_stats_aux(p, pw, x, out, lda, ldc, (bsa, 0, bsc, 0), ln, stats_out, aux_out)
+    _gemm_launch(p)
+    return out
+
+
+def linear_grouped(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=ACT_NONE, residual: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None, rope=None, ln: Optional[RowStats] = None, stats_out: Optional[RowStats] = None,
+                   aux_out: Optional[torch.Tensor] = None, flip: bool = False):
+    """G weight sets in ONE launch: x [B, G, M, K] (strided, last dim contiguous) times pw = stack_packed([...G sets]) ->
+    out [B, G, M, N]; group g of every batch item uses weight set g (blockIdx.z = b * G + g).  flip: group g reads the rows of
+    group G-1-g of x (and their statistics) -- the cross-attention memory of a decoder side is the other view's tokens."""
+    _gpu(x, residual, out)
+    G = pw.meta["groups"]
+    assert x.dim() == 4 and x.shape[1] == G and x.shape[-1] == pw.k and x.stride(3) == 1, (x.shape, G, pw.k)
+    B, _, M, _ = x.shape
+    if out is None:
+        out = torch.empty((B, G, M, pw.n), dtype=out_dtype, device=x.device)
+    assert out.shape == (B, G, M, pw.n) and out.stride(3) == 1
+    p = GemmParams()
+    xf = x[:, G - 1] if flip else x
+    _fill_common(p, xf, pw, out, act, residual, False)
+    p.m, p.lda, p.ldc = M, x.stride(2), out.stride(2)
+    p.batch, p.bmod = B * G, G
+    sa_i = -x.stride(1) if flip else x.stride(1)
+    p.sa, p.sa_i, p.sc, p.sc_i = x.stride(0), sa_i, out.stride(0), out.stride(1)
+    p.sw = pw.hi.stride(0)
+    p.sbias = pw.n
+    if residual is not None:
+        assert residual.shape == out.shape and residual.stride(3) == 1
+        p.ldr, p.sr, p.sr_i = residual.stride(2), residual.stride(0), residual.stride(1)
+    if rope is not None:
+        cos, sin, pos, ncols = rope
+        assert pos.dtype == torch.int64 and pos.is_contiguous() and pos.numel() == 2 * B * G * M and cos.shape[1] == 16
+        p.rope_cos, p.rope_sin, p.rope_pos, p.rope_ncols = _p(cos), _p(sin), _p(pos), ncols
+    _apply_ln_stats_aux(p, pw, x, out, p.lda, p.ldc, (p.sa, sa_i, p.sc, p.sc_i), ln, stats_out, aux_out, x_first=xf)
     _gemm_launch(p)
     return out
 
@@ -306,7 +423,7 @@ def conv_transpose2d(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float
     return out
 
 
-def patch_embed(img: torch.Tensor, pw: PackedWeight, out: torch.Tensor):
+def patch_embed(img: torch.Tensor, pw: PackedWeight, out: torch.Tensor, stats_out: Optional[RowStats] = None, aux_out: Optional[torch.Tensor] = None):
     """Conv2d(3->C, k16, s16) on an NCHW fp32 image, written token-major into out[b, :h*w, :]
     (out is [B, Ntok(+extra), C] fp32; reference croco/patch_embed.py:19-29)."""
     _gpu(img, out)
@@ -323,6 +440,12 @@ def patch_embed(img: torch.Tensor, pw: PackedWeight, out: torch.Tensor):
     else:  # extra tokens per batch item: one launch per batch via blockIdx.z
         p.m, p.ldc = h * w, out.stride(1)
         p.batch, p.sa, p.sw, p.sc = B, 3 * H * W, 0, out.stride(0)
+    if stats_out is not None:
+        p.stats_out = stats_out.ptr(stats_out.row_of(out))
+        p.st_ldm, p.st_sz = stats_out.div(p.ldc), (stats_out.div(p.sc) if p.batch > 1 else 0)
+    if aux_out is not None:
+        assert aux_out.dtype == torch.bfloat16 and aux_out.shape == out.shape and aux_out.stride() == out.stride()
+        p.c_aux = _p(aux_out)
     _gemm_launch(p)
     return out
 

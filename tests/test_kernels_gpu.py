@@ -97,7 +97,8 @@ def test_gemm_batched_strided(mode):
 
 
 @pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
-@pytest.mark.parametrize("cfg", [(3, 1, 1, 16, 24), (3, 2, 1, 24, 40), (1, 1, 0, 64, 16), (7, 1, 3, 3, 32)], ids=["k3s1", "k3s2", "k1", "k7c3"])
+@pytest.mark.parametrize("cfg", [(3, 1, 1, 16, 24), (3, 2, 1, 24, 40), (1, 1, 0, 64, 16), (7, 1, 3, 3, 32), (3, 1, 1, 64, 40), (3, 2, 1, 96, 72)],
+                         ids=["k3s1", "k3s2", "k1", "k7c3", "k3c64_ring", "k3s2c96_ring"])
 def test_conv2d(mode, cfg):
     ops = _ops()
     name, adt, split, tol = mode
@@ -471,3 +472,90 @@ def test_attention_peaky(mode, case):
     o1 = ops.attention(dev(q1), dev(k1), dev(v1), heads=1, head_dim=D, scale=1.0, split3=split).float().cpu()[0]
     assert torch.equal(o1[:, 0].round().long(), torch.arange(Nq) % n1), "one-hot attention selected the wrong keys"
     assert float((o1[:, 1] - 1).abs().max()) < 1e-2
+
+
+@pytest.mark.parametrize("mode", [MODES[0], MODES[2]], ids=["bf16", "bf16x3"])
+@pytest.mark.parametrize("C", [192, 200, 1024], ids=["C192", "C200_ragged", "C1024"])
+def test_gemm_layernorm_fold(mode, C):
+    """LayerNorm folded into the consuming GEMM (reference croco/blocks.py:127-130: x + f(LN(x))): the producing GEMM's epilogue emits
+    per-row (mean, M2) partials of its 64-column tiles (+ a bf16 copy of the row), the consumer multiplies the UN-normalised rows by
+    W diag(gamma) and applies rstd (acc - mean c1) + c2 in its epilogue.  Rows carry a large common offset (mean >> std) to exercise
+    the Welford merge."""
+    ops = _ops()
+    name, adt, split, tol = mode
+    Z, Nt, K0, N2 = 2, 37, 96, 136
+    a = gen(Z, Nt, K0, seed=11)
+    wp, bp = gen(C, K0, seed=12, scale=0.5), gen(C, seed=13) + 3.0          # producer: x = a Wp^T + bp + res   (row mean ~ 3)
+    res = gen(Z, Nt, C, seed=14)
+    gamma, beta = 1.0 + 0.3 * gen(C, seed=15), gen(C, seed=16)
+    w2, b2 = gen(N2, C, seed=17, scale=0.2), gen(N2, seed=18)
+    x_ref = a.to(adt).float() @ wp.t() + bp + res
+    x = torch.empty(Z, Nt, C, device="cuda")
+    xb = torch.empty(Z, Nt, C, device="cuda", dtype=torch.bfloat16)
+    st = ops.RowStats(x)
+    ops.linear(a.cuda().to(adt), ops.pack_linear(wp.cuda(), bp.cuda(), split), residual=res.cuda(), out=x, stats_out=st, aux_out=xb)
+    check(f"ln_fold[{name}] producer", x, x_ref, tol)
+    assert torch.equal(xb.float().cpu(), x.cpu().to(torch.bfloat16).float())
+    # merged statistics == the row statistics
+    T = st.tiles
+    cnt = torch.tensor([64] * (T - 1) + [C - 64 * (T - 1)], dtype=torch.float32)
+    part = st.buf.cpu().view(Z * Nt, T, 2)
+    mean = (part[:, :, 0] * cnt).sum(1) / C
+    m2 = part[:, :, 1].sum(1) + (cnt * (part[:, :, 0] - mean[:, None]) ** 2).sum(1)
+    xr = x.cpu().view(-1, C)
+    assert float((mean - xr.mean(1)).abs().max()) <= 1e-5 and float((m2 / C - xr.var(1, unbiased=False)).abs().max()) <= 1e-4 * float(xr.var(1, unbiased=False).max())
+    pw = ops.pack_linear_ln(w2.cuda(), b2.cuda(), gamma.cuda(), beta.cuda(), split)
+    pw.meta["ln_eps"] = 1e-6
+    A = x if split else xb
+    ref = F.layer_norm(x.cpu(), (C,), gamma, beta, 1e-6).to(adt).float() @ w2.t() + b2
+    out = ops.linear(A, pw, out_dtype=torch.float32, ln=st)
+    check(f"ln_fold[{name}] consumer", out, ref, max(tol, 2e-2 if not split else 0))   # bf16: x is rounded BEFORE the normalisation
+    out_v = ops.linear(A[:, :-1], pw, out_dtype=torch.float32, ln=st)                    # strided view (intrinsics token stripped)
+    check(f"ln_fold[{name}] consumer on a view", out_v, ref.view(Z, Nt, N2)[:, :-1], max(tol, 2e-2 if not split else 0))
+
+
+@pytest.mark.parametrize("mode", [MODES[0], MODES[2]], ids=["bf16", "bf16x3"])
+def test_gemm_grouped_two_sides(mode):
+    """Two weight sets in one launch (blockIdx.z = b * 2 + side), incl. the flipped read (side s multiplies the OTHER side's rows:
+    the cross-attention memory of a decoder block), folded LayerNorm statistics following the flip, RoPE on the output."""
+    from oracle import siu3r_oracle as O
+
+    ops = _ops()
+    name, adt, split, tol = mode
+    B, G, M, C, H, D = 2, 2, 21, 128, 2, 64
+    N = H * D
+    x = gen(B, G, M, C, seed=31) + 1.5
+    ws = [gen(N, C, seed=32 + g, scale=0.3) for g in range(G)]
+    bs = [gen(N, seed=36 + g) for g in range(G)]
+    gm, bt = [1 + 0.2 * gen(C, seed=40 + g) for g in range(G)], [gen(C, seed=44 + g) for g in range(G)]
+    xg = x.cuda()
+    # statistics of x via an identity-free route: produce x with a GEMM so that stats / bf16 copy exist
+    eye = torch.eye(C)
+    xx = torch.empty(B, G, M, C, device="cuda")
+    xb = torch.empty(B, G, M, C, device="cuda", dtype=torch.bfloat16)
+    st = ops.RowStats(xx)
+    ops.linear(torch.zeros(B * G * M, C, device="cuda").to(adt), ops.pack_linear(eye.cuda(), None, split), residual=xg.view(-1, C), out=xx.view(-1, C), stats_out=st, aux_out=xb.view(-1, C))
+    assert torch.equal(xx.cpu(), x)
+    pos = torch.randint(0, 9, (B * G, M, 2), generator=torch.Generator().manual_seed(3))
+    cos, sin = O.rope2d_table(9, D)
+    pw = ops.stack_packed([ops.pack_linear_ln(ws[g].cuda(), bs[g].cuda(), gm[g].cuda(), bt[g].cuda(), split) for g in range(G)])
+    A = xx if split else xb
+    for flip in (False, True):
+        out = ops.linear_grouped(A, pw, out_dtype=torch.float32, ln=st, flip=flip, rope=(cos.cuda(), sin.cuda(), pos.cuda(), N))
+        ref = torch.empty(B, G, M, N)
+        for b in range(B):
+            for g in range(G):
+                src = x[b, G - 1 - g] if flip else x[b, g]
+                y = F.layer_norm(src, (C,), gm[g], bt[g], 1e-6).to(adt).float() @ ws[g].t() + bs[g]
+                ref[b, g] = O.rope2d(y.view(1, M, H, D).permute(0, 2, 1, 3), pos[b * G + g][None]).permute(0, 2, 1, 3).reshape(M, N)
+        check(f"grouped[{name}] flip={flip}", out, ref, max(tol, 2e-2 if not split else 0))
+    # plain grouped product with bias, residual, statistics out
+    pw2 = ops.stack_packed([ops.pack_linear(ws[g].cuda(), bs[g].cuda(), split) for g in range(G)])
+    r = gen(B, G, M, N, seed=50)
+    o2 = torch.empty(B, G, M, N, device="cuda")
+    st2 = ops.RowStats(o2)
+    ops.linear_grouped(xx.to(adt), pw2, residual=r.cuda(), out=o2, stats_out=st2)
+    ref2 = torch.stack([torch.stack([x[b, g].to(adt).float() @ ws[g].t() + bs[g] for g in range(G)]) for b in range(B)]) + r
+    check(f"grouped[{name}] bias+residual", o2, ref2, tol)
+    part = st2.buf.cpu().view(B * G * M, 2, 2)
+    assert float((part[:, :, 0].mean(1) - o2.cpu().view(-1, N).mean(1)).abs().max()) <= 1e-5
