@@ -97,6 +97,13 @@ typedef struct {
   float* stats_out;
   int64_t st_ldm, st_sz, st_sz_i;
   void* c_aux;                    /* optional bf16 copy of the output (same indexing as c): the next GEMM's A operand in bf16 mode */
+  /* split-K over workgroups (LDS-DMA kernels; splitk > 1): blockIdx.y = K slice; every slice writes its fp32 partial tile to
+     sk_ws [tiles, splitk, 128 * BN] and draws a ticket from sk_cnt [tiles] (int32, ZERO on entry); the last arriver of a tile sums
+     the slabs in slice order (deterministic) and runs the epilogue.  For launches with few tiles and a long K (at batch 1 most of the
+     decoder / head / Mask2Former GEMMs): the K loop of such a tile is a latency chain that more workgroups shorten. */
+  int32_t splitk;
+  float* sk_ws;
+  int32_t* sk_cnt;
 } siu3r_gemm_params;
 int siu3r_gemm(const siu3r_gemm_params* p, void* stream);
 

@@ -37,6 +37,7 @@ class GemmParams(C.Structure):
         ("ln_ldm", C.c_int64), ("ln_sz", C.c_int64), ("ln_sz_i", C.c_int64),
         ("stats_out", C.c_void_p), ("st_ldm", C.c_int64), ("st_sz", C.c_int64), ("st_sz_i", C.c_int64),
         ("c_aux", C.c_void_p),
+        ("splitk", C.c_int32), ("sk_ws", C.c_void_p), ("sk_cnt", C.c_void_p),
     ]
 
 

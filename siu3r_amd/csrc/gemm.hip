@@ -41,7 +41,7 @@ struct Regs {
   uint4 rwh[2 * NI], rwl[SPLIT ? 2 * NI : 1];
 };
 
-template <int A_F32, int SPLIT, int NI>
+template <int A_F32, int SPLIT, int NI, bool LNF = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
   constexpr int BN = 64 * NI;
   constexpr int B_TILE_BYTES = BN * BK * 2;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
   }
 
   // ---- epilogue: LDS-staged, row-wise vectorised (gemm_epilogue.h)
-  siu3r_epi::run<NI>(p, acc, smem, tile_m, tile_n, z, t);
+  siu3r_epi::run<NI, 1, LNF>(p, acc, smem, tile_m, tile_n, z, t);
 }
 
 template <int NI>
@@ -304,6 +304,7 @@ int launch(const siu3r_gemm_params& pin, hipStream_t s) {
   p.map_rn = (tn + best - 1) / best;
   const int tiles = 8 * p.map_rm * p.map_rn;
   dim3 grid(tiles, 1, p.batch > 0 ? p.batch : 1), block(256);
+  if (p.splitk > 1 && NI != 1) p.splitk = 0;  // (slabs are sized for 128 x 64 tiles)
   if (!p.w_lo && p.a_dtype == SIU3R_BF16 && p.a_mode != 2 && !g_disable_dma) {
     const int rc = siu3r_gemm_dma_launch(p, NI, s);
     if (rc <= 0) return rc;  // 1: outside the buffer-addressed kernels' range -> register-staged kernel below
@@ -312,7 +313,12 @@ int launch(const siu3r_gemm_params& pin, hipStream_t s) {
     const int rc = siu3r_gemm_dma_x3_launch(p, s);
     if (rc <= 0) return rc;  // 1: outside the kernel's range -> register-staged bf16x3 below
   }
-  if (p.w_lo) {
+  p.splitk = 0;  // the register-staged kernels multiply the whole K
+  if (p.ln_stats) {  // (rare: a folded LayerNorm outside the LDS-DMA kernels' range)
+    if (p.w_lo) hipLaunchKernelGGL((gemm_kernel<1, 1, NI, true>), grid, block, 0, s, p);
+    else if (p.a_dtype == SIU3R_F32) hipLaunchKernelGGL((gemm_kernel<1, 0, NI, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<0, 0, NI, true>), grid, block, 0, s, p);
+  } else if (p.w_lo) {
     hipLaunchKernelGGL((gemm_kernel<1, 1, NI>), grid, block, 0, s, p);
   } else if (p.a_dtype == SIU3R_F32) {
     hipLaunchKernelGGL((gemm_kernel<1, 0, NI>), grid, block, 0, s, p);
@@ -353,6 +359,8 @@ extern "C" int siu3r_gemm(const siu3r_gemm_params* pp, void* stream) {
                 "siu3r_gemm: folded LayerNorm needs c1/c2, no bias, dense A and ln_tiles == ceil(k/64) <= 16 (k=%d, ln_tiles=%d)", p.k, p.ln_tiles);
   if (p.stats_out) SIU3R_CHECK(p.out_mode == 0 && !p.up_src, "siu3r_gemm: stats_out needs a plain row-major output");
   if (p.c_aux) SIU3R_CHECK(p.out_mode == 0, "siu3r_gemm: c_aux needs a plain row-major output");
+  if (p.splitk > 1)
+    SIU3R_CHECK(p.sk_ws && p.sk_cnt && p.splitk <= 64 && p.splitk <= p.kpad / 64, "siu3r_gemm: split-K needs a workspace, zeroed counters and splitk <= kpad / 64 (splitk=%d)", p.splitk);
   if (p.bmod > 0) SIU3R_CHECK(p.batch > 0 && p.batch % p.bmod == 0, "siu3r_gemm: batch %d is not a multiple of bmod %d", p.batch, p.bmod);
   // narrow tiles when 128x128 tiling would leave most of the 256 CUs without a workgroup, or N <= 64
   const int64_t tiles128 = (int64_t)((p.m + BM - 1) / BM) * ((p.n + 127) / 128) * (p.batch > 0 ? p.batch : 1);

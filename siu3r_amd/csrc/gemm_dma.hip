@@ -36,8 +36,9 @@ typedef __attribute__((ext_vector_type(2))) short i16x2;
 // one ds_read_b128 per ~31 cycles and one LDS-DMA piece per ~55 whatever the rest of the CU does (tools/probes/lds_bw_probe.hip),
 // so a K step costs a wave 12 x 31 + 6 x 55 cycles of issue against 256 cycles of MFMA; splitting the K tile over twice the
 // waves halves that per wave and lets the CU's LDS (~220 B/clk from 8+ waves) rather than one wave's issue rate set the pace.
-template <int NI, int MODE, bool RELU, int KSPL>
-__global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_params p) {
+// (second launch bound = waves per SIMD: the 128 x 64 kernels must keep two workgroups per CU, i.e. <= 128 VGPRs)
+template <int NI, int MODE, bool RELU, int KSPL, bool LNF = false>
+__global__ __launch_bounds__(256 * KSPL, NI == 1 ? 2 * KSPL : 1) void gemm_dma_kernel(const siu3r_gemm_params p) {
 #if __HIP_DEVICE_COMPILE__  // the buffer-resource type has no host representation; the host pass only needs the stub
   constexpr int BN = 64 * NI;
   constexpr int B_TILE_BYTES = BN * BK * 2;
@@ -69,7 +70,10 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
   const int tile_m = ry * p.map_rm + lm, tile_n = rx * p.map_rn + ln;
   if (lm >= p.map_rm || tile_m >= tiles_m || tile_n >= tiles_n) return;
   const int z = blockIdx.z;
-  const int nkt = kpad / BK;
+  // split-K: this workgroup multiplies K tiles [kbase, kbase + nkt) of the kpad / BK tiles
+  const int nkt_all = kpad / BK;
+  const int kbase = p.splitk > 1 ? (int)((int64_t)blockIdx.y * nkt_all / p.splitk) : 0;
+  const int nkt = p.splitk > 1 ? (int)((int64_t)(blockIdx.y + 1) * nkt_all / p.splitk) - kbase : nkt_all;
   uint64_t* trace = p.trace ? p.trace + (size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8 : nullptr;
   auto stamp = [&](int slot) {
     if (trace && t == 0) trace[slot] = __builtin_readcyclecounter();
@@ -193,8 +197,8 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
     unsigned char* dst = smem + stage * STAGE_BYTES + (wave * A_DMA + i) * 1024;
     if (MODE == 0) {
       unsigned voff = a_voff[i];
-      if (ktail && kt == nkt - 1) voff = (kt * BK + a_c[i] * 8 < K) ? voff : OOB;  // (an out-of-range row stays out of range)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, voff, kt * (BK * 2), 0, 0);
+      if (ktail && kbase + kt == nkt_all - 1) voff = ((kbase + kt) * BK + a_c[i] * 8 < K) ? voff : OOB;  // (an out-of-range row stays out of range)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, voff, (kbase + kt) * (BK * 2), 0, 0);
     } else if (MODE == 1) {
       const unsigned voff = (a_mask[i] & cur_bit) ? a_voff[i] : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, voff, cur_toff, 0, 0);
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
   };
   auto issue_w = [&](int kt, int stage, int i) {
     unsigned char* dst = smem + stage * STAGE_BYTES + A_TILE_BYTES + (wave * W_DMA + i) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr)dst, 16, w_voff[i], kt * (BK * 2), 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr)dst, 16, w_voff[i], (kbase + kt) * (BK * 2), 0, 0);
   };
   auto issue = [&](int kt, int stage) {
 #pragma unroll
@@ -380,6 +384,10 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
 
   // ---- 3-stage ring, prefetch distance 2, one raw barrier per K-tile, counted vmcnt
   stamp(1);
+  for (int q = 0; q < kbase; ++q) {  // split-K: tap cursor / per-lane tap state of this slice's first K tile
+    if (MODE == 1) cursor_advance();
+    if (MODE == 2) state_advance();
+  }
   issue(0, 0);
   if (nkt > 1) issue(1, 1);
   stamp(2);
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
 
   // ---- epilogue: LDS-staged, row-wise vectorised (gemm_epilogue.h)
   if (dbg & 1) { if (acc[0][0][0] == 123.456f) ((float*)p.c)[0] = 1.f; return; }
-  siu3r_epi::run<NI, KSPL>(p, acc, smem, tile_m, tile_n, z, t);
+  siu3r_epi::run<NI, KSPL, LNF>(p, acc, smem, tile_m, tile_n, z, t);
   if (trace && t == 0) {
     trace[6] = __builtin_readcyclecounter();  // last store issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -431,8 +439,8 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_kernel(const siu3r_gemm_p
 // Per K tile and workgroup the ring moves the same 24 KiB as the bf16 kernel does per 64-deep tile, for 3/2 the MFMA work at half
 // the depth: the mode costs about two bf16 launches instead of the 3.2 of the register-staged kernel (gemm.hip), and activations
 // need no second representation in HBM.  NI = 1 (128 x 64 tiles); MODE 0 (dense) and MODE 1 (conv, cin % 32 == 0).
-template <int MODE, bool RELU, int KSPL>
-__global__ __launch_bounds__(256 * KSPL) void gemm_dma_x3_kernel(const siu3r_gemm_params p) {
+template <int MODE, bool RELU, int KSPL, bool LNF = false>
+__global__ __launch_bounds__(256 * KSPL, 2 * KSPL) void gemm_dma_x3_kernel(const siu3r_gemm_params p) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int BN = 64, BKE = 32;
   constexpr int B_TILE_BYTES = BN * 128;
@@ -458,7 +466,9 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_x3_kernel(const siu3r_gem
   const int tile_m = ry * p.map_rm + lm, tile_n = rx * p.map_rn + ln;
   if (lm >= p.map_rm || tile_m >= tiles_m || tile_n >= tiles_n) return;
   const int z = blockIdx.z;
-  const int nkt = kpad / BKE;
+  const int nkt_all = kpad / BKE;
+  const int kbase = p.splitk > 1 ? (int)((int64_t)blockIdx.y * nkt_all / p.splitk) : 0;
+  const int nkt = p.splitk > 1 ? (int)((int64_t)(blockIdx.y + 1) * nkt_all / p.splitk) - kbase : nkt_all;
 
   const siu3r_zoff zof = siu3r_batch_offsets(p, z);
   const float* Ab = (const float*)p.a + zof.a;
@@ -529,8 +539,8 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_x3_kernel(const siu3r_gem
     unsigned char* dst = smem + stage * STAGE_BYTES + (wave * A_DMA + i) * 1024;
     if (MODE == 0) {
       unsigned voff = a_voff[i];
-      if (ktail && kt == nkt - 1) voff = (kt * BKE + a_c[i] * 4 < K) ? voff : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, voff, kt * (BKE * 4), 0, 0);
+      if (ktail && kbase + kt >= nkt_all - 2) voff = ((kbase + kt) * BKE + a_c[i] * 4 < K) ? voff : OOB;  // (kpad is a multiple of 64: the tail spans two tiles)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, voff, (kbase + kt) * (BKE * 4), 0, 0);
     } else {
       const unsigned voff = (a_mask[i] & cur_bit) ? a_voff[i] : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, voff, cur_toff, 0, 0);
@@ -538,7 +548,7 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_x3_kernel(const siu3r_gem
   };
   auto issue_w = [&](int kt, int stage, int i) {
     unsigned char* dst = smem + stage * STAGE_BYTES + A_TILE_BYTES + (wave * W_DMA + i) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr)dst, 16, w_voff[i], kt * 128, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr)dst, 16, w_voff[i], (kbase + kt) * 128, 0, 0);
   };
   auto issue = [&](int kt, int stage) {
 #pragma unroll
@@ -659,6 +669,8 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_x3_kernel(const siu3r_gem
     if (MODE == 1 && kt_next >= 0) cursor_advance();
   };
 
+  for (int q = 0; q < kbase; ++q)
+    if (MODE == 1) cursor_advance();
   issue(0, 0);
   if (nkt > 1) issue(1, 1);
   if (nkt > 1) {
@@ -682,7 +694,7 @@ __global__ __launch_bounds__(256 * KSPL) void gemm_dma_x3_kernel(const siu3r_gem
   }
 #undef SIU3R_X3_WAIT
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  siu3r_epi::run<1, KSPL>(p, acc, smem, tile_m, tile_n, z, t);
+  siu3r_epi::run<1, KSPL, LNF>(p, acc, smem, tile_m, tile_n, z, t);
 #endif
 }
 
@@ -706,7 +718,7 @@ int siu3r_gemm_dma_launch(const siu3r_gemm_params& p, int ni, void* stream) {
     if (mode == 2 && p.relu_in) return 1;
   }
   const int tiles = 8 * p.map_rm * p.map_rn;
-  dim3 grid(tiles, 1, p.batch > 0 ? p.batch : 1);
+  dim3 grid(tiles, p.splitk > 1 ? p.splitk : 1, p.batch > 0 ? p.batch : 1);
   hipStream_t s = (hipStream_t)stream;
   static const bool no_ksplit = getenv("SIU3R_GEMM_NO_KSPLIT") != nullptr;  // A/B switch: 4-wave workgroups for the 128x64 tile
   const int kspl = no_ksplit ? 1 : 2;
@@ -714,7 +726,8 @@ int siu3r_gemm_dma_launch(const siu3r_gemm_params& p, int ni, void* stream) {
 #define SIU3R_DMA_LAUNCH(NI_, MODE_, RELU_, KS_) hipLaunchKernelGGL((gemm_dma_kernel<NI_, MODE_, RELU_, KS_>), grid, block, 0, s, p)
 #define SIU3R_DMA_MODES(NI_, KS_)                                      \
   do {                                                                 \
-    if (mode == 0) SIU3R_DMA_LAUNCH(NI_, 0, false, KS_);               \
+    if (mode == 0 && p.ln_stats) hipLaunchKernelGGL((gemm_dma_kernel<NI_, 0, false, KS_, true>), grid, block, 0, s, p); \
+    else if (mode == 0) SIU3R_DMA_LAUNCH(NI_, 0, false, KS_);          \
     else if (mode == 1 && p.relu_in) SIU3R_DMA_LAUNCH(NI_, 1, true, KS_); \
     else if (mode == 1) SIU3R_DMA_LAUNCH(NI_, 1, false, KS_);          \
     else SIU3R_DMA_LAUNCH(NI_, 2, false, KS_);                         \
@@ -747,10 +760,13 @@ int siu3r_gemm_dma_x3_launch(const siu3r_gemm_params& p, void* stream) {
     return 1;
   }
   const int tiles = 8 * p.map_rm * p.map_rn;
-  dim3 grid(tiles, 1, p.batch > 0 ? p.batch : 1);
+  dim3 grid(tiles, p.splitk > 1 ? p.splitk : 1, p.batch > 0 ? p.batch : 1);
   hipStream_t s = (hipStream_t)stream;
   static const bool no_ksplit = getenv("SIU3R_GEMM_NO_KSPLIT") != nullptr;
-  if (no_ksplit) {
+  if (mode == 0 && p.ln_stats) {
+    if (no_ksplit) hipLaunchKernelGGL((gemm_dma_x3_kernel<0, false, 1, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_dma_x3_kernel<0, false, 2, true>), grid, dim3(512), 0, s, p);
+  } else if (no_ksplit) {
     if (mode == 0) hipLaunchKernelGGL((gemm_dma_x3_kernel<0, false, 1>), grid, dim3(256), 0, s, p);
     else if (p.relu_in) hipLaunchKernelGGL((gemm_dma_x3_kernel<1, true, 1>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_dma_x3_kernel<1, false, 1>), grid, dim3(256), 0, s, p);

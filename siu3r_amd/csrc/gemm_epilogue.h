@@ -33,7 +33,7 @@ __device__ __forceinline__ float gelu_fast(float x) {
 }
 
 template <int NI, int KSPL = 1>
-constexpr int staging_bytes() { return 128 * (64 * NI + 4) * 4 + 1024; }  // tile + per-row (mean, rstd) of a folded LayerNorm
+constexpr int staging_bytes() { return 128 * (64 * NI + 4) * 4 + 2048; }  // tile + per-row (mean, rstd) and per-column c1 of a folded LayerNorm
 
 // The whole 128 x BN accumulator tile is staged once (two raw barriers); every thread then owns ONE 8-column chunk
 // (t % CHUNKS, so its bias / RoPE axis are loop invariants) of NTASK rows.  All global reads of a group of 4 rows --
@@ -43,7 +43,9 @@ constexpr int staging_bytes() { return 128 * (64 * NI + 4) * 4 + 1024; }  // til
 // KSPL = 2: the workgroup has 8 waves; waves 4..7 hold the accumulators of the second half of every K tile for the same
 // sub-tiles as waves 0..3.  They hand their partial sums to waves 0..3 through the staging area first (same lane, same
 // register <-> same address), then the tile is staged once and all 512 threads run the row pass.
-template <int NI, int KSPL = 1>
+// LNF (compile time): this launch carries a folded LayerNorm (siu3r_gemm_params.ln_*).  A separate instantiation, so that the plain
+// epilogue keeps its register budget (110 VGPRs = two 8-wave workgroups per CU for the 128 x 64 kernel).
+template <int NI, int KSPL = 1, bool LNF = false>
 __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2][NI], unsigned char* smem, int tile_m,
                                     int tile_n, int z, int t) {
   constexpr int BN = 64 * NI, BM = 128;
@@ -62,10 +64,11 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
   const int64_t c_boff = zof.c, r_boff = zof.r;
   const float* biasp = p.bias ? p.bias + zof.bias : nullptr;
   // ---- LayerNorm folded into this GEMM: rstd_m * (acc - mean_m * c1[n]) + c2[n]
-  const bool ln = p.ln_stats != nullptr;
+  constexpr bool ln = LNF;
   const float* c1p = ln ? p.ln_c1 + zof.bias : nullptr;
   const float* c2p = ln ? p.ln_c2 + zof.bias : nullptr;
-  float* s_ln = cs + BM * LDC;  // [BM][2] behind the staged tile
+  float* s_ln = cs + BM * LDC;   // [BM][2] (mean, rstd) behind the staged tile
+  float* s_c1 = s_ln + 2 * BM;   // [BN] c1 of the tile's columns
   const int c_esz = p.c_dtype == SIU3R_F32 ? 4 : 2;
   const int r_esz = p.r_dtype == SIU3R_F32 ? 4 : 2;
   const int M = p.m, N = p.n;
@@ -104,34 +107,22 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
       for (int e = 0; e < 8; ++e) pbias[e] = addp[pn0 + e];
     }
   }
-  float c1[8], pc1[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) c1[e] = pc1[e] = 0.f;
-  if (ln && col_ok) {
-    _Pragma("unroll") for (int e = 0; e < 8; ++e)
-      if (e < nv) c1[e] = c1p[co0 + e];
-    if (rope) {
-      const int pn0 = tile_n * BN + pc * 8;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pc1[e] = c1p[pn0 + e];
-    }
-  }
-  // statistics of the tile's rows: thread r < 128 merges the 64-column (mean, M2) partials of row r (Chan's formula; counts are 64
-  // except for the last partial).  The loads go out here, the merge runs behind the first barrier (the ring is then free)
-  constexpr int LN_TMAX = 16;
-  float2 lnp[LN_TMAX];
-  const bool ln_row = ln && t < BM && tile_m * BM + t < M;
+  // statistics of the tile's rows: TPR threads per row merge the 64-column (mean, M2) partials of the row (Chan's formula; counts are
+  // 64 except for the last partial).  The loads go out here, the merge runs behind the first barrier (the ring is then free)
+  constexpr int LN_TMAX = 16, TPR = 2 * KSPL, LN_PER = LN_TMAX / TPR;
+  float2 lnp[ln ? LN_PER : 1];
+  const int ln_r = t / TPR, ln_part = t - ln_r * TPR;
+  const bool ln_row = ln && tile_m * BM + ln_r < M;
   if (ln) {
 #pragma unroll
-    for (int i = 0; i < LN_TMAX; ++i) lnp[i] = make_float2(0.f, 0.f);
+    for (int i = 0; i < LN_PER; ++i) lnp[i] = make_float2(0.f, 0.f);
     if (ln_row) {
-      const float2* sp = (const float2*)p.ln_stats + ((int64_t)zof.zo * p.ln_sz + (int64_t)zof.zi * p.ln_sz_i + (int64_t)(tile_m * BM + t) * p.ln_ldm) * p.ln_tiles;
+      const float2* sp = (const float2*)p.ln_stats + ((int64_t)zof.zo * p.ln_sz + (int64_t)zof.zi * p.ln_sz_i + (int64_t)(tile_m * BM + ln_r) * p.ln_ldm) * p.ln_tiles;
 #pragma unroll
-      for (int i = 0; i < LN_TMAX; ++i)
-        if (i < p.ln_tiles) lnp[i] = sp[i];
+      for (int i = 0; i < LN_PER; ++i)
+        if (ln_part * LN_PER + i < p.ln_tiles) lnp[i] = sp[ln_part * LN_PER + i];
     }
   }
-
   f32x8 res[G];
   int64_t pos[G];
   auto issue_loads = [&](int g) {
@@ -165,26 +156,33 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
     asm volatile("" ::: "memory");
   };
   lds_barrier();  // main loop no longer reads the ring
-  if (ln && t < BM) {
-    float mu = 0.f, rs = 0.f;
-    if (ln_row) {
-      const int Cn = p.k, last = Cn - 64 * (p.ln_tiles - 1);
-      float sum = 0.f;
+  if (ln) {
+    const int Cn = p.k, last = Cn - 64 * (p.ln_tiles - 1);
+    float sum = 0.f;
 #pragma unroll
-      for (int i = 0; i < LN_TMAX; ++i)
-        if (i < p.ln_tiles) sum += lnp[i].x * (float)(i == p.ln_tiles - 1 ? last : 64);
-      mu = sum / (float)Cn;
-      float m2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < LN_TMAX; ++i)
-        if (i < p.ln_tiles) {
-          const float d = lnp[i].x - mu;
-          m2 += lnp[i].y + d * d * (float)(i == p.ln_tiles - 1 ? last : 64);
-        }
-      rs = rsqrtf(m2 / (float)Cn + p.ln_eps);
+    for (int i = 0; i < LN_PER; ++i) {
+      const int ti = ln_part * LN_PER + i;
+      if (ti < p.ln_tiles) sum += lnp[i].x * (float)(ti == p.ln_tiles - 1 ? last : 64);
     }
-    s_ln[2 * t] = mu;
-    s_ln[2 * t + 1] = rs;
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) sum += __shfl_xor(sum, o);
+    const float mu = sum / (float)Cn;
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_PER; ++i) {
+      const int ti = ln_part * LN_PER + i;
+      if (ti < p.ln_tiles) {
+        const float d = lnp[i].x - mu;
+        m2 += lnp[i].y + d * d * (float)(ti == p.ln_tiles - 1 ? last : 64);
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) m2 += __shfl_xor(m2, o);
+    if (ln_part == 0) {
+      s_ln[2 * ln_r] = ln_row ? mu : 0.f;
+      s_ln[2 * ln_r + 1] = ln_row ? rsqrtf(m2 / (float)Cn + p.ln_eps) : 0.f;
+    }
+    if (t < BN) s_c1[t] = (tile_n * BN + t < N) ? c1p[tile_n * BN + t] : 0.f;
   }
   if (KSPL == 2) {
     if (kh == 1) {
@@ -208,6 +206,63 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
     }
     lds_barrier();  // the partials have been read: the area may be overwritten with the totals
   }
+  // ---- split-K over workgroups: publish this slice's partial tile; the tile's last arriver sums all slices in slice order.
+  // Slabs travel as 16-byte WRITE-THROUGH (sc1) stores and are read back with sc1 loads (L2-served, never a stale L1 line): no
+  // release / acquire fence is needed -- a fence would write back / invalidate whole caches under every concurrent kernel's feet
+  // (MI355X_MICROARCH.md, hand-off price list: "sc1 stores AND sc1 loads both sides") -- only "my stores have left" (vmcnt(0)) before
+  // the relaxed ticket.
+#if __HIP_DEVICE_COMPILE__
+  if (p.splitk > 1) {
+    const int S = p.splitk, tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const int64_t tile_id = ((int64_t)z * tiles_m + tile_m) * tiles_n + tile_n;
+    float* slabs = p.sk_ws + tile_id * S * (BM * BN);
+    int* s_flag = (int*)(s_c1 + 160);
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    constexpr int NV = 2 * NI * 4;  // 16-byte vectors of accumulators per thread
+    __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)slabs, (short)0, (int)(S * BM * BN * 4), 0x00020000);
+    if (kh == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            union { u32x4_t u; float f[4]; } v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.f[e] = acc[i][j][4 * q + e];
+            const int vec = (i * NI + j) * 4 + q;
+            __builtin_amdgcn_raw_buffer_store_b128(v.u, rs_, (int)((((int)blockIdx.y * NV + vec) * 256 + (t & 255)) * 16), 0, 16 /* sc1 */);
+          }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) *s_flag = __hip_atomic_fetch_add(p.sk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*s_flag != S - 1) return;  // (uniform) an earlier slice: done
+    if (kh == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int sl = 0; sl < S; ++sl) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int vec = (i * NI + j) * 4 + q;
+              union { u32x4_t u; float f[4]; } v;
+              v.u = __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(((sl * NV + vec) * 256 + (t & 255)) * 16), 0, 16 /* sc1 */);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v.f[e];
+            }
+      }
+    }
+  }
+#endif
   if (kh == 0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -253,6 +308,8 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
       if (ln) {
         ln_mu = s_ln[2 * lr];
         ln_rs = s_ln[2 * lr + 1];
+        const float4 ca = *(const float4*)(s_c1 + chunk * 8), cb = *(const float4*)(s_c1 + chunk * 8 + 4);
+        const float c1[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = ln_rs * (v[e] - ln_mu * c1[e]) + bias[e];
       } else {
@@ -266,6 +323,11 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
         const float pv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         const float cc[8] = {rc[k][0].x, rc[k][0].y, rc[k][0].z, rc[k][0].w, rc[k][1].x, rc[k][1].y, rc[k][1].z, rc[k][1].w};
         const float ss[8] = {rs[k][0].x, rs[k][0].y, rs[k][0].z, rs[k][0].w, rs[k][1].x, rs[k][1].y, rs[k][1].z, rs[k][1].w};
+        float pc1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (ln) {
+          const float4 ca = *(const float4*)(s_c1 + pc * 8), cb = *(const float4*)(s_c1 + pc * 8 + 4);
+          pc1[0] = ca.x; pc1[1] = ca.y; pc1[2] = ca.z; pc1[3] = ca.w; pc1[4] = cb.x; pc1[5] = cb.y; pc1[6] = cb.z; pc1[7] = cb.w;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float o = ln ? ln_rs * (pv[e] - ln_mu * pc1[e]) + pbias[e] : pv[e] + pbias[e];

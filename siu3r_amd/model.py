@@ -58,6 +58,24 @@ class _Weights:
             self.lin[key] = ops.pack_matrix(w, b, self.split)
         return self.lin[key]
 
+    def linear_ln(self, names, ln_name, eps=1e-6):
+        """Linear(s) (several are concatenated along the output axis) behind the LayerNorm `ln_name`, folded (ops.pack_linear_ln)."""
+        names = [names] if isinstance(names, str) else list(names)
+        key = "+".join(names) + "#ln:" + ln_name
+        if key not in self.lin:
+            w = torch.cat([self.t(n + ".weight").reshape(self.sd[n + ".weight"].shape[0], -1) for n in names], 0)
+            b = torch.cat([self.t(n + ".bias") for n in names], 0) if (names[0] + ".bias") in self.sd else None
+            pw = ops.pack_linear_ln(w, b, self.t(ln_name + ".weight"), self.t(ln_name + ".bias"), self.split)
+            pw.meta["ln_eps"] = eps
+            self.lin[key] = pw
+        return self.lin[key]
+
+    def group(self, key, build, prefixes):
+        """the same layer of several blocks (the two decoder sides) as one grouped weight: build(prefix) -> PackedWeight"""
+        if key not in self.lin:
+            self.lin[key] = ops.stack_packed([build(q) for q in prefixes])
+        return self.lin[key]
+
     def merged(self, key, names):
         if key not in self.lin:
             w = torch.cat([self.t(n + ".weight") for n in names], 0)
@@ -102,6 +120,9 @@ class _Ctx:
         self.cache: Dict = {}
         self._streams: List = []
         self.concurrent = os.environ.get("SIU3R_NO_STREAMS", "0") != "1"
+        # LayerNorms of the CroCo blocks folded into the GEMM that consumes them (statistics from the producing GEMM's epilogue), and
+        # the two decoder sides of a pair merged into grouped launches.  SIU3R_NO_LNFOLD=1 restores the kernel-per-op path (A/B runs)
+        self.fold = os.environ.get("SIU3R_NO_LNFOLD", "0") != "1"
 
     def side_stream(self, i):
         """i-th auxiliary HIP stream: the independent chains of the network (two decoder sides, the four DPT heads,
@@ -179,6 +200,28 @@ class AsymmetricCroCo:
         x = ops.linear(a, ctx.w.linear(p + ".attn.proj"), out_dtype=torch.float32, residual=x)
         return self._mlp(p + ".mlp", x, p + ".norm2")
 
+    def _new_stream(self, like):
+        """a residual-stream buffer with its row statistics and (bf16 mode) the bf16 copy the next GEMM multiplies"""
+        x = torch.empty_like(like)
+        return x, ops.RowStats(x), (None if self.ctx.split else torch.empty(like.shape, dtype=torch.bfloat16, device=like.device))
+
+    def _enc_block_folded(self, p, S, pos, rope):
+        """Block.forward (blocks.py:127-130) in 5 launches: norm1 / norm2 ride in the QKV / fc1 GEMMs (ops.pack_linear_ln), the
+        proj / fc2 GEMMs write the new residual stream, its row statistics and its bf16 copy.  S = (x fp32, RowStats, bf16 copy)."""
+        ctx = self.ctx
+        x, xs, xb = S
+        Z, N, Cc = x.shape
+        A = x if ctx.split else xb
+        qkv = ops.linear(A, ctx.w.linear_ln(p + ".attn.qkv", p + ".norm1"), out_dtype=ctx.act, ln=xs,
+                         rope=(rope[0], rope[1], pos, 2 * Cc)).view(Z, N, 3, ENC_HEADS, Cc // ENC_HEADS)
+        a = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], heads=ENC_HEADS, head_dim=Cc // ENC_HEADS, scale=(Cc // ENC_HEADS) ** -0.5, split3=ctx.split)
+        x1, s1, b1 = self._new_stream(x)
+        ops.linear(a, ctx.w.linear(p + ".attn.proj"), residual=x, out=x1, stats_out=s1, aux_out=b1)
+        h = ops.linear(x1 if ctx.split else b1, ctx.w.linear_ln(p + ".mlp.fc1", p + ".norm2"), out_dtype=ctx.act, act=ACT_GELU, ln=s1)
+        x2, s2, b2 = self._new_stream(x)
+        ops.linear(h, ctx.w.linear(p + ".mlp.fc2"), residual=x1, out=x2, stats_out=s2, aux_out=b2)
+        return x2, s2, b2
+
     def _dec_block(self, p, x, y, xpos, ypos, rope, out=None):
         """DecoderBlock.forward (blocks.py:186-191); x, y are [B, N, C] fp32 strided views."""
         ctx = self.ctx
@@ -207,21 +250,29 @@ class AsymmetricCroCo:
         Z = B * V
         img = images.reshape(Z, 3, H, W).contiguous().float()
         x = torch.empty((Z, N + 1, self.enc_embed_dim), dtype=torch.float32, device=ctx.dev)
+        xs = xb = None
+        if ctx.fold:
+            xs = ops.RowStats(x)
+            xb = None if ctx.split else torch.empty(x.shape, dtype=torch.bfloat16, device=ctx.dev)
         pe = ctx.w.lin.get("backbone.patch_embed.proj") or ctx.w.linear("backbone.patch_embed.proj")
-        ops.patch_embed(img, pe, x)
+        ops.patch_embed(img, pe, x, stats_out=xs, aux_out=xb)
         # intrinsics token: Linear(9 -> 1024) on the flattened K (backbone_croco.py:278), K padded to 16 columns
         if "backbone.intrinsic_encoder" not in ctx.w.lin:
             wi = F.pad(ctx.w.t("backbone.intrinsic_encoder.weight"), (0, 7))
             ctx.w.lin["backbone.intrinsic_encoder"] = ops.pack_matrix(wi, ctx.w.t("backbone.intrinsic_encoder.bias"), ctx.split)
         kin = torch.zeros((Z, 16), dtype=torch.float32, device=ctx.dev)
         kin[:, :9] = K.reshape(Z, 9).float()
-        ops.linear(kin, ctx.w.lin["backbone.intrinsic_encoder"], out=x[:, N])
-        return dict(x=x, all_feat=[], pos=self._positions(Z, h, w), rope=self._rope(max(h, w) + 1), dims=(B, V, H, W, N))
+        ops.linear(kin, ctx.w.lin["backbone.intrinsic_encoder"], out=x[:, N], stats_out=xs, aux_out=None if xb is None else xb[:, N])
+        return dict(x=x, S=(x, xs, xb), all_feat=[], pos=self._positions(Z, h, w), rope=self._rope(max(h, w) + 1), dims=(B, V, H, W, N))
 
     def encode_blocks(self, e, lo, hi):
         """encoder blocks lo..hi-1; every block's output is kept (the ViT-Adapter taps blocks 5/11/17/23)."""
         for i in range(lo, hi):
-            e["x"] = self._enc_block(f"backbone.enc_blocks.{i}", e["x"], e["pos"], e["rope"])
+            if self.ctx.fold:
+                e["S"] = self._enc_block_folded(f"backbone.enc_blocks.{i}", e["S"], e["pos"], e["rope"])
+                e["x"] = e["S"][0]
+            else:
+                e["x"] = self._enc_block(f"backbone.enc_blocks.{i}", e["x"], e["pos"], e["rope"])
             e["all_feat"].append(e["x"])
 
     def encode_end(self, e):
@@ -257,7 +308,14 @@ class AsymmetricCroCo:
         h, w = H // 16, W // 16
         x, pos = enc["x"], enc["pos"]
         f = ctx.ln("backbone.enc_norm", x, 1e-6, out_dtype=torch.float32)
-        g = ops.linear(f, ctx.w.linear("backbone.decoder_embed"), out_dtype=torch.float32).view(B, V, N + 1, -1)
+        merged = ctx.fold and V == 2
+        g = torch.empty((B, V, N + 1, self.dec_embed_dim), dtype=torch.float32, device=ctx.dev)
+        gs = [g] + [torch.empty_like(g) for _ in range(self.dec_depth)]
+        # merged sides (a pair): every layer buffer carries its row statistics and, in bf16 mode, the bf16 copy the next GEMMs read
+        gstat = [ops.RowStats(t) for t in gs] if merged else None
+        gb16 = [None if (ctx.split or not merged) else torch.empty(t.shape, dtype=torch.bfloat16, device=ctx.dev) for t in gs]
+        ops.linear(f, ctx.w.linear("backbone.decoder_embed"), out=g.view(B * V * (N + 1), -1), stats_out=gstat[0] if merged else None,
+                   aux_out=None if gb16[0] is None else gb16[0].view(B * V * (N + 1), -1))
         fv = f.view(B, V, N + 1, -1)
         pv = pos.view(B, V, N + 1, 2)
         pos0 = pv[:, 0].contiguous()
@@ -267,8 +325,39 @@ class AsymmetricCroCo:
             pos_rest = pv[:, 1:].reshape(B * (V - 1), N + 1, 2).contiguous()
             mem0_pos = pv[:, 1:].reshape(B, (V - 1) * (N + 1), 2).contiguous()
             memr_pos = self._ctx_positions(B, V, h, w)
-        gs = [g] + [torch.empty_like(g) for _ in range(self.dec_depth)]
-        return dict(enc=enc, fv=fv, g=gs, pos0=pos0, pos_rest=pos_rest, mem0_pos=mem0_pos, memr_pos=memr_pos, rope=enc["rope"])
+        return dict(enc=enc, fv=fv, g=gs, gstat=gstat, gb16=gb16, pos0=pos0, pos_rest=pos_rest, mem0_pos=mem0_pos, memr_pos=memr_pos, rope=enc["rope"],
+                    merged=merged)
+
+    def decode_layer_merged(self, d, i):
+        """Layer i of BOTH decoder sides of a pair (DecoderBlock.forward, blocks.py:186-191; side 0 = dec_blocks on view 0, side 1 =
+        dec_blocks2 on view 1, backbone_croco.py:231-255) in 9 launches: every Linear is one grouped GEMM over the two weight sets,
+        norm1 / norm2 / norm_y / norm3 are folded into the GEMMs they feed, and the cross-attention memory of a side -- the OTHER
+        view's tokens of the previous layer -- is read by the K/V projection through a flipped group order."""
+        ctx = self.ctx
+        B, V, H, W, N = d["enc"]["dims"]
+        x, xs, xb = d["g"][i], d["gstat"][i], d["gb16"][i]
+        Cc = x.shape[-1]
+        hd = Cc // DEC_HEADS
+        rope, pos = d["rope"], d["enc"]["pos"]  # [B*V, N+1, 2], (b, v)-major like blockIdx.z; a side's memory has the same grid positions
+        sides = [f"backbone.dec_blocks.{i}", f"backbone.dec_blocks2.{i}"]
+        W_ = ctx.w
+        grp = lambda tag, build: W_.group(f"dec{i}.{tag}", build, sides)
+        A = lambda t, tb: t if ctx.split else tb
+        qkv = ops.linear_grouped(A(x, xb), grp("qkv", lambda q: W_.linear_ln(q + ".attn.qkv", q + ".norm1")), out_dtype=ctx.act, ln=xs,
+                                 rope=(rope[0], rope[1], pos, 2 * Cc)).view(B * V, N + 1, 3, DEC_HEADS, hd)
+        a = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], heads=DEC_HEADS, head_dim=hd, scale=hd ** -0.5, split3=ctx.split)
+        x1, s1, b1 = self._new_stream(x)
+        ops.linear_grouped(a.view(B, V, N + 1, Cc), grp("proj", lambda q: W_.linear(q + ".attn.proj")), residual=x, out=x1, stats_out=s1, aux_out=b1)
+        qq = ops.linear_grouped(A(x1, b1), grp("projq", lambda q: W_.linear_ln(q + ".cross_attn.projq", q + ".norm2")), out_dtype=ctx.act, ln=s1,
+                                rope=(rope[0], rope[1], pos, Cc)).view(B * V, N + 1, DEC_HEADS, hd)
+        kv = ops.linear_grouped(A(x, xb), grp("projkv", lambda q: W_.linear_ln([q + ".cross_attn.projk", q + ".cross_attn.projv"], q + ".norm_y")),
+                                out_dtype=ctx.act, ln=xs, flip=True, rope=(rope[0], rope[1], pos, Cc)).view(B * V, N + 1, 2, DEC_HEADS, hd)
+        a = ops.attention(qq, kv[:, :, 0], kv[:, :, 1], heads=DEC_HEADS, head_dim=hd, scale=hd ** -0.5, split3=ctx.split)
+        x2, s2, b2 = self._new_stream(x)
+        ops.linear_grouped(a.view(B, V, N + 1, Cc), grp("xproj", lambda q: W_.linear(q + ".cross_attn.proj")), residual=x1, out=x2, stats_out=s2, aux_out=b2)
+        h = ops.linear_grouped(A(x2, b2), grp("fc1", lambda q: W_.linear_ln(q + ".mlp.fc1", q + ".norm3")), out_dtype=ctx.act, act=ACT_GELU, ln=s2)
+        ops.linear_grouped(h, grp("fc2", lambda q: W_.linear(q + ".mlp.fc2")), residual=x2, out=d["g"][i + 1], stats_out=d["gstat"][i + 1],
+                           aux_out=d["gb16"][i + 1])
 
     def decode_side(self, d, i, side):
         """Layer i, side 0 = view 0 (dec_blocks), side 1 = views 1..V-1 batched (dec_blocks2); reads layer i's input
@@ -301,6 +390,10 @@ class AsymmetricCroCo:
         current stream, the other views on a side stream, joined after every layer."""
         ctx = self.ctx
         d = self.decode_begin(enc)
+        if d["merged"]:
+            for i in range(self.dec_depth):
+                self.decode_layer_merged(d, i)
+            return self.decode_end(d)
         main = torch.cuda.current_stream()
         side = ctx.side_stream(0) if ctx.concurrent else main
         for i in range(self.dec_depth):
@@ -838,6 +931,7 @@ class SIU3RModel:
         self.raw_gs_dim = (sh_degree + 1) ** 2 * 3 + 3 + 4 + 1
         self.use_graph = os.environ.get("SIU3R_NO_GRAPH", "0") != "1"
         self._graphs: Dict = {}
+        self._timeline = None  # a list collects (stage, start event, end event) of the next graph-replayed forward
 
     def eval(self):
         return self
@@ -896,7 +990,18 @@ class SIU3RModel:
             st = ent["st"]
             st.images.copy_(images, non_blocking=True)
             st.K.copy_(K, non_blocking=True)
-            self._run_stages(st, lambda name, fn: fn() if name == "tail" else ent["graphs"][name].replay())
+            tl = self._timeline
+
+            def replay(name, fn):
+                if tl is not None:  # tools/timeline.py: stage start / end events on the stage's own stream
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                fn() if name == "tail" else ent["graphs"][name].replay()
+                if tl is not None:
+                    e1.record()
+                    tl.append((name, e0, e1))
+
+            self._run_stages(st, replay)
             # the Gaussians come from the eager tail (fresh memory); the logits leave the graphs' private memory, which the
             # next replay overwrites
             gaussians = st.gaussians
@@ -930,7 +1035,10 @@ class SIU3RModel:
 
         dec = [("dec_pre", dec_pre)]
         for i in range(bb.dec_depth):
-            dec += [(f"decA{i}", lambda i=i: bb.decode_side(st.dstate, i, 0)), (f"decB{i}", lambda i=i: bb.decode_side(st.dstate, i, 1))]
+            if self._merged_decoder(st):
+                dec += [(f"dec{i}", lambda i=i: bb.decode_layer_merged(st.dstate, i))]
+            else:
+                dec += [(f"decA{i}", lambda i=i: bb.decode_side(st.dstate, i, 0)), (f"decB{i}", lambda i=i: bb.decode_side(st.dstate, i, 1))]
         dec += [("dec_post", dec_post)]
         ad = self.adapter
         bounds = [0] + [i + 1 for i in ADAPTER_IDX]  # encoder segments end at the blocks the adapter taps
@@ -953,6 +1061,9 @@ class SIU3RModel:
         return enc + [("seg", lambda: self._s_seg(st))] + dec + [
             ("gs0", lambda: self._s_head(st, 0)), ("gsr", lambda: self._s_head(st, 1)), ("pts0", lambda: self._s_head(st, 2)),
             ("ptsr", lambda: self._s_head(st, 3)), ("tail", lambda: self._s_tail(st))]
+
+    def _merged_decoder(self, st) -> bool:
+        return self._ctx.fold and st.images.shape[1] == 2
 
     def _run_stages(self, st, run):
         """Enqueue the stages with their fork/join edges.  run(name, fn) either calls fn (eager) or replays its graph."""
@@ -981,6 +1092,9 @@ class SIU3RModel:
         run("dec_pre", stages["dec_pre"])
         dside = ctx.side_stream(0) if par else main
         for i in range(self.backbone.dec_depth):
+            if self._merged_decoder(st):  # both sides of the pair in grouped launches on the main stream
+                run(f"dec{i}", stages[f"dec{i}"])
+                continue
             if par:
                 dside.wait_stream(main)
             run(f"decA{i}", stages[f"decA{i}"])

@@ -194,9 +194,38 @@ def kernel_timer_active() -> bool:
     return _timer is not None
 
 
-def _gemm_launch(p: GemmParams):
+_SPLITK = __import__("os").environ.get("SIU3R_NO_SPLITK", "0") != "1"
+SPLITK_FILL = 512      # workgroup slots of the 128 x 64 kernels on the chip (256 CUs x 2)
+SPLITK_MAX_TILES = 160  # launches with at least this many tiles keep the whole K in one workgroup
+
+
+def _pick_splitk(p: GemmParams, dev):
+    """Few tiles and a long K: cut K over several workgroups (siu3r_gemm_params.splitk).  Mirrors the launcher's choice of the
+    LDS-DMA kernels (the register-staged fallbacks ignore the request).  Returns the tensors that must stay alive."""
+    if not _SPLITK:
+        return None
+    x3 = bool(p.w_x3) and p.a_dtype == F32 and ((p.a_mode == 0 and not p.relu_in) or (p.a_mode == 1 and p.cin % 32 == 0 and p.kpad == p.k and p.kh * p.kw <= 32))
+    bf = p.a_dtype == BF16 and not p.w_lo and not (p.relu_in and not (p.a_mode == 1 and p.cin % 64 == 0 and p.kh * p.kw <= 32 and p.kpad == p.k))
+    if not (x3 or bf):
+        return None
+    tiles = ((p.m + 127) // 128) * ((p.n + 63) // 64) * max(1, p.batch)
+    if tiles >= SPLITK_MAX_TILES:
+        return None
+    nkt = p.kpad // 64  # (the x3 kernel's tiles are 32 deep, but the split is validated against kpad / 64)
+    S = min(8, nkt // (4 if x3 else 8), (SPLITK_FILL + tiles - 1) // tiles)  # every slice keeps >= 8 K steps
+    if S < 2:
+        return None
+    ws = torch.empty((tiles * S * 8192,), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((tiles,), dtype=torch.int32, device=dev)
+    p.splitk, p.sk_ws, p.sk_cnt = S, ws.data_ptr(), cnt.data_ptr()
+    return ws, cnt
+
+
+def _gemm_launch(p: GemmParams, dev=None):
+    keep = _pick_splitk(p, dev if dev is not None else torch.device("cuda", torch.cuda.current_device()))
     if _timer is None:
         check(_lib.lib().siu3r_gemm(C.byref(p), _stream()))
+        del keep
         return
     # label with the kernel the launcher will pick (mirrors gemm.hip / gemm_dma.hip dispatch) so that the event
     # averages line up with rocprofv3's per-kernel rows

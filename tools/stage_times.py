@@ -5,7 +5,8 @@ import torch
 from siu3r_amd.model import SIU3RModel
 from siu3r_amd import synthetic_weights as OW
 dev = torch.device("cuda", 0)
-m = SIU3RModel(OW.make_weights(0), image_size=(512, 512), precision="bf16", device=dev)
+prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+m = SIU3RModel(OW.make_weights(0), image_size=(512, 512), precision=prec, device=dev)
 img = torch.rand(1, 2, 3, 512, 512).to(dev)
 K = torch.tensor([[318 / 256, 0, 0.5], [0, 318 / 256, 0.5], [0, 0, 1]])[None, None].repeat(1, 2, 1, 1).to(dev)
 for _ in range(4):
@@ -20,7 +21,7 @@ for name, g in ent["graphs"].items():  # the tail stage is eager (not in this di
     e1.record(); torch.cuda.synchronize()
     tot[name] = e0.elapsed_time(e1) / 20
 grp = lambda pre: sum(v for k, v in tot.items() if k.startswith(pre))
-print({k: round(v, 3) for k, v in tot.items() if not (k.startswith("dec") and k[3] in "AB")})
+print({k: round(v, 3) for k, v in tot.items() if not (k.startswith("dec") and (k[3] in "AB" or k[3].isdigit()))})
 print("encoder", round(grp("enc"), 2), "| spm+int", round(tot["spm"] + grp("int"), 2), "| seg", round(tot["seg"], 2), "| dec pre/post", round(tot["dec_pre"] + tot["dec_post"], 2),
-      "| decA", round(grp("decA"), 2), "| decB", round(grp("decB"), 2), "| heads", {k: round(tot[k], 2) for k in ("gs0", "gsr", "pts0", "ptsr")}, "| tail: eager")
+      "| decA", round(grp("decA"), 2), "| decB", round(grp("decB"), 2), "| dec (merged sides)", round(sum(v for k, v in tot.items() if k.startswith("dec") and k[3].isdigit()), 2), "| heads", {k: round(tot[k], 2) for k in ("gs0", "gsr", "pts0", "ptsr")}, "| tail: eager")
 print("sum", round(sum(tot.values()), 2))
