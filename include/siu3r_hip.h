@@ -257,8 +257,9 @@ int siu3r_lift_ids(const float* qc, int V, int H, int W, int q, int C, float sem
                    void* stream);
 
 /* fp32 [rows, k] (row stride ldx) -> bf16 hi plane [rows,kpad] (+ optional lo = bf16(x - hi)), zero padded:
- * weight / operand pre-packing for siu3r_gemm. */
-int siu3r_split_bf16(const float* x, void* hi, void* lo, int64_t rows, int k, int kpad, int64_t ldx, void* stream);
+ * weight / operand pre-packing for siu3r_gemm.  x3 (optional, kpad % 32 == 0): both planes interleaved per 32-deep K tile,
+ * [rows][kpad / 32][hi 32 | lo 32] = siu3r_gemm_params.w_x3.  hi may be null when x3 is given. */
+int siu3r_split_bf16(const float* x, void* hi, void* lo, void* x3, int64_t rows, int k, int kpad, int64_t ldx, void* stream);
 
 /* ---- panoptic post-process on device (integer outputs).  Replaces
  * VideoMask2FormerImageProcessor.post_process_panoptic_segmentation

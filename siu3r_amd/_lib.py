@@ -95,7 +95,7 @@ SIGNATURES = {
     "siu3r_pts3d_exp": [_P, _L, _P],
     "siu3r_gaussian_adapter": [_P, _I, _P, _P, _P, _P, _P, _L, _P],
     "siu3r_m2f_attn_mask": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P],
-    "siu3r_split_bf16": [_P, _P, _P, _L, _I, _I, _L, _P],
+    "siu3r_split_bf16": [_P, _P, _P, _P, _L, _I, _I, _L, _P],
     "siu3r_raster_geometry": [_I, _I, _L, C.POINTER(C.c_int32)],
     "siu3r_raster_project": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "siu3r_raster_sort": [_I, _L, _P, _P, _P, _P, _P, _P, _P],

@@ -528,15 +528,22 @@ __global__ void m2f_mask_fix_kernel(uint8_t* out, const int32_t* row_counts, int
 }
 
 // ================================ fp32 -> bf16 hi (+lo) planes, K zero-padded ====================
-__global__ void split_bf16_kernel(const float* x, u16* hi, u16* lo, int64_t rows, int k, int kpad, int64_t ldx) {
+// x3 (optional): both planes interleaved per 32-deep K tile, [row][kpad / 32][hi 32 | lo 32] -- the W operand of the bf16x3 LDS-DMA GEMM
+__global__ void split_bf16_kernel(const float* x, u16* hi, u16* lo, u16* x3, int64_t rows, int k, int kpad, int64_t ldx) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * kpad) return;
   const int64_t r = idx / kpad;
   const int c = (int)(idx - r * kpad);
   const float v = c < k ? x[r * ldx + c] : 0.f;
   const u16 h = f32_to_bf16_bits(v);
-  hi[idx] = h;
-  if (lo) lo[idx] = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
+  const u16 l = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
+  if (hi) hi[idx] = h;
+  if (lo) lo[idx] = l;
+  if (x3) {
+    const int64_t o = r * 2 * kpad + (c >> 5) * 64 + (c & 31);
+    x3[o] = h;
+    x3[o + 32] = l;
+  }
 }
 
 inline dim3 grid1d(int64_t total, int block = 256) { return dim3((unsigned)cdiv64(total, block)); }
@@ -709,11 +716,11 @@ extern "C" int siu3r_m2f_attn_mask(const float* mask_logits, uint8_t* out, int32
   return 0;
 }
 
-extern "C" int siu3r_split_bf16(const float* x, void* hi, void* lo, int64_t rows, int k, int kpad, int64_t ldx,
+extern "C" int siu3r_split_bf16(const float* x, void* hi, void* lo, void* x3, int64_t rows, int k, int kpad, int64_t ldx,
                                 void* stream) {
-  SIU3R_CHECK(x && hi && kpad >= k, "split_bf16: bad arguments");
+  SIU3R_CHECK(x && (hi || x3) && kpad >= k && (!x3 || kpad % 32 == 0), "split_bf16: bad arguments");
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(split_bf16_kernel, grid1d(rows * kpad), dim3(256), 0, (hipStream_t)stream, x, (u16*)hi, (u16*)lo, rows, k, kpad, ldx);
+  hipLaunchKernelGGL(split_bf16_kernel, grid1d(rows * kpad), dim3(256), 0, (hipStream_t)stream, x, (u16*)hi, (u16*)lo, (u16*)x3, rows, k, kpad, ldx);
   SIU3R_LAUNCH_CHECK("siu3r_split_bf16");
   return 0;
 }

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256 * KSPL, NI == 1 ? 2 * KSPL : 1) void gemm_dma_k
 // W tile carries both planes of a K tile and the tile / piece / swizzle geometry is byte for byte that of the bf16 kernel.
 // Per K tile and workgroup the ring moves the same 24 KiB as the bf16 kernel does per 64-deep tile, for 3/2 the MFMA work at half
 // the depth: the mode costs about two bf16 launches instead of the 3.2 of the register-staged kernel (gemm.hip), and activations
-// need no second representation in HBM.  NI = 1 (128 x 64 tiles); MODE 0 (dense) and MODE 1 (conv, cin % 32 == 0).
+// need no second representation in HBM.  NI = 1 (128 x 64 tiles); MODE 0 (dense), MODE 1 (conv, cin % 32 == 0) and MODE 2 (conv, small cin % 4 == 0).
 template <int MODE, bool RELU, int KSPL, bool LNF = false>
 __global__ __launch_bounds__(256 * KSPL, 2 * KSPL) void gemm_dma_x3_kernel(const siu3r_gemm_params p) {
 #if __HIP_DEVICE_COMPILE__
@@ -486,6 +486,7 @@ __global__ __launch_bounds__(256 * KSPL, 2 * KSPL) void gemm_dma_x3_kernel(const
 
   unsigned a_voff[A_DMA], a_mask[A_DMA];
   int a_c[A_DMA];
+  int a_iy0[A_DMA], a_ix0[A_DMA];  // MODE 2: top-left input pixel of the row
 #pragma unroll
   for (int i = 0; i < A_DMA; ++i) {
     const int r = (wave * A_DMA + i) * 8 + prow;
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(256 * KSPL, 2 * KSPL) void gemm_dma_x3_kernel(const
     const bool row_ok = m < M;
     if (!row_ok) m = M - 1;
     a_voff[i] = a_mask[i] = 0;
+    a_iy0[i] = a_ix0[i] = 0;
     if (MODE == 0) {
       a_voff[i] = row_ok ? (unsigned)(((int64_t)m * p.lda) * 4 + a_c[i] * 16) : OOB;
     } else {
@@ -501,12 +503,18 @@ __global__ __launch_bounds__(256 * KSPL, 2 * KSPL) void gemm_dma_x3_kernel(const
       const int b = m / ohw, rr = m - b * ohw;
       const int oy = rr / p.ow, ox = rr - oy * p.ow;
       const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-      a_voff[i] = (unsigned)((((b * ih + iy0) * iw + ix0) * cin) * 4 + a_c[i] * 16 + pad_bias);
-      unsigned mk = 0;
-      for (int ky = 0; ky < kh; ++ky)
-        for (int kx = 0; kx < kw; ++kx)
-          if (iy0 + ky >= 0 && iy0 + ky < ih && ix0 + kx >= 0 && ix0 + kx < iw) mk |= 1u << (ky * kw + kx);
-      a_mask[i] = row_ok ? mk : 0u;
+      if (MODE == 1) {
+        a_voff[i] = (unsigned)((((b * ih + iy0) * iw + ix0) * cin) * 4 + a_c[i] * 16 + pad_bias);
+        unsigned mk = 0;  // (a zero-padded K tail lands on tap kh*kw, whose bit is never set)
+        for (int ky = 0; ky < kh; ++ky)
+          for (int kx = 0; kx < kw; ++kx)
+            if (iy0 + ky >= 0 && iy0 + ky < ih && ix0 + kx >= 0 && ix0 + kx < iw) mk |= 1u << (ky * kw + kx);
+        a_mask[i] = row_ok ? mk : 0u;
+      } else {
+        a_voff[i] = (unsigned)((((b * ih + iy0) * iw + ix0) * cin) * 4 + pad_bias);
+        a_iy0[i] = row_ok ? iy0 : -(1 << 20);  // fails every bounds test
+        a_ix0[i] = ix0;
+      }
     }
   }
   unsigned w_voff[W_DMA];
@@ -535,9 +543,47 @@ __global__ __launch_bounds__(256 * KSPL, 2 * KSPL) void gemm_dma_x3_kernel(const
       cur_toff = cur_row + cur_kx * cin * 4;
     }
   };
+  // MODE 2 (any cin % 4 == 0, e.g. the 7x7 stem with cin = 8): as in the bf16 kernel, a lane fetches two chunk columns of the K tile
+  // (a_c[0] for its even pieces, a_c[1] for the odd ones) and tracks (channel offset, kx, ky) of the next tile to issue for each,
+  // advanced by 32 K elements with two conditional wraps
+  int s_c0[2] = {0, 0}, s_kx[2] = {0, 0}, s_ky[2] = {0, 0};
+  int q32_r = 0, q32_qx = 0, q32_qy = 0;
+  if (MODE == 2) {
+    const int q32 = BKE / cin;
+    q32_r = BKE - q32 * cin;
+    q32_qy = q32 / kw;
+    q32_qx = q32 - q32_qy * kw;
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const int k0 = a_c[s_] * 4;
+      const int tap = k0 / cin;
+      s_c0[s_] = k0 - tap * cin;
+      s_ky[s_] = tap / kw;
+      s_kx[s_] = tap - s_ky[s_] * kw;
+    }
+  }
+  auto state_advance = [&]() {
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      s_c0[s_] += q32_r;
+      const int carry = s_c0[s_] >= cin ? 1 : 0;
+      s_c0[s_] -= carry * cin;
+      s_kx[s_] += q32_qx + carry;
+      const int wrap = s_kx[s_] >= kw ? 1 : 0;
+      s_kx[s_] -= wrap * kw;
+      s_ky[s_] += q32_qy + wrap;
+    }
+  };
   auto issue_a = [&](int kt, int stage, int i) {
     unsigned char* dst = smem + stage * STAGE_BYTES + (wave * A_DMA + i) * 1024;
-    if (MODE == 0) {
+    if (MODE == 2) {
+      const int s_ = i & 1;
+      const int ky = s_ky[s_], kx = s_kx[s_];
+      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+      const bool ok = ky < kh && (unsigned)iy < (unsigned)ih && (unsigned)ix < (unsigned)iw;  // ky >= kh: zero-padded K tail
+      const unsigned voff = ok ? a_voff[i] + (unsigned)(((ky * iw + kx) * cin + s_c0[s_]) * 4) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, voff, 0, 0, 0);
+    } else if (MODE == 0) {
       unsigned voff = a_voff[i];
       if (ktail && kbase + kt >= nkt_all - 2) voff = ((kbase + kt) * BKE + a_c[i] * 4 < K) ? voff : OOB;  // (kpad is a multiple of 64: the tail spans two tiles)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, voff, (kbase + kt) * (BKE * 4), 0, 0);
@@ -556,6 +602,7 @@ __global__ __launch_bounds__(256 * KSPL, 2 * KSPL) void gemm_dma_x3_kernel(const
 #pragma unroll
     for (int i = 0; i < W_DMA; ++i) issue_w(kt, stage, i);
     if (MODE == 1) cursor_advance();
+    if (MODE == 2) state_advance();
   };
 
   f32x16 acc[2][1];
@@ -667,10 +714,13 @@ __global__ __launch_bounds__(256 * KSPL, 2 * KSPL) void gemm_dma_x3_kernel(const
       __builtin_amdgcn_sched_barrier(0);
     }
     if (MODE == 1 && kt_next >= 0) cursor_advance();
+    if (MODE == 2 && kt_next >= 0) state_advance();
   };
 
-  for (int q = 0; q < kbase; ++q)
+  for (int q = 0; q < kbase; ++q) {
     if (MODE == 1) cursor_advance();
+    if (MODE == 2) state_advance();
+  }
   issue(0, 0);
   if (nkt > 1) issue(1, 1);
   if (nkt > 1) {
@@ -754,8 +804,10 @@ int siu3r_gemm_dma_x3_launch(const siu3r_gemm_params& p, void* stream) {
     if (((int64_t)(p.m - 1) * p.lda + p.k) * 4 >= lim || p.relu_in) return 1;
   } else if (p.a_mode == 1) {
     const int64_t img = (int64_t)(p.m / (p.oh * p.ow)) * p.ih * p.iw * p.cin * 4 + (int64_t)(p.pad * p.iw + p.pad) * p.cin * 4;
-    if (img >= lim || p.cin % 32 != 0 || p.kh * p.kw > 32 || p.kpad != p.k) return 1;
-    mode = 1;
+    if (img >= lim || p.cin % 4 != 0) return 1;
+    if (p.cin % 32 == 0 && p.kh * p.kw <= 31) mode = 1;  // (kpad > k: the padded tiles sit on tap kh*kw, masked for every row)
+    else if (!p.relu_in) mode = 2;
+    else return 1;
   } else {
     return 1;
   }
@@ -768,10 +820,12 @@ int siu3r_gemm_dma_x3_launch(const siu3r_gemm_params& p, void* stream) {
     else hipLaunchKernelGGL((gemm_dma_x3_kernel<0, false, 2, true>), grid, dim3(512), 0, s, p);
   } else if (no_ksplit) {
     if (mode == 0) hipLaunchKernelGGL((gemm_dma_x3_kernel<0, false, 1>), grid, dim3(256), 0, s, p);
+    else if (mode == 2) hipLaunchKernelGGL((gemm_dma_x3_kernel<2, false, 1>), grid, dim3(256), 0, s, p);
     else if (p.relu_in) hipLaunchKernelGGL((gemm_dma_x3_kernel<1, true, 1>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_dma_x3_kernel<1, false, 1>), grid, dim3(256), 0, s, p);
   } else {
     if (mode == 0) hipLaunchKernelGGL((gemm_dma_x3_kernel<0, false, 2>), grid, dim3(512), 0, s, p);
+    else if (mode == 2) hipLaunchKernelGGL((gemm_dma_x3_kernel<2, false, 2>), grid, dim3(512), 0, s, p);
     else if (p.relu_in) hipLaunchKernelGGL((gemm_dma_x3_kernel<1, true, 2>), grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL((gemm_dma_x3_kernel<1, false, 2>), grid, dim3(512), 0, s, p);
   }

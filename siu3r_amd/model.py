@@ -775,12 +775,12 @@ class VideoMask2FormerForVideoSegmentation:
         if ctx.split:
             e = ops.linear(e, ctx.w.linear(p + ".2.0"), out_dtype=torch.float32)
             B, Q, Cc = e.shape
-            hi, lo, kpad = ops.split_bf16(e.view(B * Q, Cc), True)
+            hi, lo, kpad, x3 = ops.split_bf16(e.view(B * Q, Cc), True, want_x3=True)
         else:  # bf16 mode: the embedding leaves the GEMM as the bf16 "weight" plane of the mask product (256 = 4 x 64: no K padding)
-            hi, lo = ops.linear(e, ctx.w.linear(p + ".2.0"), out_dtype=torch.bfloat16), None
+            hi, lo, x3 = ops.linear(e, ctx.w.linear(p + ".2.0"), out_dtype=torch.bfloat16), None, None
             B, Q, Cc = hi.shape
             kpad = Cc
-        m = ops.bmm_nt(mask_features_bt, hi.view(B, Q, kpad), None if lo is None else lo.view(B, Q, kpad), Q, Cc)
+        m = ops.bmm_nt(mask_features_bt, hi.view(B, Q, kpad), None if lo is None else lo.view(B, Q, kpad), Q, Cc, b_x3=x3)
         m = m.view(B, self._T, self._H4, self._W4, Q)
         am = ops.m2f_attn_mask(m, size) if size is not None else None
         return m, am

@@ -57,26 +57,24 @@ class PackedWeight:
     meta: dict = None
 
 
-def split_bf16(x2d: torch.Tensor, want_lo: bool, kpad: Optional[int] = None):
-    """fp32 [rows, k] (last dim contiguous) -> bf16 hi [rows, kpad] (+ lo)."""
+def split_bf16(x2d: torch.Tensor, want_lo: bool, kpad: Optional[int] = None, want_x3: bool = False):
+    """fp32 [rows, k] (last dim contiguous) -> bf16 hi [rows, kpad] (+ lo) (+ x3 [rows, kpad/32, 2, 32]: the two planes interleaved per
+    32-deep K tile, the W layout of the bf16x3 LDS-DMA GEMM; returned as a fourth value)."""
     _gpu(x2d)
     assert x2d.dtype == torch.float32 and x2d.dim() == 2 and x2d.stride(1) == 1
     rows, k = x2d.shape
     kpad = kpad or ((k + 63) // 64) * 64
     hi = torch.empty((rows, kpad), dtype=torch.bfloat16, device=x2d.device)
     lo = torch.empty_like(hi) if want_lo else None
-    check(_lib.lib().siu3r_split_bf16(_p(x2d), _p(hi), _p(lo), rows, k, kpad, x2d.stride(0), _stream()))
-    return hi, lo, kpad
+    x3 = torch.empty((rows, kpad // 32, 2, 32), dtype=torch.bfloat16, device=x2d.device) if want_x3 else None
+    check(_lib.lib().siu3r_split_bf16(_p(x2d), _p(hi), _p(lo), _p(x3), rows, k, kpad, x2d.stride(0), _stream()))
+    return (hi, lo, kpad, x3) if want_x3 else (hi, lo, kpad)
 
 
 def pack_matrix(w2d: torch.Tensor, bias: Optional[torch.Tensor], split: bool, **meta) -> PackedWeight:
     w2d = w2d.contiguous().float()
-    hi, lo, kpad = split_bf16(w2d, split)
+    hi, lo, kpad, x3 = split_bf16(w2d, split, want_x3=True) if split else (*split_bf16(w2d, False), None)  # x3: one 128-byte row segment per K tile = [hi 32 | lo 32]
     b = None if bias is None else bias.detach().float().contiguous()
-    x3 = None
-    if lo is not None:  # load-time layout plumbing: one 128-byte row segment per K tile = [hi 32 | lo 32]
-        n_ = w2d.shape[0]
-        x3 = torch.stack((hi.view(n_, kpad // 32, 32), lo.view(n_, kpad // 32, 32)), dim=2).contiguous()
     return PackedWeight(hi=hi, lo=lo, bias=b, x3=x3, n=w2d.shape[0], k=w2d.shape[1], kpad=kpad, meta=meta)
 
 
@@ -199,12 +197,23 @@ SPLITK_FILL = 512      # workgroup slots of the 128 x 64 kernels on the chip (25
 SPLITK_MAX_TILES = 160  # launches with at least this many tiles keep the whole K in one workgroup
 
 
+def _x3_dma(p: GemmParams) -> bool:
+    """does the launcher put this bf16x3 problem on the LDS-DMA kernel? (mirrors siu3r_gemm_dma_x3_launch, sizes below 4 GiB assumed)"""
+    if not p.w_x3 or p.a_dtype != F32:
+        return False
+    if p.a_mode == 0:
+        return not p.relu_in
+    if p.a_mode == 1:
+        return p.cin % 4 == 0 and ((p.cin % 32 == 0 and p.kh * p.kw <= 31) or not p.relu_in)
+    return False
+
+
 def _pick_splitk(p: GemmParams, dev):
     """Few tiles and a long K: cut K over several workgroups (siu3r_gemm_params.splitk).  Mirrors the launcher's choice of the
     LDS-DMA kernels (the register-staged fallbacks ignore the request).  Returns the tensors that must stay alive."""
     if not _SPLITK:
         return None
-    x3 = bool(p.w_x3) and p.a_dtype == F32 and ((p.a_mode == 0 and not p.relu_in) or (p.a_mode == 1 and p.cin % 32 == 0 and p.kpad == p.k and p.kh * p.kw <= 32))
+    x3 = _x3_dma(p)
     bf = p.a_dtype == BF16 and not p.w_lo and not (p.relu_in and not (p.a_mode == 1 and p.cin % 64 == 0 and p.kh * p.kw <= 32 and p.kpad == p.k))
     if not (x3 or bf):
         return None
@@ -229,7 +238,7 @@ def _gemm_launch(p: GemmParams, dev=None):
         return
     # label with the kernel the launcher will pick (mirrors gemm.hip / gemm_dma.hip dispatch) so that the event
     # averages line up with rocprofv3's per-kernel rows
-    if p.w_x3 and p.a_mode in (0, 1) and not (p.a_mode == 0 and p.relu_in) and not (p.a_mode == 1 and (p.cin % 32 or p.kpad != p.k)):
+    if _x3_dma(p):
         variant = "gemm_dma_x3_kernel (bf16x3, fp32 A)"
     elif p.w_lo:
         variant = "gemm_kernel<1,1,1> (bf16x3)"
@@ -398,14 +407,17 @@ def linear_grouped(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32
     return out
 
 
-def bmm_nt(a: torch.Tensor, b_hi: torch.Tensor, b_lo: Optional[torch.Tensor], n: int, k: int, *, out_dtype=torch.float32):
-    """out[z, M, n] = a[z, M, k] @ b[z, n, k]^T with pre-split bf16 b planes [Z, n, kpad]."""
+def bmm_nt(a: torch.Tensor, b_hi: torch.Tensor, b_lo: Optional[torch.Tensor], n: int, k: int, *, out_dtype=torch.float32,
+           b_x3: Optional[torch.Tensor] = None):
+    """out[z, M, n] = a[z, M, k] @ b[z, n, k]^T with pre-split bf16 b planes [Z, n, kpad] (b_x3: the interleaved planes of
+    split_bf16(want_x3=True), which put a bf16x3 product on the LDS-DMA kernel)."""
     _gpu(a, b_hi)
     Z, M, K = a.shape
     assert K == k and a.stride(2) == 1
     out = torch.empty((Z, M, n), dtype=out_dtype, device=a.device)
     p = GemmParams()
     p.a, p.w_hi, p.w_lo, p.c = _p(a), _p(b_hi), _p(b_lo), _p(out)
+    p.w_x3 = _p(b_x3)
     p.m, p.n, p.k, p.kpad = M, n, k, b_hi.shape[-1]
     p.lda, p.ldc = a.stride(1), n
     p.a_dtype, p.c_dtype, p.r_dtype = _dt(a), _dt(out), F32

@@ -115,6 +115,11 @@ def test_conv2d(mode, cfg):
     ref = F.conv2d(F.relu(x.to(adt).float()), w, b, stride=s, padding=pd).permute(0, 2, 3, 1)
     out = ops.conv2d(xg, pw, stride=s, pad=pd, out_dtype=torch.float32, relu_in=True)
     check(f"conv2d[{name}] k{k}s{s} relu_in", out, ref, tol)
+    # without the fused input ReLU the small-cin shapes take the per-lane tap-state gather of the LDS-DMA kernels (bf16 and bf16x3),
+    # and cin = 96 (K = 864, kpad = 896) runs the tap-cursor kernel over a zero-padded last K tile
+    ref = F.conv2d(x.to(adt).float(), w, b, stride=s, padding=pd).permute(0, 2, 3, 1)
+    out = ops.conv2d(xg, pw, stride=s, pad=pd, out_dtype=torch.float32)
+    check(f"conv2d[{name}] k{k}s{s}", out, ref, tol)
 
 
 @pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
@@ -390,6 +395,21 @@ def test_m2f_attn_mask():
         print(f"[parity] m2f_attn_mask {size}: mismatch fraction {mism:.2e}")
         assert mism <= 1e-4  # boolean threshold of an fp32 bilinear sample: ties at |x|<1e-7 only
         assert not out[0, 3].any()
+
+
+def test_bmm_nt_runtime_operand():
+    """the Mask2Former mask product: both operands are activations; the bf16x3 form takes the planes interleaved by split_bf16"""
+    ops = _ops()
+    a, b = gen(2, 700, 256, seed=60), gen(2, 100, 256, seed=61)
+    ref = torch.einsum("zmk,znk->zmn", a, b)
+    hi, lo, kpad, x3 = ops.split_bf16(b.view(200, 256).cuda(), True, want_x3=True)
+    assert torch.equal(x3[:, :, 0].reshape(200, kpad), hi) and torch.equal(x3[:, :, 1].reshape(200, kpad), lo)
+    out3 = ops.bmm_nt(a.cuda(), hi.view(2, 100, kpad), lo.view(2, 100, kpad), 100, 256, b_x3=x3)
+    check("bmm_nt[bf16x3, LDS-DMA]", out3, ref, TOL_F32)
+    out3r = ops.bmm_nt(a.cuda(), hi.view(2, 100, kpad), lo.view(2, 100, kpad), 100, 256)
+    check("bmm_nt[bf16x3, register-staged]", out3r, ref, TOL_F32)
+    out1 = ops.bmm_nt(a.cuda().bfloat16(), hi.view(2, 100, kpad), None, 100, 256)
+    check("bmm_nt[bf16]", out1, torch.einsum("zmk,znk->zmn", a.bfloat16().float(), hi.view(2, 100, kpad).float().cpu()), TOL_BF16)
 
 
 def test_split_bf16_exact():
