@@ -1,11 +1,15 @@
 #!/usr/bin/env python
 """SIU3R hot-path benchmark (driver contract: one JSON line on rank 0).
 
-A "step" is one pass of the hot path (SIU3RModel.forward incl. on-device panoptic post-process and
-query-class-logit lifting inputs) over one batch of synthetic image pairs at 2 x 512 x 512 (BASELINE.json
-configs[1]: single pair, ViT-L encoder/decoder + DPT 3DGS heads + ViT-Adapter/Mask2Former, bf16), with
-seeded synthetic weights of the reference architecture (no checkpoint is available offline) and inputs
-already resident in HBM.  value = image-pairs/s over all ranks (weak scaling: each rank runs its own pairs).
+A "step" is one pass of the hot path (SIU3RModel.forward incl. the on-device panoptic post-process with a NON-EMPTY result and
+the query-class-logit lifting inputs) over one batch of synthetic image pairs at 2 x 512 x 512 (BASELINE.json configs[1]: single
+pair, ViT-L encoder/decoder + DPT 3DGS heads + ViT-Adapter/Mask2Former), with seeded synthetic weights of the reference
+architecture (no checkpoint is available offline) and inputs already resident in HBM.  value = image-pairs/s over all ranks (weak
+scaling: each rank runs its own pairs).
+
+The timed mode is the one that meets the north-star parity bar (<= 1e-3 max-norm on the Gaussian fields against the fp32 oracle):
+precision "bf16x3" = fp32 activations, bf16 MFMA with the hi/lo operand split (3 passes).  The plain-bf16 mode (bf16 operands,
+~2e-2 .. 1e-1 on the fields, tests/test_model_gpu.py) is timed the same way right after and reported as `second_mode`.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -13,6 +17,7 @@ already resident in HBM.  value = image-pairs/s over all ranks (weak scaling: ea
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -24,6 +29,69 @@ sys.path.insert(0, ROOT)
 
 FLOPS_PER_PAIR_512 = 4059.0e9  # algorithmic 2*MAC of one pair @512^2 (torch flop counter on the reference)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+PARITY = {"bf16x3": "<= 1e-3 max-norm on every Gaussian field vs the fp32 oracle (tests/test_model_gpu.py, tools/parity_sweep.py)",
+          "bf16": "bf16 operand rounding: 2e-2 .. 1e-1 on the fields (covariances worst), label agreement 0.85-0.93"}
+
+
+def pmc_bytes(section, kernels):
+    """HBM-side bytes per launch from the committed counter passes (tools/pmc_cmd.sh: separate FETCH_SIZE / WRITE_SIZE runs, both in
+    KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  kernels: names to sum (each with its launches per unit)."""
+    if not os.path.exists(PMC_FILE):
+        return None, None
+    sec = json.load(open(PMC_FILE)).get(section)
+    if not sec:
+        return None, None
+    total = 0.0
+    for name, per_unit in kernels:
+        e = sec.get(name)
+        if not e or "FETCH_SIZE" not in e or "WRITE_SIZE" not in e:
+            return None, None
+        total += per_unit * (2.0 * e["FETCH_SIZE"]["per_launch"] + e["WRITE_SIZE"]["per_launch"]) * 1024.0
+    return total, f"profiles/r02_pmc_summary.json[{section}]"
+
+
+def pmc_frame_bytes(section, views_per_call):
+    """HBM-side bytes of one rendered frame: every kernel the profiled rasterizer command launched (project, sort passes, binning,
+    composite, buffer clears), summed, over the frames it rendered (= composite launches x views per call)."""
+    if not os.path.exists(PMC_FILE):
+        return None, None
+    sec = json.load(open(PMC_FILE)).get(section)
+    if not sec:
+        return None, None
+    comp = [e for n, e in sec.items() if n.startswith("composite_rgb_kernel")]
+    if not comp or "FETCH_SIZE" not in comp[0]:
+        return None, None
+    frames = sum(e["FETCH_SIZE"]["launches"] for e in comp) * views_per_call
+    tot = sum(2.0 * e.get("FETCH_SIZE", {}).get("total", 0.0) + e.get("WRITE_SIZE", {}).get("total", 0.0) for e in sec.values()) * 1024.0
+    return tot / frames, f"profiles/r02_pmc_summary.json[{section}] (all kernels of the command / {frames} frames)"
+
+
+def timed_steps(step, steps, D, dev):
+    """the contract's timed region: barrier + synchronize on both sides, max over ranks"""
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    return D.max_over_ranks(time.perf_counter() - t0, device=dev), out
+
+
+def event_ms(fn, reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def main():
@@ -33,7 +101,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1, help="image pairs per step per GPU (configs[1] = 1)")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16", "bf16x3"], help="the timed mode (default: the 1e-3 parity mode)")
+    ap.add_argument("--no-second-mode", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-render", action="store_true")
@@ -55,136 +124,164 @@ def main():
     B = args.batch
 
     sd = OW.make_weights(0)
-    model = SIU3RModel(sd, image_size=(H, W), precision=args.precision, device=dev)
     g = torch.Generator().manual_seed(1234 + rank)
     images = torch.rand(B, 2, 3, H, W, generator=g).to(dev)
     K = torch.tensor([[318 / 256, 0, 0.5], [0, 318 / 256, 0.5], [0, 0, 1]])[None, None].repeat(B, 2, 1, 1).to(dev)
 
-    def step():
-        with torch.no_grad():
-            return model(images, K, enable_query_class_logit_lift=True)
+    def run_mode(precision):
+        model = SIU3RModel(sd, image_size=(H, W), precision=precision, device=dev)
 
-    # untimed warm-up: at least 3 passes whatever W is (1st packs the weights eagerly, 2nd captures the HIP graphs, 3rd replays)
-    for _ in range(max(3, args.warmup)):
-        out = step()
-    model.release_source_weights()
-    del sd
-    torch.cuda.synchronize()
-    D.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    D.barrier()
-    torch.cuda.synchronize()
-    dt = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+        def step():
+            with torch.no_grad():
+                return model(images, K, enable_query_class_logit_lift=True)
+
+        # untimed warm-up: at least 3 passes whatever W is (1st packs the weights eagerly, 2nd captures the HIP graphs, 3rd replays)
+        for _ in range(max(3, args.warmup)):
+            step()
+        model.release_source_weights()
+        dt, out = timed_steps(step, args.steps, D, dev)
+        return model, step, dt, out
+
+    model, step, dt, out = run_mode(args.precision)
 
     # the path's single collective: per-rank additive statistics
     gauss = out[0]
     stats = dict(n_pairs=B * args.steps, n_images=2 * B * args.steps, n_gaussians=gauss.means.shape[1] * B,
                  n_segments=sum(len(i) for i in out[3]), label_checksum=float(gauss.instance_labels.sum().item()))
-    gathered = D.all_gather_stats(D.pack_stats(stats), device=dev)
-    total = D.reduce_stats(gathered)
+    total = D.reduce_stats(D.all_gather_stats(D.pack_stats(stats), device=dev))
+
+    second, m2, step2 = None, None, None
+    if not args.no_second_mode:
+        other = "bf16" if args.precision == "bf16x3" else "bf16x3"
+        m2, step2, dt2, out2 = run_mode(other)
+        second = {"precision": other, "value": B * args.steps * world / dt2, "unit": "image-pairs/s", "ms_per_step": dt2 / args.steps * 1e3,
+                  "n_segments_per_step": sum(len(i) for i in out2[3]), "parity": PARITY[other]}
+        del out2
+    del sd
 
     if rank != 0:
         return
     pairs = total["n_pairs"]
     value = pairs / dt
+    x3 = args.precision == "bf16x3"
     result = {
         "metric": "image-pairs/sec @2x512^2 (SIU3R network forward incl. panoptic post-process)",
         "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (fp32 activations, 3-pass bf16 MFMA)",
-        "data": "synthetic (seeded uniform images, seeded synthetic weights of the reference architecture)",
+        "dtype": "bf16x3 (fp32 activations, bf16 MFMA with hi/lo operand split; meets the 1e-3 parity bar)" if x3 else "bf16",
+        "data": "synthetic (seeded uniform images, seeded synthetic weights of the reference architecture, shaped so that the panoptic result is non-empty)",
         "config": {"workload": f"configs[1]: single pair 2x{H}x{W} per step" if B == 1 else f"{B} pairs 2x{H}x{W} per step",
-                   "pairs_per_step_per_gpu": B, "image_size": [H, W], "precision": args.precision,
+                   "pairs_per_step_per_gpu": B, "image_size": [H, W], "precision": args.precision, "parity": PARITY[args.precision],
                    "parallelism": f"dp{world} (independent pairs, one all-gather of metric statistics)",
-                   "launch": "per-chain HIP graphs on 6 streams" if (model.use_graph and model._ctx.concurrent) else "eager"},
+                   "launch": "per-chain HIP graphs on 6 streams" if (model.use_graph and model._ctx.concurrent) else "eager",
+                   "n_segments_per_step": total["n_segments"] / max(1, world), "n_gaussians_per_step": total["n_gaussians"] / max(1, world)},
         "network_tflops_algorithmic": value * FLOPS_PER_PAIR_512 * (H * W / (512 * 512)) / 1e12,
     }
+    if second:
+        result["second_mode"] = second
 
     if not args.no_roofline:
-        timer = ops.KernelTimer()
-        ops.set_kernel_timer(timer)
-        conc, model._ctx.concurrent = model._ctx.concurrent, False  # one stream: every launch between its own two events
-        torch.cuda._sleep(int(2.0e8))  # ~0.1 s: the whole step is enqueued before it runs, so the event pairs time the
-        step()                         # kernels back to back instead of the host's launch pace
-        model._ctx.concurrent = conc
-        ops.set_kernel_timer(None)
-        summ = timer.summary()
-        dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
-        name, d = dom
-        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_pass.sh: separate
-        # FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md, both in KiB)
-        traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc_path) and args.precision == "bf16" and B == 1 and (H, W) == (512, 512):
-            pmc = json.load(open(pmc_path)).get("siu3r_gemm_dma::gemm_dma_kernel<1, 0, false, 2>") if name == "gemm_dma_kernel<1,0,false,2>" else None
-            if pmc:
-                traffic = (2.0 * pmc["fetch_size_per_launch"] + pmc["write_size_per_launch"]) * 1024.0
-                traffic_src = "profiles/r01_pmc_summary.json (gemm_dma_kernel<1,0,false,2>, mean per launch)"
-        result["roofline"] = {
-            "kernel": f"siu3r_gemm_dma::{name} (dense Linear launches; HIP events around every launch of one eager single-stream step, queued behind a sleep kernel, after the timed region)",
-            "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-            "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
-            "algorithmic_flops_per_launch_avg": d["flops"] / d["launches"],
-            "gemm_time_ms_per_step": d["ms"],
-            "all_variants": {k: {"launches": v["launches"], "ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()},
-        }
+        result["roofline"] = gemm_roofline(model, step, args.precision, B, H, W)
+        if second and m2 is not None:
+            second["roofline"] = gemm_roofline(m2, step2, second["precision"], B, H, W)
 
     if not args.no_render:
-        # render leg (the metric's "render ms/frame"): the pair's 524 288 Gaussians -> 6 target views @512^2 through the
-        # K2-semantics path (SplattingCUDA.forward, colour + depth), timed with HIP events on the launch stream
-        import copy
-        from siu3r_amd import raster, synthetic
-        from siu3r_amd.gaussian_renderer import SplattingCUDA
-        from siu3r_amd.gaussians_types import Gaussians
+        result.update(render_legs(gauss, B, H, W, dev, world))
 
-        nv = 6
-        ext = synthetic.target_views(nv)[None].repeat(B, 1, 1, 1)
-        Kt = synthetic.default_intrinsics()[None, None].repeat(B, nv, 1, 1)
-        rend = SplattingCUDA()
-        def fresh():
-            return Gaussians(means=gauss.means.clone(), covariances=gauss.covariances.clone(), harmonics=gauss.harmonics, opacities=gauss.opacities)
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baselines(images, K, H, W)
+    print(json.dumps(result))
+
+
+def gemm_roofline(model, step, precision, B, H, W):
+    """roofline object of the mode's dominant kernel (largest summed launch time): HIP events around every GEMM launch of one eager
+    single-stream step, queued behind a sleep kernel so that the pairs time the kernels back to back (after the timed region)"""
+    from siu3r_amd import ops
+
+    timer = ops.KernelTimer()
+    ops.set_kernel_timer(timer)
+    conc, model._ctx.concurrent = model._ctx.concurrent, False  # one stream: every launch between its own two events
+    torch.cuda._sleep(int(2.0e8))  # ~0.1 s: the whole step is enqueued before it runs
+    step()
+    model._ctx.concurrent = conc
+    ops.set_kernel_timer(None)
+    summ = timer.summary()
+    name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    passes = 3 if "x3" in name else 1
+    traffic, traffic_src = (None, None)
+    if B == 1 and (H, W) == (512, 512):
+        traffic, traffic_src = pmc_bytes(f"bench_{precision}", [(f"siu3r_gemm_dma::{name}", 1.0)])
+    busy = None
+    bf = os.path.join(ROOT, "profiles", "r02_mfma_busy.json")
+    if os.path.exists(bf):
+        busy = json.load(open(bf)).get(f"bench_{precision}", {}).get("kernels", {}).get(f"siu3r_gemm_dma::{name}", {}).get("mfma_busy_frac")
+    return {
+        "kernel": f"siu3r_gemm_dma::{name}",
+        "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+        "mfma_passes_per_product": passes, "mfma_issue_frac": achieved * passes / MFMA_BF16_PEAK_TFLOPS,
+        "mfma_busy_counter_frac": busy, "mfma_busy_source": "profiles/r02_mfma_busy.json (SQ_VALU_MFMA_BUSY_CYCLES pass)" if busy is not None else None,
+        "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+        "algorithmic_flops_per_launch_avg": d["flops"] / d["launches"],
+        "gemm_time_ms_per_step": sum(v["ms"] for v in summ.values()),
+        "all_variants": {k: {"launches": v["launches"], "ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()},
+    }
+
+
+def render_legs(gauss, B, H, W, dev, world):
+    """render ms/frame (the metric's second half) through the product path, K2 semantics (SplattingCUDA.forward: colour + depth):
+      render             the network's own Gaussians (synthetic weights: few of them land in view)
+      render_pair_scene  a pixel-aligned 2 x H x W Gaussian set as a trained network emits for an indoor pair (>= 50 % in view)
+      render_stress      BASELINE.json configs[4] shape: 2 097 152 Gaussians, one 1920 x 1080 frame"""
+    from siu3r_amd import cuda_splatting as cs, raster, synthetic
+    from siu3r_amd.gaussian_renderer import SplattingCUDA
+    from siu3r_amd.gaussians_types import Gaussians
+
+    out = {}
+    nv = 6
+    ext1 = synthetic.target_views(nv)
+    Kt1 = synthetic.default_intrinsics()[None].repeat(nv, 1, 1)
+    rend = SplattingCUDA()
+
+    def leg(means, cov, sh, opac, label):
+        """means [b,G,3] ... on the device; forward rescales means / covariances in place, hence the fresh copies"""
+        b = means.shape[0]
+        ext, Kt = ext1[None].repeat(b, 1, 1, 1), Kt1[None].repeat(b, 1, 1, 1)
+        fresh = lambda: Gaussians(means=means.clone(), covariances=cov.clone(), harmonics=sh, opacities=opac)
         rend.forward(fresh(), ext, Kt, (H, W), render_color=True)  # warm-up
         reps = 3
         gs = [fresh() for _ in range(reps)]
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for g_ in gs:
-            rend.forward(g_, ext, Kt, (H, W), render_color=True)
-        e1.record()
-        torch.cuda.synchronize()
-        ms_frame = e0.elapsed_time(e1) / (reps * B * nv)
-        # data-dependent sizes of one view, for the algorithmic byte count
-        from siu3r_amd import cuda_splatting as cs
-        g1 = fresh()
-        raster.scale_inplace_(g1.means, 10.0); raster.scale_inplace_(g1.covariances, 100.0)
-        e = ext[0].clone(); e[:, :3, 3] *= 10.0
-        _, _, aux = cs.render_cuda(e[1:2], Kt[0, 1:2], torch.tensor([1.0]), torch.tensor([1000.0]), (H, W), torch.zeros(1, 3), g1.means[:1], g1.covariances[:1], g1.harmonics[:1], g1.opacities[:1], return_aux=True)
+        it = iter(gs)
+        ms_frame = event_ms(lambda: rend.forward(next(it), ext, Kt, (H, W), render_color=True), reps) / (b * nv)
+        # data-dependent sizes of the views of item 0 (visible Gaussians, (Gaussian, tile) pairs) for the algorithmic byte count
+        e = ext1.clone()
+        e[:, :3, 3] *= 10.0
+        _, _, aux = cs.render_cuda(e, Kt1, torch.full((nv,), 1.0), torch.full((nv,), 1000.0), (H, W), torch.zeros(nv, 3), (means[0] * 10.0)[None].expand(nv, -1, -1),
+                                   (cov[0] * 100.0)[None].expand(nv, -1, -1, -1), sh[0][None].expand(nv, -1, -1, -1), opac[0][None].expand(nv, -1), return_aux=True)
         st = aux[0]["state"]
-        G = g1.means.shape[1]; G_v = int((st["tiles_touched"] > 0).sum()); Dp = int(st["D"]); P = H * W
-        bytes_alg = raster.algorithmic_bytes(G, G_v, Dp, P)
-        result["render"] = {"ms_per_frame": ms_frame, "views": nv, "resolution": [H, W], "gaussians": G, "visible": G_v, "tile_pairs": Dp,
-                            "semantics": "K2 (diff-gaussian-rasterization family): SH deg 4 -> RGB + depth + opacity + n_touched",
-                            "roofline": {"bound": "hbm", "achieved": bytes_alg / (ms_frame * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                         "frac": bytes_alg / (ms_frame * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_view": bytes_alg, "traffic": None,
-                                         "note": "whole per-view pipeline (project+scan+fill+sort+composite, incl. host-side camera prep and the pair-count sync)"}}
+        G = means.shape[1]
+        Gv, Dp = st.totals(0), st.totals(1)
+        bytes_alg = sum(raster.algorithmic_bytes(G, gv, d, H * W) for gv, d in zip(Gv, Dp)) / nv
+        ach = bytes_alg / (ms_frame * 1e-3) / 1e9
+        return {"ms_per_frame": ms_frame, "views": nv, "resolution": [H, W], "gaussians": G, "visible_mean": sum(Gv) / nv, "visible_frac": sum(Gv) / nv / G,
+                "tile_pairs_mean": sum(Dp) / nv, "scene": label,
+                "semantics": "K2 (diff-gaussian-rasterization family): SH deg 4 -> RGB + depth, all views of an item in one rasterizer call",
+                "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_view": bytes_alg, "traffic": None,
+                             "note": "whole per-frame pipeline (project, per-view radix sort, coarse binning, composite), incl. host-side camera prep"}}
 
-    if not args.no_render and world == 1:
-        # rasterizer stress leg (BASELINE.json configs[4] shape): 2 097 152 Gaussians (what 8 views x 512^2 produce), most of
-        # them in view, one 1920x1080 frame, SH degree 4 -> RGB + depth (K2 semantics).  The network's own output with
-        # synthetic weights leaves ~6 % of the Gaussians in view, which says little about the rasterizer's bandwidth
-        import math
-        from siu3r_amd import cuda_splatting as cs
+    out["render"] = leg(gauss.means, gauss.covariances, gauss.harmonics, gauss.opacities, "the network's own output (synthetic weights)")
+    pm, pc, po, ps = (t.to(dev) for t in synthetic.pixel_aligned_scene(H, W, 2, seed=0))
+    out["render_pair_scene"] = leg(pm[None], pc[None], ps[None], po[None], "siu3r_amd.synthetic.pixel_aligned_scene(seed=0): 2 views x H x W pixel-aligned Gaussians of an indoor pair")
+    if (H, W) == (512, 512):
+        t, src = pmc_frame_bytes("raster_pair", nv)
+        out["render_pair_scene"]["roofline"]["traffic"], out["render_pair_scene"]["roofline"]["traffic_source"] = t, src
+    del pm, pc, po, ps
+
+    if world == 1:
         Gs, Ws, Hs = 2_097_152, 1920, 1080
         m_, cov_, op_, sh_ = (t.to(dev) for t in synthetic.random_scene(Gs, seed=1, spread=3.0, depth=(2.0, 9.0), scale=(0.004, 0.03)))
-        cov6 = raster.cov6_from_cov3x3(cov_)
-        shs = sh_.permute(0, 2, 1).contiguous()
         c2w = synthetic.perturbed_camera(0, jitter=0.1)
         w2c = torch.linalg.inv(c2w)
         fx = 0.9 * Ws
@@ -192,49 +289,76 @@ def main():
         proj = cs.get_projection_matrix(torch.tensor([0.1]), torch.tensor([100.0]), torch.tensor([fovx]), torch.tensor([fovy]))[0]
         cam2 = raster.make_cam_k2(w2c=w2c, full_proj=proj @ w2c, tanfovx=math.tan(fovx / 2), tanfovy=math.tan(fovy / 2), campos=c2w[:3, 3],
                                   bg=torch.zeros(3), width=Ws, height=Hs, sh_degree=4)
+        run = lambda: raster.rasterize_views_k2([cam2], m_, cov_, sh_, op_, want_n_touched=True, sh_planar=True)
         for _ in range(2):
-            o = raster.rasterize_k2(cam2, m_, cov6, shs, op_)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            o = raster.rasterize_k2(cam2, m_, cov6, shs, op_)
-        e1.record()
-        torch.cuda.synchronize()
-        ms_s = e0.elapsed_time(e1) / 5
-        Gv_s, D_s = int((o["state"]["tiles_touched"] > 0).sum()), int(o["state"]["D"])
+            o = run()
+        ms_s = event_ms(run, 5)
+        st = o["state"]
+        Gv_s, D_s = st.totals(0)[0], st.totals(1)[0]
         b_s = raster.algorithmic_bytes(Gs, Gv_s, D_s, Hs * Ws)
-        result["render_stress"] = {"ms_per_frame": ms_s, "resolution": [Ws, Hs], "gaussians": Gs, "visible": Gv_s, "tile_pairs": D_s,
-                                   "scene": "siu3r_amd.synthetic.random_scene(seed=1): configs[4] shape (8 views x 512^2 worth of Gaussians, 1080p)",
-                                   "roofline": {"bound": "hbm", "achieved": b_s / (ms_s * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                                "frac": b_s / (ms_s * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_view": b_s, "traffic": None}}
-        del m_, cov_, op_, sh_, cov6, shs, o
+        t, src = pmc_frame_bytes("raster_stress", 1)
+        out["render_stress"] = {"ms_per_frame": ms_s, "resolution": [Ws, Hs], "gaussians": Gs, "visible": Gv_s, "visible_frac": Gv_s / Gs, "tile_pairs": D_s,
+                                "scene": "siu3r_amd.synthetic.random_scene(seed=1): configs[4] shape (8 views x 512^2 worth of Gaussians, 1080p), RGB + depth + n_touched",
+                                "roofline": {"bound": "hbm", "achieved": b_s / (ms_s * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": b_s / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_view": b_s, "traffic": t, "traffic_source": src}}
+        del m_, cov_, op_, sh_, o
+    return out
 
-    if world == 1 and not args.no_cpu_baseline:
-        from oracle import siu3r_oracle as O
 
-        # bounded CPU sample: 16 threads (256 oversubscribed threads made one forward take 830 s on the GPU box);
-        # a quarter-size pair first, and the full-size pair only if it is predicted to stay within ~40 s
-        torch.set_num_threads(min(16, os.cpu_count() or 1))
-        sd_cpu = OW.make_weights(0)
-        K_c = K[:1].cpu()
-        img_q = torch.nn.functional.interpolate(images[0].cpu(), size=(H // 2, W // 2), mode="bilinear")[None]
+def cpu_baselines(images, K, H, W):
+    """Bounded CPU samples on the host cores: the fp32 oracle forward (the metric's unit) and the OpenMP reference rasterizer
+    (oracle/raster_ref.c) on one frame of the pair scene.  Test infrastructure used as the thing to compare against, never shipped."""
+    from oracle import siu3r_oracle as O
+    from oracle import raster_oracle as RO
+    from siu3r_amd import cuda_splatting as cs, raster, synthetic
+    from siu3r_amd import synthetic_weights as OW
+
+    # 16 threads (256 oversubscribed threads made one forward take 830 s on the GPU box); a quarter-size pair first, and the
+    # full-size pair only if it is predicted to stay within ~40 s
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    sd_cpu = OW.make_weights(0)
+    K_c = K[:1].cpu()
+    img_q = torch.nn.functional.interpolate(images[0].cpu(), size=(H // 2, W // 2), mode="bilinear")[None]
+    t1 = time.perf_counter()
+    with torch.no_grad():
+        O.model_forward(sd_cpu, img_q, K_c, keep_intermediates=False)
+    t_q = time.perf_counter() - t1
+    if t_q * 4.4 <= 40.0:
         t1 = time.perf_counter()
         with torch.no_grad():
-            O.model_forward(sd_cpu, img_q, K_c, keep_intermediates=False)
-        t_q = time.perf_counter() - t1
-        if t_q * 4.4 <= 40.0:
-            t1 = time.perf_counter()
-            with torch.no_grad():
-                O.model_forward(sd_cpu, images[:1].cpu(), K_c, keep_intermediates=False)
-            t_cpu = time.perf_counter() - t1
-            sample = f"1 pair 2x{H}x{W}, one fp32 forward = {t_cpu:.1f} s"
-        else:
-            t_cpu = t_q * 4.27  # FLOP ratio 4059.0 / 950.7 GFLOP between 512^2 and 256^2
-            sample = f"1 pair 2x{H//2}x{W//2} = {t_q:.1f} s, scaled x4.27 (FLOP ratio) to 2x{H}x{W}"
-        result["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "image-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-                                  "sample": sample + "; oracle/siu3r_oracle.py = parity-pinned fp32 port of the reference forward"}
-    print(json.dumps(result))
+            O.model_forward(sd_cpu, images[:1].cpu(), K_c, keep_intermediates=False)
+        t_cpu = time.perf_counter() - t1
+        sample = f"1 pair 2x{H}x{W}, one fp32 forward = {t_cpu:.1f} s"
+    else:
+        t_cpu = t_q * 4.27  # FLOP ratio 4059.0 / 950.7 GFLOP between 512^2 and 256^2 (SURVEY.md Appendix B)
+        sample = f"1 pair 2x{H//2}x{W//2} = {t_q:.1f} s, scaled x4.27 (FLOP ratio) to 2x{H}x{W}"
+    base = {"value": 1.0 / t_cpu, "unit": "image-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": sample + "; oracle/siu3r_oracle.py = parity-pinned fp32 port of the reference forward"}
+
+    # rasterizer: one 512^2 frame of the pixel-aligned pair scene (524 288 Gaussians) through oracle/raster_ref.c, OpenMP over tiles
+    threads = min(32, os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(threads)  # read when libgomp starts its first team (the library is loaded below)
+    means, cov, opac, sh = synthetic.pixel_aligned_scene(H, W, 2, seed=0)
+    e = synthetic.target_views(2)[1].clone()
+    e[:3, 3] *= 10.0
+    Kt = synthetic.default_intrinsics()
+    fov = cs.get_fov(Kt[None])
+    tan = (0.5 * fov).tan()[0]
+    proj = cs.get_projection_matrix(torch.tensor([1.0]), torch.tensor([1000.0]), fov[:, 0], fov[:, 1])[0]
+    w2c = torch.linalg.inv(e)
+    cam = raster.make_cam_k2(w2c, proj @ w2c, float(tan[0]), float(tan[1]), e[:3, 3].tolist(), [0, 0, 0], W, H, sh_degree=4)
+    a = ((means * 10.0).numpy(), raster.cov6_from_cov3x3(cov * 100.0).numpy(), opac.numpy(), sh.permute(0, 2, 1).contiguous().numpy())
+    RO.forward(cam, *a, want_lists=False)  # warm-up (page faults, thread team start)
+    t1 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t1 < 5.0 and n < 20):
+        ref = RO.forward(cam, *a, want_lists=False)
+        n += 1
+    t_r = (time.perf_counter() - t1) / n
+    base["raster"] = {"value": 1.0 / t_r, "unit": "frames/s", "ms_per_frame": t_r * 1e3, "cores": threads, "kind": "port",
+                      "sample": f"{n} x one {H}x{W} frame of the pair scene ({means.shape[0]} Gaussians, {int((ref['tiles_touched'] > 0).sum())} visible, "
+                                f"{ref['D']} tile pairs), whole pipeline; oracle/raster_ref.c (-O2 -fopenmp, tiles in parallel; projection and sort serial)"}
+    return base
 
 
 if __name__ == "__main__":

@@ -238,18 +238,21 @@ def _gemm_launch(p: GemmParams, dev=None):
         return
     # label with the kernel the launcher will pick (mirrors gemm.hip / gemm_dma.hip dispatch) so that the event
     # averages line up with rocprofv3's per-kernel rows
+    tf = lambda b: "true" if b else "false"
+    lnf = bool(p.ln_stats)
     if _x3_dma(p):
-        variant = "gemm_dma_x3_kernel (bf16x3, fp32 A)"
+        mode = 0 if p.a_mode == 0 else (1 if (p.cin % 32 == 0 and p.kh * p.kw <= 31) else 2)
+        variant = f"gemm_dma_x3_kernel<{mode}, {tf(p.relu_in and mode == 1)}, 2, {tf(lnf and mode == 0)}>"
     elif p.w_lo:
-        variant = "gemm_kernel<1,1,1> (bf16x3)"
+        variant = "gemm_kernel<1, 1, 1>"
     elif p.a_dtype == F32 or p.a_mode == 2:
-        variant = "gemm_kernel<1,0,1> (fp32 A)"
+        variant = "gemm_kernel<1, 0, 1>"
     elif p.a_mode == 0:
-        variant = "gemm_dma_kernel<1,0,false,2>" if not p.relu_in else "gemm_kernel<0,0,1>"
+        variant = f"gemm_dma_kernel<1, 0, false, 2, {tf(lnf)}>" if not p.relu_in else "gemm_kernel<0, 0, 1>"
     elif p.cin % 64 == 0 and p.kh * p.kw <= 32 and p.kpad == p.k:
-        variant = "gemm_dma_kernel<1,1,true,2>" if p.relu_in else "gemm_dma_kernel<1,1,false,2>"
+        variant = f"gemm_dma_kernel<1, 1, {tf(p.relu_in)}, 2, false>"
     else:
-        variant = "gemm_dma_kernel<1,2,false,2>" if not p.relu_in else "gemm_kernel<0,0,1>"
+        variant = "gemm_dma_kernel<1, 2, false, 2, false>" if not p.relu_in else "gemm_kernel<0, 0, 1>"
     flops = 2.0 * p.m * p.n * p.k * max(1, p.batch)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
