@@ -520,6 +520,10 @@ __global__ void m2f_mask_kernel(const float* ml, uint8_t* out, int32_t* row_coun
   out[((int64_t)b * Q + q) * ld + ((int64_t)t * OH + oy) * OW + ox] = blocked;
   if (blocked) atomicAdd(&row_counts[b * Q + q], 1);
 }
+__global__ void zero_i32_kernel(int32_t* p, int64_t n) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) p[idx] = 0;
+}
 __global__ void m2f_mask_fix_kernel(uint8_t* out, const int32_t* row_counts, int64_t rows, int64_t nk, int64_t ld) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * nk) return;
@@ -705,10 +709,9 @@ extern "C" int siu3r_m2f_attn_mask(const float* mask_logits, uint8_t* out, int32
   SIU3R_CHECK(mask_logits && out && row_counts_ws, "m2f_attn_mask: null pointer");
   SIU3R_CHECK(out_ld >= (int64_t)T * OH * OW, "m2f_attn_mask: out_ld too small");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(row_counts_ws, 0, sizeof(int32_t) * B * Q, s) != hipSuccess) {
-    siu3r_set_error("m2f_attn_mask: memset failed");
-    return 2;
-  }
+  // (a kernel, not hipMemsetAsync: inside a captured per-chain graph the memset node was observed not to be ordered before the
+  // counting kernel on replay -- stale counts from the previous replay survived)
+  hipLaunchKernelGGL(zero_i32_kernel, grid1d((int64_t)B * Q), dim3(256), 0, s, row_counts_ws, (int64_t)B * Q);
   const int64_t nk = (int64_t)T * OH * OW;
   hipLaunchKernelGGL(m2f_mask_kernel, grid1d((int64_t)B * nk * Q), dim3(256), 0, s, mask_logits, out, row_counts_ws, B, T, IH, IW, OH, OW, Q, out_ld);
   hipLaunchKernelGGL(m2f_mask_fix_kernel, grid1d((int64_t)B * Q * nk), dim3(256), 0, s, out, row_counts_ws, (int64_t)B * Q, nk, out_ld);

@@ -801,7 +801,9 @@ class VideoMask2FormerForVideoSegmentation:
             ctx.cache[key] = [_sine_pos_3d(T, a, b).contiguous().to(ctx.dev) for (a, b) in sizes]
         pos3 = ctx.cache[key]
         le = ctx.w.v(tm + ".level_embed.weight")
-        ones = ctx.cache.setdefault("ones256", torch.ones(256, device=ctx.dev))
+        if "ones256" not in ctx.cache:
+            ctx.cache["ones256"] = torch.ones(256, device=ctx.dev)
+        ones = ctx.cache["ones256"]
         # Keys / values of the three memory levels for all nine layers up front: layer idx reads level idx % 3, and its
         # key projection Wk (feats + pos) + bk = Wk feats + (Wk pos + bk) has an input-independent second term, so one GEMM per
         # level yields K and V of its three layers (N = 6 x 256) with that constant riding in as the residual -- 3 launches on
