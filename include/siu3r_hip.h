@@ -144,8 +144,9 @@ int siu3r_attention(const siu3r_attn_params* p, void* stream);
 /* ---- element-wise / gather kernels (see DESIGN.md for the HBM roofline of each) ---------- */
 /* y = a + b (b broadcast over rows when b_rows < rows: row r uses b[r % b_rows]) */
 int siu3r_add(const float* a, const float* b, float* y, int64_t rows, int64_t b_rows, int C, void* stream);
-/* image [N,3,H,W] fp32 (NCHW) -> [N,H,W,8] channel-last, zero padded channels */
-int siu3r_pack_image_nhwc8(const float* img, void* out, int out_dtype, int N, int H, int W, void* stream);
+/* image [N,3,H,W] fp32 (NCHW) -> [N,H,W,cpad] channel-last, zero padded channels: cpad = 8 (bf16 or fp32) or 4 (fp32: one 16-byte
+ * pixel per gather chunk of the bf16x3 convolution) */
+int siu3r_pack_image_nhwc(const float* img, void* out, int out_dtype, int N, int H, int W, int cpad, void* stream);
 /* bilinear resize NHWC; align_corners as in F.interpolate; y = affine(resize(x) + addend)
  * (heads/dpt_block.py:230-235 align=1; vit_adapter.py:429-433, video_seg_decoder.py:2173-2178 align=0) */
 int siu3r_resize_bilinear(const void* x, int x_dtype, void* y, int y_dtype, const void* addend, int add_dtype,

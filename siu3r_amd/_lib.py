@@ -85,7 +85,7 @@ SIGNATURES = {
     "siu3r_layernorm2": [_P, _P, _I, _P, _P, _P, _L, _I, _L, _L, _L, _F, _P],
     "siu3r_attention": [C.POINTER(AttnParams), _P],
     "siu3r_add": [_P, _P, _P, _L, _L, _I, _P],
-    "siu3r_pack_image_nhwc8": [_P, _P, _I, _I, _I, _I, _P],
+    "siu3r_pack_image_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "siu3r_resize_bilinear": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "siu3r_affine_add": [_P, _I, _P, _I, _P, _I, _P, _P, _L, _I, _P],
     "siu3r_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _I, _P],

@@ -135,11 +135,16 @@ __global__ void add_kernel(const float* a, const float* b, float* y, int64_t row
 }
 
 // ================================ image pack NCHW(3) -> NHWC(8) =================================
-__global__ void pack_image_kernel(const float* img, void* out, int out_dtype, int N, int H, int W) {
+__global__ void pack_image_kernel(const float* img, void* out, int out_dtype, int N, int H, int W, int cpad) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t hw = (int64_t)H * W;
   if (idx >= (int64_t)N * hw) return;
   const int64_t n = idx / hw, r = idx - n * hw;
+  if (cpad == 4) {  // fp32 only: one 16-byte pixel = one chunk of the bf16x3 GEMM's small-cin gather
+    float4 o = {img[(n * 3 + 0) * hw + r], img[(n * 3 + 1) * hw + r], img[(n * 3 + 2) * hw + r], 0.f};
+    ((float4*)out)[idx] = o;
+    return;
+  }
   f32x8 v;
 #pragma unroll
   for (int j = 0; j < 8; ++j) v.v[j] = 0.f;
@@ -600,10 +605,11 @@ extern "C" int siu3r_add(const float* a, const float* b, float* y, int64_t rows,
   return 0;
 }
 
-extern "C" int siu3r_pack_image_nhwc8(const float* img, void* out, int out_dtype, int N, int H, int W, void* stream) {
+extern "C" int siu3r_pack_image_nhwc(const float* img, void* out, int out_dtype, int N, int H, int W, int cpad, void* stream) {
   SIU3R_CHECK(img && out, "pack_image: null pointer");
-  hipLaunchKernelGGL(pack_image_kernel, grid1d((int64_t)N * H * W), dim3(256), 0, (hipStream_t)stream, img, out, out_dtype, N, H, W);
-  SIU3R_LAUNCH_CHECK("siu3r_pack_image_nhwc8");
+  SIU3R_CHECK(cpad == 8 || (cpad == 4 && out_dtype == SIU3R_F32), "pack_image: 8 channels (bf16 / fp32) or 4 channels (fp32) per pixel, got %d", cpad);
+  hipLaunchKernelGGL(pack_image_kernel, grid1d((int64_t)N * H * W), dim3(256), 0, (hipStream_t)stream, img, out, out_dtype, N, H, W, cpad);
+  SIU3R_LAUNCH_CHECK("siu3r_pack_image_nhwc");
   return 0;
 }
 

@@ -343,7 +343,9 @@ extern "C" int siu3r_gemm(const siu3r_gemm_params* pp, void* stream) {
   if (p.a_mode == 0) {
     SIU3R_CHECK(p.k % 8 == 0 && p.lda % 8 == 0, "siu3r_gemm: dense A needs k %% 8 == 0 and lda %% 8 == 0 (k=%d lda=%ld)", p.k, (long)p.lda);
   } else if (p.a_mode == 1) {
-    SIU3R_CHECK(p.cin % 8 == 0, "siu3r_gemm: conv gather needs cin %% 8 == 0 (cin=%d)", p.cin);
+    // (cin % 4: fp32 activations on the bf16x3 LDS-DMA gather only -- 16-byte chunks of 4 channels)
+    SIU3R_CHECK(p.cin % 8 == 0 || (p.cin % 4 == 0 && p.w_x3 && p.a_dtype == SIU3R_F32 && !p.relu_in && !g_disable_dma),
+                "siu3r_gemm: conv gather needs cin %% 8 == 0 (cin %% 4 == 0 for fp32 activations with w_x3) (cin=%d)", p.cin);
     SIU3R_CHECK(p.k == p.kh * p.kw * p.cin, "siu3r_gemm: conv k=%d != kh*kw*cin", p.k);
     SIU3R_CHECK(p.m % (p.oh * p.ow) == 0, "siu3r_gemm: conv m=%d not a multiple of oh*ow", p.m);
   } else {

@@ -23,6 +23,9 @@
 namespace siu3r_gemm_dma {
 
 constexpr int BM = 128, BK = 64, STAGES = 3;
+#ifndef SIU3R_GEMM_PD_WIDE
+#define SIU3R_GEMM_PD_WIDE 2  // prefetch distance (K tiles in flight) of the 128 x 128 kernels; 3 and 4 (= 5 ring stages of 32 KiB, the whole LDS) measured no faster
+#endif
 constexpr int A_TILE_BYTES = BM * BK * 2;
 constexpr unsigned OOB = 0xffffff00u;  // >= num_records of every resource below: the DMA writes zeros
 constexpr int RSRC_FLAGS = 0x00020000;
@@ -47,8 +50,24 @@ __global__ __launch_bounds__(256 * KSPL, NI == 1 ? 2 * KSPL : 1) void gemm_dma_k
   constexpr int W_DMA = 2 * NI / KSPL;   // ... for W (BN/8 pieces)
   constexpr int LP = A_DMA + W_DMA;
   constexpr int KSW = 4 / KSPL;          // k-substeps (of 16) of a K tile handled by one wave
+  // ring depth: the L2 -> LDS stream of a CU is latency-bound (~1.2 us issue -> landed), its rate is set by the bytes in flight.  Two
+  // 128 x 64 workgroups per CU hold 2 x 2 tiles of 24 KiB in flight (3 stages each); the single 128 x 128 workgroup gets 5 stages
+  // and keeps 4 tiles of 32 KiB in flight
+  constexpr int PD = (NI == 2) ? SIU3R_GEMM_PD_WIDE : 2;
+  constexpr int STAGES = PD + 1;
   static_assert(STAGES * STAGE_BYTES >= siu3r_epi::staging_bytes<NI, KSPL>(), "epilogue staging must fit the ring");
+  static_assert(STAGES * STAGE_BYTES <= 160 * 1024, "ring exceeds the LDS");
   __shared__ __attribute__((aligned(128))) unsigned char smem[STAGES * STAGE_BYTES];
+  // s_waitcnt vmcnt(tiles * LP): at most `tiles` younger K tiles' pieces of this wave still in flight
+  auto wait_tiles_in_flight = [&](int tiles) {
+    static_assert(PD <= 4 && LP * 3 <= 63, "vmcnt immediates");
+    const int n = tiles * LP;
+    if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define SIU3R_VM_CASE(V) else if (n == V) asm volatile("s_waitcnt vmcnt(" #V ")" ::: "memory");
+    SIU3R_VM_CASE(3) SIU3R_VM_CASE(4) SIU3R_VM_CASE(6) SIU3R_VM_CASE(8) SIU3R_VM_CASE(9) SIU3R_VM_CASE(12) SIU3R_VM_CASE(16) SIU3R_VM_CASE(18) SIU3R_VM_CASE(24)
+#undef SIU3R_VM_CASE
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -302,8 +321,8 @@ __global__ __launch_bounds__(256 * KSPL, NI == 1 ? 2 * KSPL : 1) void gemm_dma_k
       asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa[j][0]), "+v"(fa[j][1]), "+v"(fb[j][0])::"memory");          \
   } while (0)
   auto tile_body = [&](int kt, int st, u32x4 (&fa)[4][2], u32x4 (&fb)[4][NI], u32x4 (&na)[4][2], u32x4 (&nb)[4][NI]) {
-    const int kt_next = (kt + 2 < nkt && !(dbg & 2)) ? kt + 2 : -1;  // wave-uniform
-    int stage_next = st + 2;
+    const int kt_next = (kt + PD < nkt && !(dbg & 2)) ? kt + PD : -1;  // wave-uniform
+    int stage_next = st + PD;
     if (stage_next >= STAGES) stage_next -= STAGES;
     int stage_read = st + 1;
     if (stage_read >= STAGES) stage_read -= STAGES;
@@ -326,17 +345,14 @@ __global__ __launch_bounds__(256 * KSPL, NI == 1 ? 2 * KSPL : 1) void gemm_dma_k
       else if (j == 2) { if (NI == 2) SIU3R_WAIT_FRAGS(4); else SIU3R_WAIT_FRAGS(3); }
       else SIU3R_WAIT_FRAGS(0);
       if (j == KSW - 1 && kt + 1 < nkt) {
-        // this wave has finished reading tile kt.  Tile kt+1 must have landed: only the LP pieces of tile kt+2 (issued in
-        // this tile's first group) may remain in flight
-        if (kt_next >= 0) {
-          if (LP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          else if (LP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-          else if (LP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this wave has finished reading tile kt.  Tile kt+1 must have landed: only the pieces of tiles kt+2 .. kt+PD (the last one
+        // issued in this tile's first group) may remain in flight
+        {
+          int younger = nkt - 2 - kt;  // issued tiles behind kt+1
+          if (dbg & 2) younger = 0;
+          wait_tiles_in_flight(younger < PD - 1 ? younger : PD - 1);
         }
-        if (!(dbg & 8)) __builtin_amdgcn_s_barrier();  // tile kt+1 is visible to every wave; stage st is free for tile kt+3
+        if (!(dbg & 8)) __builtin_amdgcn_s_barrier();  // tile kt+1 is visible to every wave; stage st is free for tile kt+PD+1
         asm volatile("" ::: "memory");
         if (!(dbg & 16)) issue_tile_reads(stage_read, na, nb);
       }
@@ -388,17 +404,11 @@ __global__ __launch_bounds__(256 * KSPL, NI == 1 ? 2 * KSPL : 1) void gemm_dma_k
     if (MODE == 1) cursor_advance();
     if (MODE == 2) state_advance();
   }
-  issue(0, 0);
-  if (nkt > 1) issue(1, 1);
+#pragma unroll
+  for (int q = 0; q < PD; ++q)
+    if (q < nkt) issue(q, q);
   stamp(2);
-  if (nkt > 1) {
-    if (LP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (LP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (LP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  wait_tiles_in_flight((nkt < PD ? nkt : PD) - 1);
   __builtin_amdgcn_s_barrier();  // tile 0 is in LDS
   asm volatile("" ::: "memory");
   stamp(3);

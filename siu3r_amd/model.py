@@ -522,7 +522,7 @@ class _DPTHead:
         out: optional [B, H*W, 83] fp32 destination (a view of the model's [B, V, H*W, 83] raw-Gaussian buffer)."""
         ctx, p = self.ctx, self.p
         path1 = self.trunk(tokens, H, W)
-        x = ops.conv2d(img_nhwc8, ctx.w.conv(f"{p}.dpt.input_merger.0", cin_pad=8), pad=3, out_dtype=ctx.act,
+        x = ops.conv2d(img_nhwc8, ctx.w.conv(f"{p}.dpt.input_merger.0", cin_pad=ops.image_channels(ctx.split)), pad=3, out_dtype=ctx.act,
                        act=ACT_RELU, up_src=path1)
         x = ops.conv2d(x, ctx.w.conv(f"{p}.dpt.head.0"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
         if out is not None:
@@ -591,7 +591,7 @@ class CroCoViTAdapter:
         Z, Hi, Wi, _ = img8.shape
         h, w = Hi // 16, Wi // 16
         sp = "adapter.spm"
-        c = ops.conv2d(img8, ctx.w.conv(sp + ".stem.0", cin_pad=8, bn=sp + ".stem.1"), stride=2, pad=1, out_dtype=ctx.act, act=ACT_RELU)
+        c = ops.conv2d(img8, ctx.w.conv(sp + ".stem.0", cin_pad=ops.image_channels(ctx.split), bn=sp + ".stem.1"), stride=2, pad=1, out_dtype=ctx.act, act=ACT_RELU)
         c = ops.conv2d(c, ctx.w.conv(sp + ".stem.3", bn=sp + ".stem.4"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
         c = ops.conv2d(c, ctx.w.conv(sp + ".stem.6", bn=sp + ".stem.7"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
         c1 = ops.maxpool3x3s2(c)
@@ -647,7 +647,7 @@ class CroCoViTAdapter:
 
     def forward(self, x, all_feat):
         """reference signature (vit_adapter.py:393): returns [f1..f4] as NCHW-shaped (channels-last) tensors."""
-        img8 = ops.pack_image_nhwc8(x.contiguous().float(), self.ctx.act)
+        img8 = ops.pack_image_nhwc(x.contiguous().float(), self.ctx.act, ops.image_channels(self.ctx.split))
         return [f.permute(0, 3, 1, 2) for f in self.forward_nhwc(x, img8, all_feat)]
 
     __call__ = forward
@@ -1121,7 +1121,7 @@ class SIU3RModel:
         ctx = self._ctx
         B, V, _, H, W = st.images.shape
         st.img_bv = st.images.reshape(B * V, 3, H, W).contiguous().float()
-        st.img8 = ops.pack_image_nhwc8(st.img_bv, ctx.act)
+        st.img8 = ops.pack_image_nhwc(st.img_bv, ctx.act, ops.image_channels(ctx.split))
         st.enc = self.backbone.encode_begin(st.images, st.K)
 
     def _s_seg(self, st):
@@ -1142,7 +1142,7 @@ class SIU3RModel:
         first = i in (0, 2)
         toks = [(t[:, 0] if first else self._rest_views(t))[..., :-1, :] for t in st.dec["layers"]]
         if i < 2:
-            img8 = st.img8.view(B, V, H, W, 8)
+            img8 = st.img8.view(B, V, H, W, st.img8.shape[-1])
             img = (img8[:, 0] if first else self._rest_views(img8)).contiguous()
             head = self.gaussian_param_head1 if first else self.gaussian_param_head2
             # the last GEMM writes straight into the [B, V, H*W, 83] buffer the Gaussian adapter reads (no 350 MB concat),

@@ -573,13 +573,24 @@ def add(a: torch.Tensor, b: torch.Tensor):
     return y
 
 
-def pack_image_nhwc8(img: torch.Tensor, out_dtype):
+def pack_image_nhwc(img: torch.Tensor, out_dtype, cpad: int = 8):
+    """[N,3,H,W] fp32 -> [N,H,W,cpad] channel-last, zero-padded channels (cpad 8, or 4 for the fp32 image of the bf16x3 mode)."""
     _gpu(img)
     assert img.dtype == torch.float32 and img.is_contiguous() and img.shape[1] == 3
     N, _, H, W = img.shape
-    out = torch.empty((N, H, W, 8), dtype=out_dtype, device=img.device)
-    check(_lib.lib().siu3r_pack_image_nhwc8(_p(img), _p(out), _dt(out), N, H, W, _stream()))
+    out = torch.empty((N, H, W, cpad), dtype=out_dtype, device=img.device)
+    check(_lib.lib().siu3r_pack_image_nhwc(_p(img), _p(out), _dt(out), N, H, W, cpad, _stream()))
     return out
+
+
+def pack_image_nhwc8(img: torch.Tensor, out_dtype):
+    return pack_image_nhwc(img, out_dtype, 8)
+
+
+def image_channels(split: bool) -> int:
+    """channels per pixel of the packed input image: the bf16x3 convolutions gather 16-byte chunks = 4 fp32, so RGB + one zero
+    channel halves the K extent of the 7x7 / 3x3 stems against the 8 channels the bf16 gather (8 bf16 per chunk) needs"""
+    return 4 if split else 8
 
 
 def resize_bilinear(x: torch.Tensor, size, align_corners: bool, *, addend=None, ch_scale=None, ch_shift=None,

@@ -131,11 +131,12 @@ def test_conv2d_upsample_add_epilogue(mode):
     img = gen(B, 3, H, W, seed=11).abs()
     low = gen(B, C, H // 2, W // 2, seed=12)
     w, b = gen(C, 3, 7, 7, seed=13, scale=0.2), gen(C, seed=14)
-    pw = ops.pack_conv(w.cuda(), b.cuda(), split, cin_pad=8)
     ref = (F.relu(F.conv2d(img.to(adt).float(), w, b, padding=3)) + F.interpolate(low.to(adt).float(), scale_factor=2, mode="bilinear", align_corners=True)).permute(0, 2, 3, 1)
-    out = ops.conv2d(ops.pack_image_nhwc8(img.cuda(), adt), pw, stride=1, pad=3, act=ops.ACT_RELU, out_dtype=torch.float32,
-                     up_src=low.permute(0, 2, 3, 1).contiguous().cuda().to(adt))
-    check(f"conv7x7+up_add[{name}]", out, ref, tol)
+    for cp in ((8, 4) if split else (8,)):  # the bf16x3 mode packs RGB + one zero channel (ops.image_channels)
+        pw = ops.pack_conv(w.cuda(), b.cuda(), split, cin_pad=cp)
+        out = ops.conv2d(ops.pack_image_nhwc(img.cuda(), adt, cp), pw, stride=1, pad=3, act=ops.ACT_RELU, out_dtype=torch.float32,
+                         up_src=low.permute(0, 2, 3, 1).contiguous().cuda().to(adt))
+        check(f"conv7x7+up_add[{name}] cin_pad={cp}", out, ref, tol)
 
 
 @pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
