@@ -36,12 +36,14 @@ def _compile(src):
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
     stamp = obj + ".sha1"
     dg = _digest(path)
-    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dg:
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dg and os.path.exists(obj.replace(".o", ".resources.txt")):
         return obj
-    cmd = ["hipcc", *FLAGS, "-c", path, "-o", obj]
+    cmd = ["hipcc", *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+    with open(obj.replace(".o", ".resources.txt"), "w") as fh:  # per-kernel VGPR / LDS / occupancy remarks (tests/test_abi.py reads them)
+        fh.write(r.stderr)
     with open(stamp, "w") as fh:
         fh.write(dg)
     return obj
@@ -60,6 +62,26 @@ def build(force: bool = False) -> str:
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
     return OUT
+
+
+def kernel_resources(src: str) -> dict:
+    """{mangled kernel name: {"VGPRs": n, "AGPRs": n, "ScratchSize [bytes/lane]": n, "Occupancy [waves/SIMD]": n, "LDS Size [bytes/block]": n, ...}}
+    from the compiler's resource remarks of one source file (written by the last compile of that file)."""
+    import re
+
+    path = os.path.join(OBJ, src.replace(".hip", ".resources.txt"))
+    if not os.path.exists(path):
+        build()
+    out, cur = {}, None
+    for line in open(path):
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z][^:]*): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    return out
 
 
 if __name__ == "__main__":

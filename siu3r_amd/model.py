@@ -1012,6 +1012,11 @@ class SIU3RModel:
                 seg_out[k_] = seg_out[k_].clone()
         results = self.processor.post_process_panoptic_segmentation(
             seg_out, threshold=self.seg_threshold, target_sizes=[(H, W)] * B, label_ids_to_fuse=self.label_ids_to_fuse)
+        if not eager:
+            # the channel-last logits / mask features / memory levels live in the graphs' private memory, which the next replay
+            # overwrites: they served the post-process above and do not leave with the result
+            for k_ in ("_masks_channel_last", "_mask_features", "_ms"):
+                seg_out.pop(k_, None)
         gaussians, masks, infos, qcl, qscores = pp.post_process_gaussians(gaussians, results, B, V, H, W, enable_query_class_logit_lift)
         if return_intermediates:
             _, _, decs = self.backbone._assemble(st.enc, st.dec)

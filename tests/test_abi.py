@@ -71,3 +71,27 @@ def test_rows_layout_host_logic():
     assert _rows_layout(x[:, :-1]) == (2, 8, 16, 144)
     assert _rows_layout(torch.zeros(3, 4, 5, 8)[:, :, :, :]) == (1, 60, 8, 0)
     assert _rows_layout(torch.zeros(2, 2, 9, 16)[:, 0]) == (2, 9, 16, 288)
+
+
+def test_gemm_kernels_keep_two_workgroups_per_cu():
+    """The 128 x 64 LDS-DMA GEMM kernels (eight waves, KSPL = 2) are tuned for TWO workgroups per CU: that needs <= 128 VGPRs (4 waves
+    per SIMD), no scratch, and two 72 KiB rings inside the 160 KiB LDS.  An epilogue edit that pushes a variant over the line halves
+    its occupancy silently (seen this round: 110 -> 152 VGPRs cost 25 % of the step), so the compiler's own resource remarks are
+    checked at build time, without a GPU."""
+    from siu3r_amd import build as B
+
+    B.build()
+    res = B.kernel_resources("gemm_dma.hip")
+    import re
+
+    checked = 0
+    for name, r in res.items():
+        m = re.search(r"gemm_dma_kernelILi(\d)ELi(\d)ELb(\d)ELi(\d)ELb(\d)E", name)
+        x = re.search(r"gemm_dma_x3_kernelILi(\d)ELb(\d)ELi(\d)ELb(\d)E", name)
+        if m and m.group(1) == "1" and m.group(4) == "2" or x and x.group(3) == "2":
+            checked += 1
+            assert r["VGPRs"] + r.get("AGPRs", 0) <= 128, (name, r)
+            assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0, (name, r)
+            assert r["Occupancy [waves/SIMD]"] >= 4, (name, r)
+            assert 2 * r["LDS Size [bytes/block]"] <= 160 * 1024, (name, r)
+    assert checked >= 10, sorted(res)
