@@ -135,9 +135,11 @@ typedef struct {
   const uint8_t* mask;
   int32_t split3;
   int64_t mask_ld;        /* bytes per mask row (>= Nk, multiple of 64; padding bytes are ignored) */
-  float* ws;            /* split-KV workspace, fp32 [B, H, splits, 128, D + 4] (partial O, running max, partial sum, 2 pad); NULL = no split */
-  int32_t splits;       /* > 1: the keys are cut into `splits` ranges of whole 64-key tiles, one workgroup each, combined by a second
-                           kernel.  Only for Nq <= 128 on the bf16 fast path (Mask2Former's 100 queries against 512..8192 keys) */
+  float* ws;            /* split-KV workspace, fp32 [B, H, splits, ceil(Nq/128)*128, D + 4] (partial O, running max, partial sum, 2 pad);
+                           NULL = no split */
+  int32_t splits;       /* > 1: the keys are cut into `splits` ranges of whole 64-key tiles, one workgroup per (query tile, range),
+                           combined by a second kernel.  Fast paths only (bf16, or fp32 with split3; no RoPE-on-load): few query tiles
+                           against many keys (Mask2Former's 100 queries x 512..8192 keys) */
 } siu3r_attn_params;
 int siu3r_attention(const siu3r_attn_params* p, void* stream);
 

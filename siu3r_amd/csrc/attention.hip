@@ -369,11 +369,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
 //     only on a ragged last tile; the O rescale is skipped while no lane's running maximum grows;
 //   * P is packed with v_cvt_pk_bf16_f32; the cross-half maximum / sum use v_permlane32_swap.
 // Per 64-key tile and wave: 16 MFMAs (512 cycles) against ~32 v_exp_f32 (quarter rate, 512 cycles) + ~110 VALU.
-template <int D, int MASK, int SPLITKV>
+// X3 = bf16x3 mode on the same structure: q / k / v / out are fp32; K and V tiles are split into hi + lo bf16 planes when they are
+// stored to LDS (two plane pairs per stage), Q and P are split in registers, and every product is three MFMAs (lo*hi + hi*lo + hi*hi).
+template <int D, int MASK, int SPLITKV, int X3 = 0>
 __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params p) {
   constexpr int K_BYTES = KT * D * 2;
   constexpr int V_BYTES = KT * D * 2;
-  constexpr int STAGE = K_BYTES + V_BYTES;
+  constexpr int PLANE = K_BYTES + V_BYTES;          // [K | V] of one bf16 plane
+  constexpr int STAGE = (X3 ? 2 : 1) * PLANE;        // X3: [K hi | V hi | K lo | V lo]
   constexpr int CH = D / 32;  // 16-byte chunks per thread per tile and tensor
   constexpr int KS = D / 16;
   constexpr int DT = D / 32;
@@ -385,14 +388,27 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
-  // SPLITKV: one 128-query tile (Nq <= 128); blockIdx.x is the key-range index instead
-  const int q_row = (SPLITKV ? 0 : blockIdx.x * 128) + wave * 32 + l31;
+  // SPLITKV: blockIdx.x = query tile * splits + key-range index
+  const int q_tile = SPLITKV ? (int)blockIdx.x / p.splits : (int)blockIdx.x;
+  const int k_split = SPLITKV ? (int)blockIdx.x - q_tile * p.splits : 0;
+  const int q_row = q_tile * 128 + wave * 32 + l31;
   const bool q_ok = q_row < p.Nq;
   const float sl2 = p.scale * 1.4426950408889634f;
 
-  // Q fragments (B operand: lane = query, 8 consecutive d per k-substep), raw bf16
-  bf16x8 qf[KS];
-  {
+  // Q fragments (B operand: lane = query, 8 consecutive d per k-substep), raw bf16 (X3: fp32, split once)
+  bf16x8 qf[KS], qfl[X3 ? KS : 1];
+  if constexpr (X3) {
+    const float* qp = (const float*)p.q + (int64_t)b * p.q_sb + (int64_t)(q_ok ? q_row : p.Nq - 1) * p.q_sn + (int64_t)h * p.q_sh;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 a = *(const float4*)(qp + ks * 16 + 8 * lh), c = *(const float4*)(qp + ks * 16 + 8 * lh + 4);
+      const float f[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+      uint4 hi, lo;
+      split_bf16x8(f, hi, lo);
+      qf[ks] = as_bf16x8(hi);
+      qfl[ks] = as_bf16x8(lo);
+    }
+  } else {
     const u16* qp = (const u16*)p.q + (int64_t)b * p.q_sb + (int64_t)(q_ok ? q_row : p.Nq - 1) * p.q_sn + (int64_t)h * p.q_sh;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -403,19 +419,35 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
   // staging: thread -> (key = t>>2, chunks ld_c0 + 2c)
   const int ld_key = t >> 2;
   const int ld_c0 = (D == 64) ? ((t & 1) + 4 * ((t >> 1) & 1)) : (t & 3);
-  struct KVRegs { u32x4v kb[CH], vb[CH]; };
-  const u16* kbase = (const u16*)p.k + (int64_t)b * p.k_sb + (int64_t)h * p.k_sh;
-  const u16* vbase = (const u16*)p.v + (int64_t)b * p.v_sb + (int64_t)h * p.v_sh;
+  struct KVRegs { u32x4v kb[X3 ? 2 * CH : CH], vb[X3 ? 2 * CH : CH]; };
+  constexpr int ESZ = X3 ? 4 : 2;
+  const unsigned char* kbase = (const unsigned char*)p.k + ((int64_t)b * p.k_sb + (int64_t)h * p.k_sh) * ESZ;
+  const unsigned char* vbase = (const unsigned char*)p.v + ((int64_t)b * p.v_sb + (int64_t)h * p.v_sh) * ESZ;
   auto load_tile = [&](int kt, KVRegs& rg) {
     int key = kt * KT + ld_key;
     if (key > p.Nk - 1) key = p.Nk - 1;  // clamped: finite garbage, its scores are masked and its P is 0
-    const u16* kp = kbase + (int64_t)key * p.k_sn;
-    const u16* vp = vbase + (int64_t)key * p.v_sn;
+    const unsigned char* kp = kbase + (int64_t)key * p.k_sn * ESZ;
+    const unsigned char* vp = vbase + (int64_t)key * p.v_sn * ESZ;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      rg.kb[c] = *(const u32x4v*)(kp + (ld_c0 + 2 * c) * 8);
-      rg.vb[c] = *(const u32x4v*)(vp + (ld_c0 + 2 * c) * 8);
+      const int ch = ld_c0 + 2 * c;  // 8-element chunk
+      if constexpr (X3) {
+        rg.kb[2 * c] = *(const u32x4v*)(kp + ch * 32);
+        rg.kb[2 * c + 1] = *(const u32x4v*)(kp + ch * 32 + 16);
+        rg.vb[2 * c] = *(const u32x4v*)(vp + ch * 32);
+        rg.vb[2 * c + 1] = *(const u32x4v*)(vp + ch * 32 + 16);
+      } else {
+        rg.kb[c] = *(const u32x4v*)(kp + ch * 16);
+        rg.vb[c] = *(const u32x4v*)(vp + ch * 16);
+      }
     }
+  };
+  auto split_chunk = [&](const u32x4v& a, const u32x4v& c, uint4& hi, uint4& lo) {
+    // (whole-vector casts: element-wise __builtin_bit_cast(float, a[i]) made hipcc treat all four elements as a[0])
+    typedef __attribute__((ext_vector_type(4))) float f32x4v;
+    const f32x4v fa = __builtin_bit_cast(f32x4v, a), fc = __builtin_bit_cast(f32x4v, c);
+    const float f[8] = {fa[0], fa[1], fa[2], fa[3], fc[0], fc[1], fc[2], fc[3]};
+    split_bf16x8(f, hi, lo);
   };
   auto store_tile = [&](int stage, const KVRegs& rg) {
     unsigned char* sK = smem + stage * STAGE;
@@ -423,9 +455,19 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int ch = ld_c0 + 2 * c;
-      *(u32x4v*)(sK + k_off<D>(ld_key, ch)) = rg.kb[c];
       const int pc = (D == 64) ? ((((ch >> 2) ^ ((ld_key >> 1) & 1)) << 2) | (ch & 3)) : ch;
-      *(u32x4v*)(sV + ld_key * RS + pc * 16) = rg.vb[c];
+      if constexpr (X3) {
+        uint4 hi, lo;
+        split_chunk(rg.kb[2 * c], rg.kb[2 * c + 1], hi, lo);
+        *(uint4*)(sK + k_off<D>(ld_key, ch)) = hi;
+        *(uint4*)(sK + PLANE + k_off<D>(ld_key, ch)) = lo;
+        split_chunk(rg.vb[2 * c], rg.vb[2 * c + 1], hi, lo);
+        *(uint4*)(sV + ld_key * RS + pc * 16) = hi;
+        *(uint4*)(sV + PLANE + ld_key * RS + pc * 16) = lo;
+      } else {
+        *(u32x4v*)(sK + k_off<D>(ld_key, ch)) = rg.kb[c];
+        *(u32x4v*)(sV + ld_key * RS + pc * 16) = rg.vb[c];
+      }
     }
   };
 
@@ -440,7 +482,7 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
   int kt0 = 0, kt1 = nkt;  // this workgroup's range of 64-key tiles
   if (SPLITKV) {
     const int per = (nkt + p.splits - 1) / p.splits;
-    kt0 = blockIdx.x * per;
+    kt0 = k_split * per;
     kt1 = min(nkt, kt0 + per);
   }
 
@@ -479,6 +521,11 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 kf = as_bf16x8(*(const uint4*)(sK + k_off<D>(kb * 32 + l31, ks * 2 + lh)));
+        if constexpr (X3) {
+          const bf16x8 kfl = as_bf16x8(*(const uint4*)(sK + PLANE + k_off<D>(kb * 32 + l31, ks * 2 + lh)));
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl, qf[ks], sacc[kb], 0, 0, 0);
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfl[ks], sacc[kb], 0, 0, 0);
+        }
         sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
       }
     }
@@ -536,7 +583,15 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
         float pf[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = sacc[kb][8 * sb + j];
-        const bf16x8 ph = as_bf16x8(pack_bf16x8(pf));
+        bf16x8 ph, plo;
+        if constexpr (X3) {
+          uint4 hi, lo;
+          split_bf16x8(pf, hi, lo);
+          ph = as_bf16x8(hi);
+          plo = as_bf16x8(lo);
+        } else {
+          ph = as_bf16x8(pack_bf16x8(pf));
+        }
         const int rbase = (kb * 32 + 16 * sb) * RS + v_lane;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
@@ -546,6 +601,15 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
           const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0);
           const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p1);
           const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+          if constexpr (X3) {
+            auto q0 = (__attribute__((address_space(3))) s16x4*)(sV + PLANE + rbase + ho);
+            auto q1 = (__attribute__((address_space(3))) s16x4*)(sV + PLANE + rbase + 8 * RS + ho);
+            const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(q0);
+            const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(q1);
+            const bf16x8 vfl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl, ph, oacc[dt], 0, 0, 0);
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, plo, oacc[dt], 0, 0, 0);
+          }
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, ph, oacc[dt], 0, 0, 0);
         }
       }
@@ -584,7 +648,8 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
   if (SPLITKV) {
     // partial result of this key range: un-normalised O (relative to m_run), m_run and l; an empty range contributes
     // (NEG_BIG, 0, 0), which the combine step weights by exp2(-inf) = 0
-    float* w = p.ws + ((((int64_t)b * p.H + h) * p.splits + blockIdx.x) * 128 + (wave * 32 + l31)) * (D + 4);
+    const int64_t nqp = (int64_t)((p.Nq + 127) / 128) * 128;
+    float* w = p.ws + ((((int64_t)b * p.H + h) * p.splits + k_split) * nqp + q_row) * (D + 4);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -597,6 +662,17 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
     return;
   }
   const float inv = 1.f / l_tot;
+  if constexpr (X3) {
+    if (q_ok) {
+      float* op = (float*)p.out + ((int64_t)b * p.Nq + q_row) * ((int64_t)p.H * D) + (int64_t)h * D;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(float4*)(op + dt * 32 + 8 * g + 4 * lh) = make_float4(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+    }
+    return;
+  }
   if (q_ok) {
     u16* op = (u16*)p.out + ((int64_t)b * p.Nq + q_row) * ((int64_t)p.H * D) + (int64_t)h * D;
 #pragma unroll
@@ -622,12 +698,13 @@ __global__ void attn_combine_kernel(const siu3r_attn_params p) {
   const int64_t bh = r / p.Nq;
   if (bh >= (int64_t)p.B * p.H) return;
   const float sl2 = p.scale * 1.4426950408889634f;
-  const float* w = p.ws + (bh * p.splits * 128 + q) * (D + 4);
+  const int64_t nqp = (int64_t)((p.Nq + 127) / 128) * 128;
+  const float* w = p.ws + (bh * p.splits * nqp + q) * (D + 4);
   float M = NEG_BIG;
-  for (int s_ = 0; s_ < p.splits; ++s_) M = fmaxf(M, w[(int64_t)s_ * 128 * (D + 4) + D]);
+  for (int s_ = 0; s_ < p.splits; ++s_) M = fmaxf(M, w[(int64_t)s_ * nqp * (D + 4) + D]);
   float L = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
   for (int s_ = 0; s_ < p.splits; ++s_) {
-    const float* ws = w + (int64_t)s_ * 128 * (D + 4);
+    const float* ws = w + (int64_t)s_ * nqp * (D + 4);
     const float wt = __builtin_amdgcn_exp2f((ws[D] - M) * sl2);
     const float4 o = *(const float4*)(ws + 4 * d4);
     L += wt * ws[D + 1];
@@ -635,6 +712,10 @@ __global__ void attn_combine_kernel(const siu3r_attn_params p) {
   }
   const float inv = 1.f / L;
   const int b = (int)(bh / p.H), h = (int)(bh % p.H);
+  if (p.dtype == SIU3R_F32) {
+    *(float4*)((float*)p.out + ((int64_t)b * p.Nq + q) * ((int64_t)p.H * D) + (int64_t)h * D + 4 * d4) = make_float4(o0 * inv, o1 * inv, o2 * inv, o3 * inv);
+    return;
+  }
   u16* op = (u16*)p.out + ((int64_t)b * p.Nq + q) * ((int64_t)p.H * D) + (int64_t)h * D + 4 * d4;
   uint2 pk;
   pk.x = pack_bf16x2(o0 * inv, o1 * inv);
@@ -642,23 +723,24 @@ __global__ void attn_combine_kernel(const siu3r_attn_params p) {
   *(uint2*)op = pk;
 }
 
-template <int D>
+template <int D, int X3>
 int launch_fast(const siu3r_attn_params& p, hipStream_t s) {
   dim3 block(256);
-  if (p.splits > 1 && p.ws && p.Nq <= 128) {
-    dim3 grid(p.splits, p.H, p.B);
+  const int qtiles = (p.Nq + 127) / 128;
+  if (p.splits > 1 && p.ws) {
+    dim3 grid(qtiles * p.splits, p.H, p.B);
     if (p.mask)
-      hipLaunchKernelGGL((attn_fast_kernel<D, 1, 1>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((attn_fast_kernel<D, 1, 1, X3>), grid, block, 0, s, p);
     else
-      hipLaunchKernelGGL((attn_fast_kernel<D, 0, 1>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((attn_fast_kernel<D, 0, 1, X3>), grid, block, 0, s, p);
     const int64_t n = (int64_t)p.B * p.H * p.Nq * (D / 4);
     hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((unsigned)((n + 255) / 256)), block, 0, s, p);
   } else {
-    dim3 grid((p.Nq + 127) / 128, p.H, p.B);
+    dim3 grid(qtiles, p.H, p.B);
     if (p.mask)
-      hipLaunchKernelGGL((attn_fast_kernel<D, 1, 0>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((attn_fast_kernel<D, 1, 0, X3>), grid, block, 0, s, p);
     else
-      hipLaunchKernelGGL((attn_fast_kernel<D, 0, 0>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((attn_fast_kernel<D, 0, 0, X3>), grid, block, 0, s, p);
   }
   SIU3R_LAUNCH_CHECK("siu3r_attention(fast)");
   return 0;
@@ -694,7 +776,8 @@ extern "C" int siu3r_attention(const siu3r_attn_params* pp, void* stream) {
               "siu3r_attention: q/k/v strides must keep 16-byte alignment");
   hipStream_t s = (hipStream_t)stream;
   static const bool no_fast = getenv("SIU3R_ATTN_NO_FAST") != nullptr;  // A/B switch
-  if (p.dtype == SIU3R_BF16 && !p.split3 && !p.rope_cos && !no_fast) return p.D == 64 ? launch_fast<64>(p, s) : launch_fast<32>(p, s);
+  if (p.dtype == SIU3R_BF16 && !p.split3 && !p.rope_cos && !no_fast) return p.D == 64 ? launch_fast<64, 0>(p, s) : launch_fast<32, 0>(p, s);
+  if (p.dtype == SIU3R_F32 && p.split3 && !p.rope_cos && !no_fast) return p.D == 64 ? launch_fast<64, 1>(p, s) : launch_fast<32, 1>(p, s);
   if (p.D == 64) {
     if (p.split3) return launch<64, 1, 1>(p, s);
     if (p.dtype == SIU3R_F32) return launch<64, 1, 0>(p, s);

@@ -497,6 +497,9 @@ def patch_embed(img: torch.Tensor, pw: PackedWeight, out: torch.Tensor, stats_ou
 # ------------------------------------------------------------------------------------------------
 # attention / norms / element-wise
 # ------------------------------------------------------------------------------------------------
+_ATTN_SPLITKV = __import__("os").environ.get("SIU3R_NO_ATTN_SPLITKV", "0") != "1"
+
+
 def attention(q, k, v, *, heads: int, head_dim: int, scale: float, rope=None, qpos=None, kpos=None,
               mask: Optional[torch.Tensor] = None, split3=False):
     """q [B,Nq,H,D] / k,v [B,Nk,H,D] strided views (D contiguous) -> out [B,Nq,H*D]."""
@@ -522,12 +525,20 @@ def attention(q, k, v, *, heads: int, head_dim: int, scale: float, rope=None, qp
         p.mask, p.mask_ld = _p(mask), mask.shape[2]
     p.split3 = int(split3)
     ws = None
-    if q.dtype == torch.bfloat16 and not split3 and rope is None and Nq <= 128 and Nk >= 1024:
-        # few queries against many keys (Mask2Former: 100 queries x 512..8192 keys): split the keys over workgroups
+    fast = rope is None and ((q.dtype == torch.bfloat16 and not split3) or (q.dtype == torch.float32 and split3))
+    if fast and _ATTN_SPLITKV:
         nkt = (Nk + 63) // 64
-        p.splits = min(16, nkt // 4)
-        ws = torch.empty((B, heads, p.splits, 128, head_dim + 4), dtype=torch.float32, device=q.device)
-        p.ws = _p(ws)
+        qt = (Nq + 127) // 128
+        splits = 1
+        if Nq <= 128 and Nk >= 1024:
+            # few queries against many keys (Mask2Former: 100 queries x 512..8192 keys): split the keys over workgroups
+            splits = min(16, nkt // 4)
+        # (splitting the ViT attention of one pair -- 288 workgroups on 512 slots -- into 2-3 key ranges measured no gain: 36 -> 39 us
+        # bf16, 78 -> 76 us bf16x3, the combine pass eats what the extra workgroups win)
+        if splits > 1:
+            p.splits = splits
+            ws = torch.empty((B, heads, splits, qt * 128, head_dim + 4), dtype=torch.float32, device=q.device)
+            p.ws = _p(ws)
     check(_lib.lib().siu3r_attention(C.byref(p), _stream()))
     return out
 

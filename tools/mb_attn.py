@@ -23,3 +23,6 @@ if __name__ == "__main__":
     bench(2, 16, 1025, 1025, 64, torch.float32, True)
     bench(8, 1, 100, 8192, 32, mask=True)
     bench(8, 1, 100, 2048, 32, mask=True)
+    bench(2, 12, 1025, 1025, 64, torch.float32, True)
+    bench(1, 8, 100, 8192, 32, torch.float32, True, mask=True)
+    bench(1, 8, 100, 2048, 32, torch.float32, True, mask=True)
