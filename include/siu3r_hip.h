@@ -7,7 +7,8 @@
  *     TORCH_CHECK behaviour (reference: src/models/croco/curope/curope.cpp:54-59, kernels.cu:91-94).
  *   - all pointers are raw DEVICE pointers unless stated; no entry point allocates, synchronises
  *     or owns memory; kernels are enqueued on `stream` (a hipStream_t passed as void*).
- *   - dtype codes: SIU3R_BF16 = 0, SIU3R_F32 = 1.
+ *   - dtype codes: SIU3R_BF16 = 0, SIU3R_F32 = 1 everywhere; siu3r_rope2d (seam 1) also takes SIU3R_F16 = 2 and SIU3R_F64 = 3,
+ *     the types the reference's kernel dispatches (kernels.cu:101).
  *   - activations are channel-last ("NHWC" / token-major) everywhere.
  *
  * Each group cites the reference interface it replaces.
@@ -21,6 +22,8 @@ extern "C" {
 
 #define SIU3R_BF16 0
 #define SIU3R_F32 1
+#define SIU3R_F16 2
+#define SIU3R_F64 3
 
 const char* siu3r_last_error(void);
 #define SIU3R_ABI_VERSION 3 /* 3: view-batched sort-free rasterizer (project/sort/bin/composite/tile_lists), raster_cam.nt_post_blend */

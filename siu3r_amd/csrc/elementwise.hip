@@ -43,8 +43,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ================================ RoPE2D (seam 1) ================================================
 // One thread per (token, rotation pair); loops over heads re-using cos/sin, like the reference
 // kernel (kernels.cu:17-82): inv_freq = fwd / powf(base, q/Q), angle = pos * inv_freq.
-template <typename T>
-__global__ void rope2d_kernel(T* tokens, const int64_t* pos, int B, int N, int H, int D, int64_t sb, int64_t sn,
+// DT: SIU3R_BF16 / SIU3R_F32 / SIU3R_F16 / SIU3R_F64 -- the reference dispatches float, double and half (kernels.cu:101); the rotation
+// runs in fp32 (double tokens: in double, with the fp32 cos / sin of the reference's __sincosf-free path)
+template <int DT>
+__global__ void rope2d_kernel(void* tokens, const int64_t* pos, int B, int N, int H, int D, int64_t sb, int64_t sn,
                               int64_t sh, float base, float fwd) {
   const int Q = D / 4, half = D / 2;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -57,20 +59,29 @@ __global__ void rope2d_kernel(T* tokens, const int64_t* pos, int B, int N, int H
   const float inv_freq = fwd / powf(base, q / float(Q));
   const float freq = pos[tok * 2 + axis] * inv_freq;
   const float c = cosf(freq), s = sinf(freq);
-  T* tp = tokens + b * sb + n * sn + axis * 2 * Q + q;
+  const int64_t e0 = b * sb + n * sn + axis * 2 * Q + q;
   for (int h = 0; h < H; ++h) {
-    T* p = tp + h * sh;
-    float u, v;
-    if (sizeof(T) == 4) {
-      u = ((float*)p)[0];
-      v = ((float*)p)[Q];
-      ((float*)p)[0] = u * c - v * s;
-      ((float*)p)[Q] = v * c + u * s;
+    const int64_t e = e0 + h * sh;
+    if (DT == SIU3R_F32) {
+      float* p = (float*)tokens + e;
+      const float u = p[0], v = p[Q];
+      p[0] = u * c - v * s;
+      p[Q] = v * c + u * s;
+    } else if (DT == SIU3R_F64) {
+      double* p = (double*)tokens + e;
+      const double u = p[0], v = p[Q];
+      p[0] = u * (double)c - v * (double)s;
+      p[Q] = v * (double)c + u * (double)s;
+    } else if (DT == SIU3R_F16) {
+      _Float16* p = (_Float16*)tokens + e;
+      const float u = (float)p[0], v = (float)p[Q];
+      p[0] = (_Float16)(u * c - v * s);
+      p[Q] = (_Float16)(v * c + u * s);
     } else {
-      u = bf16_bits_to_f32(((u16*)p)[0]);
-      v = bf16_bits_to_f32(((u16*)p)[Q]);
-      ((u16*)p)[0] = f32_to_bf16_bits(u * c - v * s);
-      ((u16*)p)[Q] = f32_to_bf16_bits(v * c + u * s);
+      u16* p = (u16*)tokens + e;
+      const float u = bf16_bits_to_f32(p[0]), v = bf16_bits_to_f32(p[Q]);
+      p[0] = f32_to_bf16_bits(u * c - v * s);
+      p[Q] = f32_to_bf16_bits(v * c + u * s);
     }
   }
 }
@@ -563,16 +574,20 @@ inline dim3 grid1d(int64_t total, int block = 256) { return dim3((unsigned)cdiv6
 extern "C" int siu3r_rope2d(void* tokens, int dtype, int B, int N, int H, int D, int64_t sb, int64_t sn, int64_t sh,
                             const int64_t* positions, float base, float fwd, void* stream) {
   SIU3R_CHECK(D % 4 == 0, "token dim must be multiple of 4");  // kernels.cu:94
-  SIU3R_CHECK(dtype == SIU3R_F32 || dtype == SIU3R_BF16, "rope_2d: unsupported dtype %d", dtype);
+  SIU3R_CHECK(dtype == SIU3R_F32 || dtype == SIU3R_BF16 || dtype == SIU3R_F16 || dtype == SIU3R_F64, "rope_2d: unsupported dtype %d", dtype);
   SIU3R_CHECK(B >= 0 && N >= 0 && H >= 0, "rope_2d: negative size");
   const int64_t total = (int64_t)B * N * (D / 2);
   if (total == 0 || H == 0) return 0;  // empty launch is a no-op, like a 0-block CUDA launch
   SIU3R_CHECK(tokens && positions, "rope_2d: null pointer");
   hipStream_t s = (hipStream_t)stream;
   if (dtype == SIU3R_F32)
-    hipLaunchKernelGGL(rope2d_kernel<float>, grid1d(total), dim3(256), 0, s, (float*)tokens, positions, B, N, H, D, sb, sn, sh, base, fwd);
+    hipLaunchKernelGGL(rope2d_kernel<SIU3R_F32>, grid1d(total), dim3(256), 0, s, tokens, positions, B, N, H, D, sb, sn, sh, base, fwd);
+  else if (dtype == SIU3R_F64)
+    hipLaunchKernelGGL(rope2d_kernel<SIU3R_F64>, grid1d(total), dim3(256), 0, s, tokens, positions, B, N, H, D, sb, sn, sh, base, fwd);
+  else if (dtype == SIU3R_F16)
+    hipLaunchKernelGGL(rope2d_kernel<SIU3R_F16>, grid1d(total), dim3(256), 0, s, tokens, positions, B, N, H, D, sb, sn, sh, base, fwd);
   else
-    hipLaunchKernelGGL(rope2d_kernel<u16>, grid1d(total), dim3(256), 0, s, (u16*)tokens, positions, B, N, H, D, sb, sn, sh, base, fwd);
+    hipLaunchKernelGGL(rope2d_kernel<SIU3R_BF16>, grid1d(total), dim3(256), 0, s, tokens, positions, B, N, H, D, sb, sn, sh, base, fwd);
   SIU3R_LAUNCH_CHECK("siu3r_rope2d");
   return 0;
 }

@@ -734,6 +734,7 @@ def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: flo
         raise RuntimeError("positions are not contiguous")
     if positions.dtype != torch.int64:
         raise RuntimeError("positions must be int64")
-    check(_lib.lib().siu3r_rope2d(_p(tokens), _dt(tokens), B, N, H, D, tokens.stride(0), tokens.stride(1),
+    code = {torch.float16: 2, torch.float64: 3}.get(tokens.dtype)  # the seam also takes the reference's half / double (kernels.cu:101)
+    check(_lib.lib().siu3r_rope2d(_p(tokens), code if code is not None else _dt(tokens), B, N, H, D, tokens.stride(0), tokens.stride(1),
                                   tokens.stride(2), _p(positions), float(base), float(fwd), _stream()))
     return None

@@ -205,6 +205,13 @@ def test_rope2d_seam():
     bf = tok.transpose(1, 2).contiguous().cuda().bfloat16()
     ops.rope_2d(bf, pos.cuda(), 100.0, 1.0)
     check("rope2d bf16", bf.transpose(1, 2), O.rope2d(tok.bfloat16().float(), pos), 8e-3)
+    # the reference's kernel dispatches float, double and half (kernels.cu:101): the seam takes those too
+    hf = tok.transpose(1, 2).contiguous().cuda().half()
+    ops.rope_2d(hf, pos.cuda(), 100.0, 1.0)
+    check("rope2d fp16", hf.transpose(1, 2), O.rope2d(tok.half().float(), pos), 1e-3)
+    db = tok.transpose(1, 2).contiguous().cuda().double()
+    ops.rope_2d(db, pos.cuda(), 100.0, 1.0)
+    check("rope2d fp64", db.transpose(1, 2), ref, 2e-6)
     # error behaviour mirrors TORCH_CHECK -> RuntimeError (curope.cpp:54-59, kernels.cu:91-94)
     with pytest.raises(RuntimeError):
         ops.rope_2d(t[0], pos.cuda(), 100.0, 1.0)
