@@ -42,12 +42,18 @@ def pack_stats(stats: Dict[str, float]) -> torch.Tensor:
     return torch.tensor([float(stats.get(k, 0.0)) for k in STAT_KEYS], dtype=torch.float64)
 
 
+def _collective_device(device):
+    """tensors of a collective live on the GPU for RCCL ("nccl") and on the host for gloo (CPU tests, single-GPU dry runs)"""
+    return device if (device is not None and dist.get_backend() == "nccl") else None
+
+
 def all_gather_stats(vec: torch.Tensor, device=None) -> torch.Tensor:
     """The single collective of the path: [world, len(STAT_KEYS)] fp64 on every rank."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return vec[None].clone()
     world = dist.get_world_size()
-    v = vec.to(device) if device is not None else vec
+    device = _collective_device(device)
+    v = vec.to(device) if device is not None else vec.cpu()
     out = [torch.empty_like(v) for _ in range(world)]
     dist.all_gather(out, v)
     return torch.stack(out).cpu()
@@ -63,7 +69,7 @@ def reduce_stats(gathered: torch.Tensor) -> Dict[str, float]:
 def max_over_ranks(x: float, device=None) -> float:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return x
-    t = torch.tensor([x], dtype=torch.float64, device=device)
+    t = torch.tensor([x], dtype=torch.float64, device=_collective_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
