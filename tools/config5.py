@@ -12,7 +12,21 @@ from siu3r_amd.model import SIU3RMultiViewModel
 
 V, S, W, H = 8, 512, 1920, 1080
 dev = torch.device("cuda", 0)
-model = SIU3RMultiViewModel(OW.make_weights(0), image_size=(S, S), precision="bf16", device=dev)
+prec = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
+model = SIU3RMultiViewModel(OW.make_weights(0), image_size=(S, S), precision=prec, device=dev)
+
+
+def pick_camera(means, tan_x, tan_y, near):
+    """a camera looking down +z at the Gaussian cloud from far enough back that most of it is in the frustum (as tests/test_configs_gpu.py)"""
+    c = means.median(0).values
+    d = (means - c).abs()
+    need = torch.maximum(torch.quantile(d[:, 0], 0.8) / tan_x, torch.quantile(d[:, 1], 0.8) / tan_y)
+    back = float(need + torch.quantile(d[:, 2], 0.8)) + near
+    c2w = torch.eye(4)
+    c2w[:3, 3] = torch.tensor([float(c[0]), float(c[1]), float(c[2]) - back])
+    return c2w
+
+
 g = torch.Generator().manual_seed(5)
 images = torch.rand(1, V, 3, S, S, generator=g).to(dev)
 K = synthetic.default_intrinsics()[None, None].repeat(1, V, 1, 1).to(dev)
@@ -26,13 +40,15 @@ for _ in range(n):
 torch.cuda.synchronize()
 ms_model = (time.perf_counter() - t0) / n * 1e3
 G_ = out[0]
-res = dict(views=V, image_size=[S, S], gaussians=int(G_.means.shape[1]), model_ms_per_forward=ms_model, segments=len(out[3][0]))
+res = dict(views=V, image_size=[S, S], precision=prec, gaussians=int(G_.means.shape[1]), model_ms_per_forward=ms_model, segments=len(out[3][0]))
+means_c = G_.means[0].float().cpu()
 # viewer semantics (A25b): quats wxyz, log-scales, logit-opacities, SH [G,25,3]
 x, y, z, w = G_.rotations[0].unbind(-1)
 splats = dict(means=G_.means[0], quats=torch.stack((w, x, y, z), -1).contiguous(), scales=G_.scales[0].log(), opacities=torch.logit(G_.opacities[0].clamp(1e-6, 1 - 1e-6)),
               sh0=G_.harmonics[0].permute(0, 2, 1)[:, :1].contiguous(), shN=G_.harmonics[0].permute(0, 2, 1)[:, 1:].contiguous())
-c2w = synthetic.target_views(3)[1][None]
-Kp = torch.tensor([[0.6 * W, 0, W / 2], [0, 0.6 * W, H / 2], [0, 0, 1]])[None]
+fx = 0.5 * W
+c2w = pick_camera(means_c, (W / 2) / fx, (H / 2) / fx, 0.01)[None]
+Kp = torch.tensor([[fx, 0, W / 2], [0, fx, H / 2], [0, 0, 1]])[None]
 for _ in range(2):
     col, al, info = rasterize_splats(splats, c2w, Kp, W, H, sh_degree=4, radius_clip=0.1)
 torch.cuda.synchronize()
@@ -43,10 +59,13 @@ torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / n * 1e3
 Gv, D = int((info["tiles_touched"][0] > 0).sum()), int(info["tile_pairs"][0])
 b = raster.algorithmic_bytes(res["gaussians"], Gv, D, H * W, channels=3) + res["gaussians"] * 300
-res["viewer_render"] = dict(ms_per_frame=ms, resolution=[W, H], visible=Gv, tile_pairs=D, algorithmic_GBps=b / ms / 1e6, mean_alpha=float(al.mean()))
+res["viewer_render"] = dict(ms_per_frame=ms, resolution=[W, H], visible=Gv, visible_frac=Gv / res["gaussians"], tile_pairs=D, algorithmic_GBps=b / ms / 1e6, mean_alpha=float(al.mean()))
 # K2 semantics (SplattingCUDA.forward: x10 scene scale, black background, colour + depth)
 rend = SplattingCUDA()
-ext, Kt = c2w[None].to(dev), synthetic.default_intrinsics()[None, None].to(dev)
+from siu3r_amd import cuda_splatting as cs
+Kn = torch.tensor([[0.5, 0, 0.5], [0, 0.5 * W / H, 0.5], [0, 0, 1]])
+tan = (0.5 * cs.get_fov(Kn[None])).tan()[0]
+ext, Kt = pick_camera(means_c, float(tan[0]), float(tan[1]), 0.2)[None, None], Kn[None, None]
 def fresh():
     return Gaussians(means=G_.means.clone(), covariances=G_.covariances.clone(), harmonics=G_.harmonics, opacities=G_.opacities)
 rend.forward(fresh(), ext, Kt, (H, W), render_color=True)
