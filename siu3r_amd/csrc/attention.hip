@@ -371,8 +371,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
 // Per 64-key tile and wave: 16 MFMAs (512 cycles) against ~32 v_exp_f32 (quarter rate, 512 cycles) + ~110 VALU.
 // X3 = bf16x3 mode on the same structure: q / k / v / out are fp32; K and V tiles are split into hi + lo bf16 planes when they are
 // stored to LDS (two plane pairs per stage), Q and P are split in registers, and every product is three MFMAs (lo*hi + hi*lo + hi*hi).
-template <int D, int MASK, int SPLITKV, int X3 = 0>
+// KH = 1: a workgroup covers 64 queries; waves 2g and 2g+1 own the SAME 32 queries and each takes one 32-key half of every 64-key tile
+// (its own running maximum / sum / O), merged through LDS at the end.  Twice the workgroups with half the per-tile chain per wave:
+// the ViT attention of one pair has only 288 128-query workgroups for 256 CUs, i.e. one wave per SIMD and nothing to overlap with.
+template <int D, int MASK, int SPLITKV, int X3 = 0, int KH = 0>
 __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params p) {
+  static_assert(!(KH && SPLITKV), "key halves and key ranges are alternatives");
+  constexpr int NKB = KH ? 1 : 2;   // 32-key blocks of a tile handled by one wave
+  constexpr int QT = KH ? 64 : 128;  // queries per workgroup
   constexpr int K_BYTES = KT * D * 2;
   constexpr int V_BYTES = KT * D * 2;
   constexpr int PLANE = K_BYTES + V_BYTES;          // [K | V] of one bf16 plane
@@ -391,7 +397,8 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
   // SPLITKV: blockIdx.x = query tile * splits + key-range index
   const int q_tile = SPLITKV ? (int)blockIdx.x / p.splits : (int)blockIdx.x;
   const int k_split = SPLITKV ? (int)blockIdx.x - q_tile * p.splits : 0;
-  const int q_row = q_tile * 128 + wave * 32 + l31;
+  const int kb0 = KH ? (wave & 1) : 0;  // first 32-key block of this wave
+  const int q_row = q_tile * QT + (KH ? (wave >> 1) : wave) * 32 + l31;
   const bool q_ok = q_row < p.Nq;
   const float sl2 = p.scale * 1.4426950408889634f;
 
@@ -513,45 +520,47 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
   auto process = [&](int kt, int cur, const uint4 (&mk)[4]) {
     const unsigned char* sK = smem + cur * STAGE;
     const unsigned char* sV = sK + K_BYTES;
-    f32x16 sacc[2];
+    f32x16 sacc[NKB];  // sacc[j] = key block kb0 + j
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int j = 0; j < NKB; ++j) {
+      const int kb = kb0 + j;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+      for (int r = 0; r < 16; ++r) sacc[j][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 kf = as_bf16x8(*(const uint4*)(sK + k_off<D>(kb * 32 + l31, ks * 2 + lh)));
         if constexpr (X3) {
           const bf16x8 kfl = as_bf16x8(*(const uint4*)(sK + PLANE + k_off<D>(kb * 32 + l31, ks * 2 + lh)));
-          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl, qf[ks], sacc[kb], 0, 0, 0);
-          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfl[ks], sacc[kb], 0, 0, 0);
+          sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl, qf[ks], sacc[j], 0, 0, 0);
+          sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfl[ks], sacc[j], 0, 0, 0);
         }
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
+        sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[j], 0, 0, 0);
       }
     }
     // lane holds keys key(kb,r) = kt*64 + kb*32 + (r&3) + 8*(r>>2) + 4*lh of query l31
     if (ragged && kt == nkt - 1) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int j = 0; j < NKB; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (kt * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= p.Nk) sacc[kb][r] = NEG_BIG;
+          if (kt * KT + (kb0 + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= p.Nk) sacc[j][r] = NEG_BIG;
     }
     if constexpr (MASK) {
       const uint32_t* w = (const uint32_t*)&mk[0];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int j = 0; j < NKB; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+          const int kb = kb0 + j;
           const uint32_t ws = lh ? w[2 * (kb * 4 + g) + 1] : w[2 * (kb * 4 + g)];
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if ((ws >> (8 * e)) & 0xffu) sacc[kb][4 * g + e] = NEG_BIG;
+            if ((ws >> (8 * e)) & 0xffu) sacc[j][4 * g + e] = NEG_BIG;
         }
     }
-    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+    float mx = fmaxf(sacc[0][0], sacc[NKB - 1][0]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);  // v_max3_f32
+    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[NKB - 1][r]);  // v_max3_f32
     mx = fmaxf(mx, other_half(mx));
     const float m_new = fmaxf(m_run, mx);
     if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {  // wave-uniform: rescale only when some maximum grew
@@ -566,23 +575,24 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
     float psum = 0.f;
     const float nm = -m_run * sl2;  // exp2((s - m) * sl2) as one fma + v_exp_f32 per score; m tracks the RAW maximum
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int j = 0; j < NKB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][r], sl2, nm));
-        sacc[kb][r] = pv;
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[j][r], sl2, nm));
+        sacc[j][r] = pv;
         psum += pv;
       }
     l_run += psum;
 
     // O^T += V^T P^T : B operand = P registers as they are (virtual-k order), A operand = transposed LDS reads
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int jb = 0; jb < NKB; ++jb)
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb) {
+        const int kb = kb0 + jb;
         float pf[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = sacc[kb][8 * sb + j];
+        for (int j = 0; j < 8; ++j) pf[j] = sacc[jb][8 * sb + j];
         bf16x8 ph, plo;
         if constexpr (X3) {
           uint4 hi, lo;
@@ -644,7 +654,37 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
   }
 
   // epilogue: O[q, h*D + d] = O^T[d][q] / l
-  const float l_tot = l_run + other_half(l_run);
+  float l_tot = l_run + other_half(l_run);
+  if constexpr (KH) {
+    // merge the two key halves of a query group: the odd wave parks (m, l, O) in LDS, the even wave folds them into its own
+    lds_barrier();  // every wave is done with the K / V stages
+    float* xs = (float*)smem + (wave >> 1) * (32 * (D + 2));
+    if (wave & 1) {
+      if (lh == 0) {
+        xs[l31 * (D + 2) + D] = m_run;
+        xs[l31 * (D + 2) + D + 1] = l_tot;
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xs[l31 * (D + 2) + dt * 32 + 8 * g + 4 * lh + e] = oacc[dt][4 * g + e];
+    }
+    lds_barrier();
+    if (wave & 1) return;
+    const float m1 = xs[l31 * (D + 2) + D], l1 = xs[l31 * (D + 2) + D + 1];
+    const float M = fmaxf(m_run, m1);
+    const float w0 = __builtin_amdgcn_exp2f((m_run - M) * sl2), w1 = __builtin_amdgcn_exp2f((m1 - M) * sl2);
+    l_tot = l_tot * w0 + l1 * w1;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          oacc[dt][4 * g + e] = oacc[dt][4 * g + e] * w0 + xs[l31 * (D + 2) + dt * 32 + 8 * g + 4 * lh + e] * w1;
+  }
   if (SPLITKV) {
     // partial result of this key range: un-normalised O (relative to m_run), m_run and l; an empty range contributes
     // (NEG_BIG, 0, 0), which the combine step weights by exp2(-inf) = 0
@@ -723,6 +763,9 @@ __global__ void attn_combine_kernel(const siu3r_attn_params p) {
   *(uint2*)op = pk;
 }
 
+// measured (tools/mb_attn.py): bf16 108 workgroups 22.9 -> 18.4 us, 288 workgroups 36.0 -> 39.0 us; bf16x3 288 workgroups 78 -> 70 us
+static const int64_t g_attn_kh_max = getenv("SIU3R_ATTN_KH_MAX") ? atoll(getenv("SIU3R_ATTN_KH_MAX")) : -1;
+
 template <int D, int X3>
 int launch_fast(const siu3r_attn_params& p, hipStream_t s) {
   dim3 block(256);
@@ -735,6 +778,10 @@ int launch_fast(const siu3r_attn_params& p, hipStream_t s) {
       hipLaunchKernelGGL((attn_fast_kernel<D, 0, 1, X3>), grid, block, 0, s, p);
     const int64_t n = (int64_t)p.B * p.H * p.Nq * (D / 4);
     hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((unsigned)((n + 255) / 256)), block, 0, s, p);
+  } else if (!p.mask && p.Nk >= 64 && (int64_t)qtiles * p.H * p.B < (g_attn_kh_max >= 0 ? g_attn_kh_max : (X3 ? 512 : 256))) {
+    // too few 128-query workgroups to give every SIMD two waves: 64-query workgroups whose wave pairs split each key tile
+    dim3 grid((p.Nq + 63) / 64, p.H, p.B);
+    hipLaunchKernelGGL((attn_fast_kernel<D, 0, 0, X3, 1>), grid, block, 0, s, p);
   } else {
     dim3 grid(qtiles, p.H, p.B);
     if (p.mask)
