@@ -124,14 +124,16 @@ __global__ __launch_bounds__(256 * KSPL, NI == 1 ? 2 * KSPL : 1) void gemm_dma_k
     const int r = (wave * A_DMA + i) * 8 + prow;
     a_c[i] = pchunk ^ ((r >> 1) & 7);
     int m = tile_m * BM + r;
-    // rows beyond M are never stored: their pieces are out-of-range fetches (zeros, no memory traffic) -- M = 2 x 1025 tokens
-    // leaves a 2-row seventeenth tile row whose workgroups then move a third of the bytes
+    // rows beyond M are never stored: they fetch row M - 1 again (one cached line per K tile).  Out-of-range offsets ("zeros, no
+    // traffic") looked cheaper and are not: a piece whose lanes are out of range lands far later than a real one, and M = 2 x 1025
+    // tokens leaves a 2-row seventeenth tile row in every encoder GEMM (bf16x3 2050 x 1024 x 4096: 249 us with out-of-range rows,
+    // 107 us clamped; bf16 2050 x 3072 x 1024: 31.9 -> 27.7 us)
     const bool row_ok = m < M;
     if (!row_ok) m = M - 1;
     a_voff[i] = a_mask[i] = 0;
     a_iy0[i] = a_ix0[i] = 0;
     if (MODE == 0) {
-      a_voff[i] = row_ok ? (unsigned)(((int64_t)m * p.lda + a_c[i] * 8) * 2) : OOB;
+      a_voff[i] = (unsigned)(((int64_t)m * p.lda + a_c[i] * 8) * 2);
     } else {
       const int ohw = p.oh * p.ow;
       const int b = m / ohw, rr = m - b * ohw;
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(256 * KSPL, 2 * KSPL) void gemm_dma_x3_kernel(const
     a_voff[i] = a_mask[i] = 0;
     a_iy0[i] = a_ix0[i] = 0;
     if (MODE == 0) {
-      a_voff[i] = row_ok ? (unsigned)(((int64_t)m * p.lda) * 4 + a_c[i] * 16) : OOB;
+      a_voff[i] = (unsigned)(((int64_t)m * p.lda) * 4 + a_c[i] * 16);  // (row clamped to M - 1, see the bf16 kernel)
     } else {
       const int ohw = p.oh * p.ow;
       const int b = m / ohw, rr = m - b * ohw;

@@ -543,6 +543,42 @@ def test_gemm_layernorm_fold(mode, C):
 
 
 @pytest.mark.parametrize("mode", [MODES[0], MODES[2]], ids=["bf16", "bf16x3"])
+@pytest.mark.parametrize("rows", [1, 2, 4, 5], ids=["stub1", "stub2", "stub4", "stub5"])
+def test_gemm_stub_row_tiles(mode, rows):
+    """M = k * 128 + r with a few valid rows in the last row tile (the 2 x 1025 token layout: r = 2, one decoder side: r = 1; rows beyond M are
+    out-of-range fetches) through every epilogue feature such a tile can meet: bias + GELU + residual, folded LayerNorm with row statistics
+    out, batched launch, split-K (few tiles, long K)."""
+    ops = _ops()
+    name, adt, split, tol = mode
+    M, N, K = 256 + rows, 200, 1024
+    a, w, b, r = gen(M, K, seed=71), gen(N, K, seed=72, scale=0.1), gen(N, seed=73), gen(M, N, seed=74)
+    pw = ops.pack_linear(w.cuda(), b.cuda(), split)
+    out = ops.linear(a.cuda().to(adt), pw, out_dtype=torch.float32, act=ops.ACT_GELU, residual=r.cuda())
+    check(f"stub[{name}] r={rows} gelu+residual", out, F.gelu(a.to(adt).float() @ w.t() + b) + r, tol)
+    # long K and few tiles -> split-K slices, each with its own FMA-path partial
+    M2, N2, K2 = 128 + rows, 128, 4096
+    a2, w2 = gen(M2, K2, seed=75), gen(N2, K2, seed=76, scale=0.05)
+    out2 = ops.linear(a2.cuda().to(adt), ops.pack_linear(w2.cuda(), None, split), out_dtype=torch.float32)
+    check(f"stub[{name}] r={rows} split-K", out2, a2.to(adt).float() @ w2.t(), tol)
+    # batched [Z, 128 + rows, C] tokens: producer with statistics out, consumer with the folded LayerNorm
+    Z, Nt, C = 2, 128 + rows, 192
+    x0 = gen(Z, Nt, 96, seed=77)
+    wp, bp = gen(C, 96, seed=78, scale=0.5), gen(C, seed=79) + 2.0
+    x = torch.empty(Z, Nt, C, device="cuda")
+    xb = torch.empty(Z, Nt, C, device="cuda", dtype=torch.bfloat16)
+    st = ops.RowStats(x)
+    ops.linear(x0.cuda().to(adt), ops.pack_linear(wp.cuda(), bp.cuda(), split), out=x, stats_out=st, aux_out=xb)
+    check(f"stub[{name}] r={rows} producer", x, x0.to(adt).float() @ wp.t() + bp, tol)
+    gamma, beta = 1.0 + 0.3 * gen(C, seed=80), gen(C, seed=81)
+    w3, b3 = gen(136, C, seed=82, scale=0.2), gen(136, seed=83)
+    pw3 = ops.pack_linear_ln(w3.cuda(), b3.cuda(), gamma.cuda(), beta.cuda(), split)
+    pw3.meta["ln_eps"] = 1e-6
+    ref = F.layer_norm(x.cpu(), (C,), gamma, beta, 1e-6).to(adt).float() @ w3.t() + b3
+    out3 = ops.linear(x if split else xb, pw3, out_dtype=torch.float32, ln=st)
+    check(f"stub[{name}] r={rows} folded LayerNorm", out3, ref, max(tol, 2e-2 if not split else 0))
+
+
+@pytest.mark.parametrize("mode", [MODES[0], MODES[2]], ids=["bf16", "bf16x3"])
 def test_gemm_grouped_two_sides(mode):
     """Two weight sets in one launch (blockIdx.z = b * 2 + side), incl. the flipped read (side s multiplies the OTHER side's rows:
     the cross-attention memory of a decoder block), folded LayerNorm statistics following the flip, RoPE on the output."""
