@@ -79,6 +79,19 @@ def default_pair_capacity(G: int) -> int:
     return int(min(max(8 * G, 1 << 20), (1 << 31) - 1024))
 
 
+# Capacities that a scene of a given size needed before: a caller that renders many frames of similar scenes (an evaluation loop) pays
+# the detect-and-repeat of an overflowing bound once, not on every call.  key: (kind, G, V, width, height) -> capacity
+_CAPACITY_HINTS: Dict[tuple, int] = {}
+
+
+def _hinted(kind: str, G: int, V: int, W: int, H: int, default: int) -> int:
+    return max(default, _CAPACITY_HINTS.get((kind, G, V, W, H), 0))
+
+
+def _remember(kind: str, G: int, V: int, W: int, H: int, needed: int):
+    _CAPACITY_HINTS[(kind, G, V, W, H)] = int(min(needed + needed // 4 + 1024, (1 << 31) - 1024))
+
+
 class RasterOverflow(RuntimeError):
     pass
 
@@ -106,7 +119,9 @@ class _State(dict):
         if not dict.__contains__(self, "ids"):
             V, T = dict.__getitem__(self, "V"), dict.__getitem__(self, "T")
             dev = dict.__getitem__(self, "stats").device
+            hint_key = ("pairs", dict.__getitem__(self, "G"), V, dict.__getitem__(self, "W"), dict.__getitem__(self, "H"))
             cap_d = dict.__getitem__(self, "cap_d_hint") or max(1, max(self.totals(1)))
+            cap_d = max(cap_d, _CAPACITY_HINTS.get(hint_key, 0))
             while True:
                 tcount = torch.empty((V, T), dtype=torch.int32, device=dev)
                 tstart = torch.empty((V, T + 2), dtype=torch.int32, device=dev)
@@ -120,6 +135,7 @@ class _State(dict):
                 if d_max <= cap_d:
                     break
                 cap_d = d_max  # the bound was too small: repeat with the exact pair count
+                _remember(*hint_key, d_max)
             dict.__setitem__(self, "cap_d", cap_d)
             dict.__setitem__(self, "tile_start_all", tstart)
             dict.__setitem__(self, "ids_all", ids)
@@ -161,8 +177,8 @@ def _project_sort_bin(cams: Sequence[RasterCam], means, cov, opac, colors, chann
     geo = geometry(cams[0].width, cams[0].height, G)
     f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
-    cap_e = int(entry_capacity) if entry_capacity else default_entry_capacity(G)
-    st = _State(V=V, G=G, T=geo["T"], geo=geo, cams=arr, cams_dev=torch.empty((V * geo["cam_bytes"],), dtype=torch.uint8, device=dev),
+    cap_e = int(entry_capacity) if entry_capacity else _hinted("entries", G, V, cams[0].width, cams[0].height, default_entry_capacity(G))
+    st = _State(V=V, G=G, W=cams[0].width, H=cams[0].height, T=geo["T"], geo=geo, cams=arr, cams_dev=torch.empty((V * geo["cam_bytes"],), dtype=torch.uint8, device=dev),
                 rec=f(V, G, 12), radii=i32(V, G, 2), rect=i32(V, G, 4), tiles_touched_all=i32(V, G), keys=i32(V, G), keys_b=i32(V, G), sorted_ids=i32(V, G), ids_b=i32(V, G),
                 stats=torch.empty((V, 4), dtype=torch.int64, device=dev), defer=not check_overflow, cap_d_hint=None)
     st["tiles_touched"] = st["tiles_touched_all"][0]
@@ -191,6 +207,7 @@ def _with_retry(run, entry_capacity, check_overflow):
     st = out["state"]
     e_max = max(st.totals(2))
     if e_max > st["cap_e"]:
+        _remember("entries", st["G"], st["V"], st["W"], st["H"], e_max)
         out = run(e_max)
         out["state"].verify()
     return out
