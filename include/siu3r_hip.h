@@ -183,7 +183,7 @@ int siu3r_gaussian_adapter(const void* raw, int raw_dtype, float* opacities, flo
                            float* harmonics, float* covariances, int64_t n, void* stream);
 /* Mask2Former attention mask (video_seg_decoder.py:1461-1478 + 1306-1308): mask logits
  * [B,T,IH,IW,Q] (channel-last) -> uint8 [B,Q,out_ld] (first T*OH*OW bytes of each row), 1 = blocked; rows fully
- * blocked are cleared. */
+ * blocked are cleared.  row_counts_ws: B*Q int32 of scratch (zeroed by the call; holds a "row has an open key" flag). */
 int siu3r_m2f_attn_mask(const float* mask_logits, uint8_t* out, int32_t* row_counts_ws, int B, int T, int IH,
                         int IW, int OH, int OW, int Q, int64_t out_ld, void* stream);
 

@@ -534,7 +534,9 @@ __global__ void m2f_mask_kernel(const float* ml, uint8_t* out, int32_t* row_coun
   const uint8_t blocked = sg < 0.5f ? 1 : 0;
   const int64_t nk = (int64_t)T * OH * OW;
   out[((int64_t)b * Q + q) * ld + ((int64_t)t * OH + oy) * OW + ox] = blocked;
-  if (blocked) atomicAdd(&row_counts[b * Q + q], 1);
+  // a row whose keys are ALL blocked is un-blocked afterwards (video_seg_decoder.py:1474-1477): "some key is open" needs no count and
+  // no atomic -- every open key stores the same 1 (one same-address atomic per blocked key was ~2.4 ns each: most of this kernel)
+  if (!blocked) row_counts[b * Q + q] = 1;
 }
 __global__ void zero_i32_kernel(int32_t* p, int64_t n) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -544,7 +546,7 @@ __global__ void m2f_mask_fix_kernel(uint8_t* out, const int32_t* row_counts, int
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * nk) return;
   const int64_t r = idx / nk;
-  if (row_counts[r] == nk) out[r * ld + (idx - r * nk)] = 0;
+  if (row_counts[r] == 0) out[r * ld + (idx - r * nk)] = 0;  // no open key in this row
 }
 
 // ================================ fp32 -> bf16 hi (+lo) planes, K zero-padded ====================
