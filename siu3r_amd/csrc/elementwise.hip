@@ -448,29 +448,36 @@ __global__ void pts3d_kernel(float* xyz, int64_t n) {
 // fully coalesced in both directions (row stride 83 words is odd -> conflict-free LDS access).
 constexpr int GA_ROWS = 128, GA_D = 83, GA_SH = 75;
 __constant__ float c_sh_mask[25];
-__global__ __launch_bounds__(128) void gaussian_adapter_kernel(const void* raw, int raw_dtype, float* opac,
+__global__ __launch_bounds__(256) void gaussian_adapter_kernel(const void* raw, int raw_dtype, float* opac,
                                                                float* scales, float* rots, float* sh, float* cov,
                                                                int64_t n) {
   __shared__ float s[GA_ROWS * GA_D];
+  __shared__ float so[GA_ROWS * 17];  // per row: 3 scales, 4 rotations, 9 covariance entries (stride 17: conflict-free), copied out coalesced
   const int64_t g0 = (int64_t)blockIdx.x * GA_ROWS;
   const int rows = (int)((n - g0) < GA_ROWS ? (n - g0) : GA_ROWS);
-  for (int i = threadIdx.x; i < rows * GA_D; i += GA_ROWS) s[i] = load_as_f32(raw, raw_dtype, g0 * GA_D + i);
+  // 256 threads move the rows (16 bytes per lane on full fp32 blocks: 128 x 83 floats start 16-byte aligned), 128 of them compute
+  const int nt = blockDim.x;
+  if (raw_dtype == SIU3R_F32 && rows == GA_ROWS) {
+    const float4* src = (const float4*)((const float*)raw + g0 * GA_D);
+    for (int i = threadIdx.x; i < GA_ROWS * GA_D / 4; i += nt) ((float4*)s)[i] = src[i];
+  } else {
+    for (int i = threadIdx.x; i < rows * GA_D; i += nt) s[i] = load_as_f32(raw, raw_dtype, g0 * GA_D + i);
+  }
   __syncthreads();
   const int t = threadIdx.x;
   if (t < rows) {
     const float* r = s + t * GA_D;
-    const int64_t g = g0 + t;
-    opac[g] = 1.f / (1.f + expf(-r[0]));
+    opac[g0 + t] = 1.f / (1.f + expf(-r[0]));
     float sc[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const float x = r[1 + j];
       const float sp = x > 20.f ? x : log1pf(expf(x));
       sc[j] = fminf(0.001f * sp, 0.3f);
-      scales[g * 3 + j] = sc[j];
+      so[t * 17 + j] = sc[j];
     }
     const float qi = r[4], qj = r[5], qk = r[6], qr = r[7];
-    rots[g * 4 + 0] = qi; rots[g * 4 + 1] = qj; rots[g * 4 + 2] = qk; rots[g * 4 + 3] = qr;
+    so[t * 17 + 3] = qi; so[t * 17 + 4] = qj; so[t * 17 + 5] = qk; so[t * 17 + 6] = qr;
     const float nrm = sqrtf(qi * qi + qj * qj + qk * qk + qr * qr) + 1e-8f;
     const float i_ = qi / nrm, j_ = qj / nrm, k_ = qk / nrm, r_ = qr / nrm;
     const float two_s = 2.f / ((i_ * i_ + j_ * j_ + k_ * k_ + r_ * r_) + 1e-8f);
@@ -497,14 +504,30 @@ __global__ __launch_bounds__(128) void gaussian_adapter_kernel(const void* raw, 
         float v = 0.f;
 #pragma unroll
         for (int k2 = 0; k2 < 3; ++k2) v += (M[a * 3 + k2] * sc[k2]) * R[b * 3 + k2];
-        cov[g * 9 + a * 3 + b] = v;
+        so[t * 17 + 7 + a * 3 + b] = v;
       }
   }
   __syncthreads();
+  // (a thread writing its own row's 3 / 4 / 9 floats leaves every store instruction of the wave strided: staged and copied out instead)
+  for (int i = threadIdx.x; i < rows * 3; i += nt) scales[g0 * 3 + i] = so[(i / 3) * 17 + i % 3];
+  for (int i = threadIdx.x; i < rows * 4; i += nt) rots[g0 * 4 + i] = so[(i >> 2) * 17 + 3 + (i & 3)];
+  for (int i = threadIdx.x; i < rows * 9; i += nt) cov[g0 * 9 + i] = so[(i / 9) * 17 + 7 + i % 9];
   // harmonics: [n, 3, 25] = raw[:, 8:83] * mask[d_sh]
-  for (int i = threadIdx.x; i < rows * GA_SH; i += GA_ROWS) {
-    const int rr = i / GA_SH, e = i - rr * GA_SH;
-    sh[g0 * GA_SH + i] = s[rr * GA_D + 8 + e] * c_sh_mask[e % 25];
+  if (rows == GA_ROWS) {  // 128 x 75 floats: 16-byte aligned, a multiple of four
+    for (int i4 = threadIdx.x; i4 < GA_ROWS * GA_SH / 4; i4 += nt) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i4 * 4 + u, rr = i / GA_SH, e = i - rr * GA_SH;
+        v[u] = s[rr * GA_D + 8 + e] * c_sh_mask[e % 25];
+      }
+      ((float4*)(sh + g0 * GA_SH))[i4] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  } else {
+    for (int i = threadIdx.x; i < rows * GA_SH; i += nt) {
+      const int rr = i / GA_SH, e = i - rr * GA_SH;
+      sh[g0 * GA_SH + i] = s[rr * GA_D + 8 + e] * c_sh_mask[e % 25];
+    }
   }
 }
 
@@ -722,7 +745,7 @@ extern "C" int siu3r_gaussian_adapter(const void* raw, int raw_dtype, float* opa
     }
     mask_set = true;
   }
-  hipLaunchKernelGGL(gaussian_adapter_kernel, dim3((unsigned)cdiv64(n, GA_ROWS)), dim3(GA_ROWS), 0, (hipStream_t)stream, raw, raw_dtype, opacities, scales, rotations, harmonics, covariances, n);
+  hipLaunchKernelGGL(gaussian_adapter_kernel, dim3((unsigned)cdiv64(n, GA_ROWS)), dim3(256), 0, (hipStream_t)stream, raw, raw_dtype, opacities, scales, rotations, harmonics, covariances, n);
   SIU3R_LAUNCH_CHECK("siu3r_gaussian_adapter");
   return 0;
 }
