@@ -173,7 +173,7 @@ def main():
         "config": {"workload": f"configs[1]: single pair 2x{H}x{W} per step" if B == 1 else f"{B} pairs 2x{H}x{W} per step",
                    "pairs_per_step_per_gpu": B, "image_size": [H, W], "precision": args.precision, "parity": PARITY[args.precision],
                    "parallelism": f"dp{world} (independent pairs, one all-gather of metric statistics)",
-                   "launch": "per-chain HIP graphs on 6 streams" if (model.use_graph and model._ctx.concurrent) else "eager",
+                   "launch": "per-chain HIP graphs on 4 streams (encoder+decoder+pts3d heads | ViT-Adapter+Mask2Former | Gaussian head 1 | Gaussian head 2)" if (model.use_graph and model._ctx.concurrent) else "eager",
                    "n_segments_per_step": total["n_segments"] / max(1, world), "n_gaussians_per_step": total["n_gaussians"] / max(1, world)},
         "network_tflops_algorithmic": value * FLOPS_PER_PAIR_512 * (H * W / (512 * 512)) / 1e12,
     }

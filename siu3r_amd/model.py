@@ -1110,14 +1110,18 @@ class SIU3RModel:
             if par:
                 main.wait_stream(dside)
         run("dec_post", stages["dec_post"])
-        hs = [ctx.side_stream(2 + i) if par else main for i in range(3)] + [main]
-        for s_ in hs[:3]:
+        # the two Gaussian heads (5.8 ms each in bf16x3) on their own streams; the two pts3d heads (3.3 + 1.7 ms) back to back on the main
+        # stream: three chains of about equal length.  (A fourth stream for pts0 shares a hardware queue with one of the others on this
+        # runtime -- it then ran alone AFTER the Gaussian heads; with GPU_MAX_HW_QUEUES=8 it overlaps, but the extra concurrency slows
+        # the encoder / decoder critical path by more than it saves: 25.3 -> 31.3 ms.)
+        hs = [ctx.side_stream(2 + i) if par else main for i in range(2)]
+        for s_ in hs:
             if s_ is not main:
                 s_.wait_stream(main)
-        for name, s_ in zip(("gs0", "gsr", "pts0", "ptsr"), hs):
+        for name, s_ in zip(("gs0", "gsr", "ptsr", "pts0"), hs + [main, main]):
             with torch.cuda.stream(s_):
                 run(name, stages[name])
-        for s_ in hs[:3] + [seg_stream]:
+        for s_ in hs + [seg_stream]:
             if s_ is not main:
                 main.wait_stream(s_)
         run("tail", stages["tail"])
