@@ -2,7 +2,7 @@
 # usage: tools/stage_profile.sh <stage>: kernels of one stage graph (one replay), aggregated
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/sp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/sp -- python $GRAFT_REPO_ROOT/tools/stage_profile.py $1 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/sp -- python $GRAFT_REPO_ROOT/tools/stage_profile.py $1 $2 > /dev/null 2>&1
 f=$(find /tmp/sp -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
