@@ -62,12 +62,13 @@ __global__ void pp_class_kernel(const float* logits, float* probs, float* scores
 __global__ void pp_mask256_kernel(const float* ml, float* out, int BT, int IH, int IW, int OS, int Q) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)BT * OS * OS * Q) return;
-  const int q = (int)(idx % Q);
-  int64_t r = idx / Q;
-  const int ox = (int)(r % OS);
-  r /= OS;
-  const int oy = (int)(r % OS);
-  const int bt = (int)(r / OS);
+  // (32-bit index arithmetic: the launcher keeps the volume below 2^31 elements; 64-bit divisions dominated these kernels)
+  unsigned r = (unsigned)idx / (unsigned)Q;
+  const int q = (int)((unsigned)idx - r * (unsigned)Q);
+  unsigned r2 = r / (unsigned)OS;
+  const int ox = (int)(r - r2 * (unsigned)OS);
+  const int bt = (int)(r2 / (unsigned)OS);
+  const int oy = (int)(r2 - (unsigned)bt * (unsigned)OS);
   int y0, y1, x0, x1;
   float ly, lx;
   src_idx(oy, IH, OS, y0, y1, ly);
@@ -99,9 +100,10 @@ __global__ __launch_bounds__(256) void pp_argmax_kernel(const float* p256, const
   const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t npix = (int64_t)T * H * W;
   if (pix < npix && nk > 0) {
-    const int x = (int)(pix % W);
-    const int y = (int)((pix / W) % H);
-    const int t = (int)(pix / ((int64_t)W * H));
+    const unsigned row = (unsigned)pix / (unsigned)W;
+    const int x = (int)((unsigned)pix - row * (unsigned)W);
+    const int t = (int)(row / (unsigned)H);
+    const int y = (int)(row - (unsigned)t * (unsigned)H);
     int y0, y1, x0, x1;
     float ly, lx;
     src_idx(y, MS, H, y0, y1, ly);
@@ -190,28 +192,42 @@ __global__ void pp_write_kernel(const int32_t* lab_map, const int32_t* seg_id, c
 }
 
 // out [(T*H*W), nq, C] for ONE batch item; acc = device list of accepted k (indices into kept_idx)
-__global__ void pp_qcl_kernel(const float* p256, const float* probs, const int32_t* kept_idx, const int32_t* acc, int nq,
-                              float* out, int b, int T, int H, int W, int MS, int Q, int C) {
-  // one thread per OUTPUT ELEMENT (pixel, accepted query j, class c): consecutive lanes write consecutive floats.  (A thread per
-  // (pixel, j) wrote its 21 floats alone, 84 bytes from its neighbour's: 380 GB/s on a 176 MB volume.)  The bilinear mask sample is
-  // recomputed per class from cached lines.
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t npix = (int64_t)T * H * W;
-  if (idx >= npix * nq * C) return;
-  const int c = (int)(idx % C);
-  const int64_t pj = idx / C;
-  const int j = (int)(pj % nq);
-  const int64_t pix = pj / nq;
-  const int x = (int)(pix % W);
-  const int y = (int)((pix / W) % H);
-  const int t = (int)(pix / ((int64_t)W * H));
-  int y0, y1, x0, x1;
-  float ly, lx;
-  src_idx(y, MS, H, y0, y1, ly);
-  src_idx(x, MS, W, x0, x1, lx);
-  const int q = kept_idx[b * Q + acc[b * Q + j]];
-  const float mp = sample256(p256, ((int64_t)b * T + t) * MS * MS, MS, Q, q, y0, y1, x0, x1, ly, lx);
-  out[idx] = probs[((int64_t)b * Q + q) * C + c] * mp;
+__global__ __launch_bounds__(256) void pp_qcl_kernel(const float* p256, const float* probs, const int32_t* kept_idx, const int32_t* acc, int nq,
+                                                     float* out, int b, int T, int H, int W, int MS, int Q, int C) {
+  // A workgroup owns 256 consecutive (pixel, accepted query) pairs = one contiguous run of 256 x C output floats.  Phase 1: one thread
+  // per pair does the index arithmetic and the bilinear mask sample once.  Phase 2: all threads write the run, consecutive lanes to
+  // consecutive floats.  (A thread per pair writing its own 21 floats left every store strided: 380 GB/s on the 176 MB volume; a thread
+  // per element redid the 64-bit index arithmetic per float.)
+  __shared__ float s_mp[256];
+  __shared__ int s_q[256];
+  const unsigned npairs = (unsigned)((int64_t)T * H * W * nq);
+  const unsigned pair0 = blockIdx.x * 256u, pair = pair0 + threadIdx.x;
+  float mp = 0.f;
+  int q = 0;
+  if (pair < npairs) {
+    const unsigned pix = pair / (unsigned)nq;
+    const int j = (int)(pair - pix * (unsigned)nq);
+    const unsigned row = pix / (unsigned)W;
+    const int x = (int)(pix - row * (unsigned)W);
+    const unsigned t = row / (unsigned)H;
+    const int y = (int)(row - t * (unsigned)H);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_idx(y, MS, H, y0, y1, ly);
+    src_idx(x, MS, W, x0, x1, lx);
+    q = kept_idx[b * Q + acc[b * Q + j]];
+    mp = sample256(p256, ((int64_t)b * T + t) * MS * MS, MS, Q, q, y0, y1, x0, x1, ly, lx);
+  }
+  s_mp[threadIdx.x] = mp;
+  s_q[threadIdx.x] = q;
+  __syncthreads();
+  const unsigned nloc = min(256u, npairs - pair0) * (unsigned)C;
+  float* o = out + (size_t)pair0 * C;
+  const float* pb = probs + (int64_t)b * Q * C;
+  for (unsigned e = threadIdx.x; e < nloc; e += 256u) {
+    const unsigned pl = e / (unsigned)C, c = e - pl * (unsigned)C;
+    o[e] = pb[s_q[pl] * C + c] * s_mp[pl];
+  }
 }
 
 inline dim3 g1(int64_t n, int blk = 256) { return dim3((unsigned)cdiv64(n, blk)); }
@@ -227,6 +243,8 @@ extern "C" int siu3r_panoptic_stage1(const float* class_logits, const float* mas
                                      float overlap, uint32_t fuse_mask, void* stream) {
   SIU3R_CHECK(class_logits && mask_logits_cl && probs && p256 && lab_map && seg, "panoptic_stage1: null pointer");
   SIU3R_CHECK(Q <= 128 && C <= 64, "panoptic_stage1: supports up to 128 queries / 64 classes (Q=%d C=%d)", Q, C);
+  SIU3R_CHECK((int64_t)B * T * mask_size * mask_size * Q < 0x7fffffffll && (int64_t)T * H * W < 0x7fffffffll,
+              "panoptic_stage1: mask volume / pixel count must stay below 2^31");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(pp_class_kernel, dim3(B), dim3(64), 0, s, class_logits, probs, scores, labels, kept_idx, n_keep, Q, C, threshold);
   hipLaunchKernelGGL(pp_mask256_kernel, g1((int64_t)B * T * mask_size * mask_size * Q), dim3(256), 0, s, mask_logits_cl, p256, B * T, IH, IW, mask_size, Q);
@@ -246,7 +264,8 @@ extern "C" int siu3r_panoptic_qcl(const float* p256, const float* probs, const i
                                   int nq, float* out, int b, int T, int H, int W, int mask_size, int Q, int C,
                                   void* stream) {
   SIU3R_CHECK(p256 && probs && kept_idx && acc_list && out && nq > 0, "panoptic_qcl: bad arguments");
-  hipLaunchKernelGGL(pp_qcl_kernel, g1((int64_t)T * H * W * nq * C), dim3(256), 0, (hipStream_t)stream, p256, probs, kept_idx, acc_list, nq, out, b, T, H, W, mask_size, Q, C);
+  SIU3R_CHECK((int64_t)T * H * W * nq * C < 0x7fffffffll, "panoptic_qcl: the volume must stay below 2^31 elements");
+  hipLaunchKernelGGL(pp_qcl_kernel, g1((int64_t)T * H * W * nq), dim3(256), 0, (hipStream_t)stream, p256, probs, kept_idx, acc_list, nq, out, b, T, H, W, mask_size, Q, C);
   SIU3R_LAUNCH_CHECK("siu3r_panoptic_qcl");
   return 0;
 }
