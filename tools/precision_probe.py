@@ -5,7 +5,7 @@ output tensor against the plain fp32 run.  This is how the "mixed" precision map
 
     python tools/precision_probe.py [size] [policy ...]
 
-policy = name:spec,name:spec...   spec in {f32, bf16, fp16, x3}; `name` is a substring of the layer (weight) name; the first
+policy = name:spec,name:spec...   spec in {f32, bf16, fp16, x3, fp16x2} or "act|weight" (e.g. x3|bf16); `name` is a substring of the layer (weight) name; the first
 match wins; `*` matches everything; `mm` addresses the weight-free products (q k^T, p v, mask einsum).
 Examples:  "*:bf16"   "*:fp16"   "downstream_head:x3,*:fp16"
 """
@@ -57,7 +57,8 @@ class Emu(TorchFunctionMode):
                 return func(*args, **kwargs)  # depthwise 3x3: VALU fp32 on the GPU path
             s = self.spec(self.names.get(id(w), "?unnamed"))
             if s != "f32":
-                args = (rnd(x, s), rnd(w, s)) + tuple(args[2:])
+                sa, sw = s.split("|") if "|" in s else (s, s)  # "x3|bf16": activations hi+lo, weights one bf16 plane (a 2-pass product)
+                args = (rnd(x, sa), rnd(w, sw)) + tuple(args[2:])
             return func(*args, **kwargs)
         if func in (torch.matmul, torch.Tensor.matmul, torch.Tensor.__matmul__, torch.bmm):
             s = self.spec("mm")
