@@ -107,8 +107,12 @@ typedef struct {
   int32_t splitk;
   float* sk_ws;
   int32_t* sk_cnt;
+  int32_t sk_pp;                  /* set by siu3r_gemm_plan: splitk / sk_ws were sized for the tile of the ping-pong kernels */
 } siu3r_gemm_params;
 int siu3r_gemm(const siu3r_gemm_params* p, void* stream);
+/* tuning aid (tools/, tests): key 0 = tile selection of the 8-wave ping-pong kernels: 0 auto (default), -1 never, 1 = 256 x 256,
+ * 2 = 256 x 128, 3 = 128 x 128 wherever the problem is inside their range.  Process-wide; not for concurrent use. */
+int siu3r_gemm_tune(int key, int value);
 
 /* ---- LayerNorm over the last dim (fp32 in, act-dtype out); reference: nn.LayerNorm call sites
  * croco/blocks.py:127-191 (eps 1e-6), video_seg_decoder.py:945-1018 (eps 1e-5). */

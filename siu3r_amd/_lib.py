@@ -37,7 +37,7 @@ class GemmParams(C.Structure):
         ("ln_ldm", C.c_int64), ("ln_sz", C.c_int64), ("ln_sz_i", C.c_int64),
         ("stats_out", C.c_void_p), ("st_ldm", C.c_int64), ("st_sz", C.c_int64), ("st_sz_i", C.c_int64),
         ("c_aux", C.c_void_p),
-        ("splitk", C.c_int32), ("sk_ws", C.c_void_p), ("sk_cnt", C.c_void_p),
+        ("splitk", C.c_int32), ("sk_ws", C.c_void_p), ("sk_cnt", C.c_void_p), ("sk_pp", C.c_int32),
     ]
 
 
@@ -81,6 +81,7 @@ SIGNATURES = {
     "siu3r_abi_version": [],
     "siu3r_rope2d": [_P, _I, _I, _I, _I, _I, _L, _L, _L, _P, _F, _F, _P],
     "siu3r_gemm": [C.POINTER(GemmParams), _P],
+    "siu3r_gemm_tune": [_I, _I],
     "siu3r_layernorm": [_P, _P, _I, _P, _P, _L, _I, _L, _L, _F, _P],
     "siu3r_layernorm2": [_P, _P, _I, _P, _P, _P, _L, _I, _L, _L, _L, _F, _P],
     "siu3r_attention": [C.POINTER(AttnParams), _P],

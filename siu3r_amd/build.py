@@ -16,6 +16,9 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsiu3r_hip.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+# per-file extras.  gemm_pp.hip: its epilogue walks the accumulator blocks in fully unrolled loops whose bodies are large; above the default
+# pragma-unroll size limit the loops stay rolled, the block index becomes a run-time value and the accumulators move to scratch memory
+EXTRA_FLAGS = {"gemm_pp.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
 
 
 def _sources():
@@ -24,10 +27,11 @@ def _sources():
 
 def _digest(path):
     h = hashlib.sha1()
-    for f in [path, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(HERE, "..", "include", "siu3r_hip.h")]:
+    for f in [path, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(CSRC, "gemm_epilogue_pp.h"),
+              os.path.join(HERE, "..", "include", "siu3r_hip.h")]:
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + EXTRA_FLAGS.get(os.path.basename(path), [])).encode())
     return h.hexdigest()
 
 
@@ -38,7 +42,7 @@ def _compile(src):
     dg = _digest(path)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dg and os.path.exists(obj.replace(".o", ".resources.txt")):
         return obj
-    cmd = ["hipcc", *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", path, "-o", obj]
+    cmd = ["hipcc", *FLAGS, *EXTRA_FLAGS.get(src, []), "-Rpass-analysis=kernel-resource-usage", "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

@@ -19,6 +19,7 @@
 
 int siu3r_gemm_dma_launch(const siu3r_gemm_params& p, int ni, void* stream);  // gemm_dma.hip (bf16 LDS-DMA fast path)
 int siu3r_gemm_dma_x3_launch(const siu3r_gemm_params& p, void* stream);       // gemm_dma.hip (bf16x3 LDS-DMA path, fp32 A)
+int siu3r_gemm_pp_launch(const siu3r_gemm_params& p, void* stream);           // gemm_pp.hip (8-wave ping-pong kernels, 256 x 256 / 256 x 128 tiles)
 static const bool g_disable_dma = getenv("SIU3R_GEMM_NO_DMA") != nullptr;     // debugging / A-B switch
 // 128x64 tiles (two workgroups per CU) beat 128x128 (one per CU: 96 KiB ring) at every size measured on gfx950 --
 // finer wave quantisation and a second workgroup to overlap prologue/epilogue; 128x128 stays reachable for A/B runs
@@ -364,6 +365,10 @@ extern "C" int siu3r_gemm(const siu3r_gemm_params* pp, void* stream) {
   if (p.splitk > 1)
     SIU3R_CHECK(p.sk_ws && p.sk_cnt && p.splitk <= 64 && p.splitk <= p.kpad / 64, "siu3r_gemm: split-K needs a workspace, zeroed counters and splitk <= kpad / 64 (splitk=%d)", p.splitk);
   if (p.bmod > 0) SIU3R_CHECK(p.batch > 0 && p.batch % p.bmod == 0, "siu3r_gemm: batch %d is not a multiple of bmod %d", p.batch, p.bmod);
+  if (!g_disable_dma && p.a_mode != 2) {
+    const int rc = siu3r_gemm_pp_launch(p, stream);
+    if (rc != 1) return rc;  // 1: left to the 128 x 64 kernels below
+  }
   // narrow tiles when 128x128 tiling would leave most of the 256 CUs without a workgroup, or N <= 64
   const int64_t tiles128 = (int64_t)((p.m + BM - 1) / BM) * ((p.n + 127) / 128) * (p.batch > 0 ? p.batch : 1);
   const bool narrow = (p.n <= 64) || (tiles128 < g_narrow_max && p.n > 64) || p.w_x3 != nullptr;

@@ -1,0 +1,347 @@
+// Epilogue of the 8-wave ping-pong GEMM (gemm_pp.hip): the same fused operations as gemm_epilogue.h (bias, folded LayerNorm, GELU /
+// ReLU, residual, RoPE2D, conv-transpose pixel shuffle, x2 bilinear upsample-add, row statistics, bf16 copy, deterministic split-K)
+// for 128 MI x 64 NJ tiles held by 4 x 2 waves of 32 MI x 32 NJ each.
+//
+// Wave-private staging: a wave transposes ONE 32-row x 64-column pair of accumulator blocks at a time through its own 8.5 KiB of LDS
+// (lane = column  ->  lane = (row, 8-column chunk)), so that every global access is a 16-byte vector and a tile row is written in
+// 256-byte runs, and then moves on to its next pair.  No workgroup barrier after the first one, the accumulators are released pair by
+// pair (the 256 x 256 kernel holds 128 of them: a workgroup-wide row pass on top of those spilled ~200 registers), and a 64-column
+// group (one RoPE head, one row-statistics group) is always inside one pair.
+#pragma once
+#include "common.h"
+#include "gemm_epilogue.h"  // gelu_fast
+
+namespace siu3r_epi_pp {
+
+constexpr int NT = 512;
+constexpr int LDW = 68;                           // floats per staged row (64 + 4: 16-byte aligned rows, spreads banks)
+constexpr int WAVE_STAGE_BYTES = 32 * LDW * 4 + 64 * 2 * 4;  // 32 x 64 block pair + (mean, rstd) of the wave's 64 rows
+constexpr int staging_bytes() { return 8 * WAVE_STAGE_BYTES + 64; }
+
+template <int MI, int NJ, bool LNF>
+__device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[MI][NJ], unsigned char* smem, int tile_m, int tile_n, int z,
+                                    int t, int wave, int wm, int wn) {
+  constexpr int BN = 64 * NJ, BM = 128 * MI;
+  static_assert(NJ % 2 == 0, "block pairs");
+  const int lane = t & 63;
+  const int l31 = lane & 31, lh = lane >> 5;
+  unsigned char* Cb = (unsigned char*)p.c;
+  const unsigned char* Rb = (const unsigned char*)p.residual;
+  const siu3r_zoff zof = siu3r_batch_offsets(p, z);
+  const int64_t c_boff = zof.c, r_boff = zof.r;
+  const float* biasp = p.bias ? p.bias + zof.bias : nullptr;
+  constexpr bool ln = LNF;
+  const float* c1p = ln ? p.ln_c1 + zof.bias : nullptr;
+  const float* c2p = ln ? p.ln_c2 + zof.bias : nullptr;
+  const float* addp = ln ? c2p : biasp;
+  const int c_esz = p.c_dtype == SIU3R_F32 ? 4 : 2;
+  const int r_esz = p.r_dtype == SIU3R_F32 ? 4 : 2;
+  const int M = p.m, N = p.n;
+  int* s_flag = (int*)(smem + 8 * WAVE_STAGE_BYTES);
+
+  // ---- split-K over workgroups (deterministic): slabs as 16-byte write-through stores, relaxed ticket, the tile's last arriver sums
+  // the slabs in slice order and resets the ticket for the next launch that uses this counter (same stream: see ops.py)
+#if __HIP_DEVICE_COMPILE__
+  if (p.splitk > 1) {
+    const int S = p.splitk, tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const int64_t tile_id = ((int64_t)z * tiles_m + tile_m) * tiles_n + tile_n;
+    float* slabs = p.sk_ws + tile_id * S * (BM * BN);
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    constexpr int NV = MI * NJ * 4;
+    __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)slabs, (short)0, (int)(S * BM * BN * 4), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          union { u32x4_t u; float f[4]; } v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v.f[e] = acc[i][j][4 * q + e];
+          const int vec = (i * NJ + j) * 4 + q;
+          __builtin_amdgcn_raw_buffer_store_b128(v.u, rs_, (int)((((int)blockIdx.y * NV + vec) * NT + t) * 16), 0, 16 /* sc1 */);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) *s_flag = __hip_atomic_fetch_add(p.sk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*s_flag != S - 1) return;
+    if (t == 0) __hip_atomic_store(p.sk_cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int sl = 0; sl < S; ++sl) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int vec = (i * NJ + j) * 4 + q;
+            union { u32x4_t u; float f[4]; } v;
+            v.u = __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(((sl * NV + vec) * NT + t) * 16), 0, 16 /* sc1 */);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v.f[e];
+          }
+    }
+  }
+#endif
+
+  float* ws = (float*)(smem + wave * WAVE_STAGE_BYTES);  // this wave's [32][LDW] block pair
+  float* w_ln = ws + 32 * LDW;                           // (mean, rstd) of the wave's 32 MI rows
+  const int row_w0 = tile_m * BM + wm * (32 * MI);       // first row of the wave
+  const int prow = lane >> 3, chunk = lane & 7;          // row pass: 8 rows x 8 chunks per step
+
+  if (ln) {
+    // lane r merges the 64-column (mean, M2) partials of row r of the wave (Chan's formula)
+    if (lane < 32 * MI) {
+      const int m = row_w0 + lane;
+      float mu = 0.f, rstd = 0.f;
+      if (m < M) {
+        const float2* sp = (const float2*)p.ln_stats + ((int64_t)zof.zo * p.ln_sz + (int64_t)zof.zi * p.ln_sz_i + (int64_t)m * p.ln_ldm) * p.ln_tiles;
+        const int Cn = p.k, last = Cn - 64 * (p.ln_tiles - 1);
+        float2 part[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[i] = i < p.ln_tiles ? sp[i] : make_float2(0.f, 0.f);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (i < p.ln_tiles) sum += part[i].x * (float)(i == p.ln_tiles - 1 ? last : 64);
+        mu = sum / (float)Cn;
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (i < p.ln_tiles) {
+            const float d = part[i].x - mu;
+            m2 += part[i].y + d * d * (float)(i == p.ln_tiles - 1 ? last : 64);
+          }
+        rstd = rsqrtf(m2 / (float)Cn + p.ln_eps);
+      }
+      w_ln[2 * lane] = mu;
+      w_ln[2 * lane + 1] = rstd;
+    }
+  }
+
+#pragma unroll
+  for (int jp = 0; jp < NJ / 2; ++jp) {
+    // ---- column invariants of this 64-column group
+    const int n0 = tile_n * BN + wn * (32 * NJ) + jp * 64 + chunk * 8;
+    const bool col_ok = n0 < N;
+    const int nv = col_ok ? min(8, N - n0) : 0;
+    int co0 = n0, kidx = 0;
+    if (p.out_mode == 1) {
+      kidx = n0 / p.cout;
+      co0 = n0 - kidx * p.cout;
+    }
+    const bool full = nv == 8 && (p.out_mode == 0 || co0 + 8 <= p.cout);
+    const bool rope = p.rope_cos != nullptr && n0 < p.rope_ncols && col_ok;
+    const int pc = chunk ^ 2;  // RoPE partner chunk: 16 columns away inside the 64-wide head
+    const int d0 = n0 & 63, axis = d0 >> 5;
+    const bool upper = (d0 & 16) != 0;
+    float bias[8], pbias[8], c1[8], pc1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = pbias[e] = c1[e] = pc1[e] = 0.f;
+    if (col_ok) {
+      if (addp) {
+        if (nv == 8 && (((uintptr_t)(addp + co0)) & 15) == 0) {
+          const float4 a = *(const float4*)(addp + co0), b = *(const float4*)(addp + co0 + 4);
+          bias[0] = a.x; bias[1] = a.y; bias[2] = a.z; bias[3] = a.w; bias[4] = b.x; bias[5] = b.y; bias[6] = b.z; bias[7] = b.w;
+        } else {
+          _Pragma("unroll") for (int e = 0; e < 8; ++e)
+            if (e < nv) bias[e] = addp[co0 + e];
+        }
+      }
+      if (ln) {
+        _Pragma("unroll") for (int e = 0; e < 8; ++e)
+          if (e < nv) c1[e] = c1p[n0 + e];
+      }
+      if (rope) {
+        const int pn0 = n0 - chunk * 8 + pc * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (addp) pbias[e] = addp[pn0 + e];
+          if (ln) pc1[e] = c1p[pn0 + e];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int mblk = row_w0 + i * 32;
+      if (mblk < M) {  // (wave-uniform)
+      // ---- global reads of the block pair's four row groups go out first: residual, RoPE positions
+      f32x8 res[4];
+      int64_t pos[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int m = mblk + k * 8 + prow;
+        const bool ok = col_ok && m < M;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) res[k].v[e] = 0.f;
+        pos[k] = 0;
+        if (!ok) continue;
+        if (Rb && p.out_mode == 0) {
+          const int64_t ridx = r_boff + (int64_t)m * p.ldr + n0;
+          if (full && (((uintptr_t)Rb + ridx * r_esz) & 15) == 0) {
+            res[k] = load8_as_f32(Rb, p.r_dtype, ridx);
+          } else {
+            _Pragma("unroll") for (int e = 0; e < 8; ++e)
+              if (e < nv) res[k].v[e] = load_as_f32(Rb, p.r_dtype, ridx + e);
+          }
+        }
+        if (rope) pos[k] = p.rope_pos[((int64_t)z * M + m) * 2 + axis];
+      }
+      // ---- transpose the pair through the wave's LDS (same wave: LDS operations of a wave complete in order, a counted wait is the
+      // only synchronisation needed; the previous pair's reads were waited for before its last use)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ws[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDW + jj * 32 + l31] = acc[i][2 * jp + jj][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float4 rc[4][2], rs[4][2];
+      if (rope) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float* cs_ = p.rope_cos + pos[k] * 16 + (d0 & 8);
+          const float* sn_ = p.rope_sin + pos[k] * 16 + (d0 & 8);
+          rc[k][0] = *(const float4*)cs_; rc[k][1] = *(const float4*)(cs_ + 4);
+          rs[k][0] = *(const float4*)sn_; rs[k][1] = *(const float4*)(sn_ + 4);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int lr = i * 32 + k * 8 + prow;  // row inside the wave
+        const int m = row_w0 + lr;
+        float v[8], pv[8];
+        {
+          const float* rowp = ws + (k * 8 + prow) * LDW;
+          const float4 a = *(const float4*)(rowp + chunk * 8), b = *(const float4*)(rowp + chunk * 8 + 4);
+          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pv[e] = 0.f;
+          if (rope) {
+            const float4 c = *(const float4*)(rowp + pc * 8), d = *(const float4*)(rowp + pc * 8 + 4);
+            pv[0] = c.x; pv[1] = c.y; pv[2] = c.z; pv[3] = c.w; pv[4] = d.x; pv[5] = d.y; pv[6] = d.z; pv[7] = d.w;
+          }
+        }
+        if (k == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging area may be rewritten
+        if (m >= M) continue;                  // (uniform over the 8 lanes of a row)
+        if (!col_ok && !p.stats_out) continue;
+        float ln_mu = 0.f, ln_rs = 1.f;
+        if (ln) {
+          ln_mu = w_ln[2 * lr];
+          ln_rs = w_ln[2 * lr + 1];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = ln_rs * (v[e] - ln_mu * c1[e]) + bias[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bias[e];
+        }
+        if (rope) {
+          const float cc[8] = {rc[k][0].x, rc[k][0].y, rc[k][0].z, rc[k][0].w, rc[k][1].x, rc[k][1].y, rc[k][1].z, rc[k][1].w};
+          const float ss[8] = {rs[k][0].x, rs[k][0].y, rs[k][0].z, rs[k][0].w, rs[k][1].x, rs[k][1].y, rs[k][1].z, rs[k][1].w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float o = ln ? ln_rs * (pv[e] - ln_mu * pc1[e]) + pbias[e] : pv[e] + pbias[e];
+            v[e] = upper ? (v[e] * cc[e] + o * ss[e]) : (v[e] * cc[e] - o * ss[e]);
+          }
+        }
+        if (p.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = siu3r_epi::gelu_fast(v[e]);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        int64_t oidx;
+        if (p.out_mode == 0) {
+          oidx = (int64_t)m * p.ldc + n0;
+        } else {
+          const int ihw = p.ih * p.iw;
+          const int b = m / ihw, rr = m - b * ihw;
+          const int iy = rr / p.iw, ix = rr - iy * p.iw;
+          const int ky = kidx / p.up, kx = kidx - ky * p.up;
+          oidx = (((int64_t)b * (p.ih * p.up) + iy * p.up + ky) * (p.iw * p.up) + ix * p.up + kx) * p.cout + co0;
+        }
+        if (p.up_src && col_ok) {
+          const int ohw = p.oh * p.ow;
+          const int b = m / ohw, rr = m - b * ohw;
+          const int oy = rr / p.ow, ox = rr - oy * p.ow;
+          const int sh = p.oh >> 1, sw = p.ow >> 1;
+          const float fy = (p.oh > 1) ? (float)(sh - 1) / (float)(p.oh - 1) * oy : 0.f;
+          const float fx = (p.ow > 1) ? (float)(sw - 1) / (float)(p.ow - 1) * ox : 0.f;
+          const int y0 = (int)fy, x0 = (int)fx;
+          const int y1 = y0 + (y0 < sh - 1 ? 1 : 0), x1 = x0 + (x0 < sw - 1 ? 1 : 0);
+          const float ly = fy - y0, lx = fx - x0;
+          const int64_t sb = (int64_t)b * sh * sw;
+          const int64_t i00 = (sb + (int64_t)y0 * sw + x0) * N + n0, i01 = (sb + (int64_t)y0 * sw + x1) * N + n0;
+          const int64_t i10 = (sb + (int64_t)y1 * sw + x0) * N + n0, i11 = (sb + (int64_t)y1 * sw + x1) * N + n0;
+          if (full && (N & 7) == 0) {
+            const f32x8 a = load8_as_f32(p.up_src, p.up_dtype, i00), b_ = load8_as_f32(p.up_src, p.up_dtype, i01);
+            const f32x8 c = load8_as_f32(p.up_src, p.up_dtype, i10), d = load8_as_f32(p.up_src, p.up_dtype, i11);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              v[e] += (1.f - ly) * ((1.f - lx) * a.v[e] + lx * b_.v[e]) + ly * ((1.f - lx) * c.v[e] + lx * d.v[e]);
+          } else {
+            _Pragma("unroll") for (int e = 0; e < 8; ++e)
+              if (e < nv) v[e] += (1.f - ly) * ((1.f - lx) * load_as_f32(p.up_src, p.up_dtype, i00 + e) + lx * load_as_f32(p.up_src, p.up_dtype, i01 + e)) +
+                      ly * ((1.f - lx) * load_as_f32(p.up_src, p.up_dtype, i10 + e) + lx * load_as_f32(p.up_src, p.up_dtype, i11 + e));
+          }
+        }
+        if (Rb) {
+          if (p.out_mode == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += res[k].v[e];
+          } else {
+            _Pragma("unroll") for (int e = 0; e < 8; ++e)
+              if (e < nv) v[e] += load_as_f32(Rb, p.r_dtype, r_boff + oidx + e);
+          }
+        }
+        if (p.stats_out) {
+          // (mean, centred sum of squares) of this row's 64-column group, reduced over the group's 8 lanes
+          const int n64 = min(64, N - (n0 & ~63));
+          float s1 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s1 += e < nv ? v[e] : 0.f;
+          s1 += __shfl_xor(s1, 1);
+          s1 += __shfl_xor(s1, 2);
+          s1 += __shfl_xor(s1, 4);
+          const float mean = s1 / (float)max(n64, 1);
+          float s2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = v[e] - mean;
+            s2 += e < nv ? d * d : 0.f;
+          }
+          s2 += __shfl_xor(s2, 1);
+          s2 += __shfl_xor(s2, 2);
+          s2 += __shfl_xor(s2, 4);
+          if (chunk == 0 && n64 > 0) {
+            const int64_t row = (int64_t)zof.zo * p.st_sz + (int64_t)zof.zi * p.st_sz_i + (int64_t)m * p.st_ldm;
+            ((float2*)p.stats_out)[row * ((N + 63) >> 6) + (n0 >> 6)] = make_float2(mean, s2);
+          }
+          if (!col_ok) continue;
+        }
+        const int64_t cidx = c_boff + oidx;
+        if (full && (((uintptr_t)Cb + cidx * c_esz) & 15) == 0) {
+          f32x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o.v[e] = v[e];
+          store8_from_f32(Cb, p.c_dtype, cidx, o);
+          if (p.c_aux) store8_from_f32(p.c_aux, SIU3R_BF16, cidx, o);
+        } else {
+          _Pragma("unroll") for (int e = 0; e < 8; ++e)
+            if (e < nv) {
+              store_from_f32(Cb, p.c_dtype, cidx + e, v[e]);
+              if (p.c_aux) store_from_f32(p.c_aux, SIU3R_BF16, cidx + e, v[e]);
+            }
+        }
+      }
+      }
+    }
+  }
+}
+
+}  // namespace siu3r_epi_pp
