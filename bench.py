@@ -211,13 +211,13 @@ def gemm_roofline(model, step, precision, B, H, W):
     passes = 3 if "x3" in name else 1
     traffic, traffic_src = (None, None)
     if B == 1 and (H, W) == (512, 512):
-        traffic, traffic_src = pmc_bytes(f"bench_{precision}", [(f"siu3r_gemm_dma::{name}", 1.0)])
+        traffic, traffic_src = pmc_bytes(f"bench_{precision}", [(name, 1.0)])
     busy = None
     bf = os.path.join(ROOT, "profiles", "r02_mfma_busy.json")
     if os.path.exists(bf):
-        busy = json.load(open(bf)).get(f"bench_{precision}", {}).get("kernels", {}).get(f"siu3r_gemm_dma::{name}", {}).get("mfma_busy_frac")
+        busy = json.load(open(bf)).get(f"bench_{precision}", {}).get("kernels", {}).get(name, {}).get("mfma_busy_frac")
     return {
-        "kernel": f"siu3r_gemm_dma::{name}",
+        "kernel": name,
         "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
         "mfma_passes_per_product": passes, "mfma_issue_frac": achieved * passes / MFMA_BF16_PEAK_TFLOPS,

@@ -26,7 +26,7 @@ extern "C" {
 #define SIU3R_F64 3
 
 const char* siu3r_last_error(void);
-#define SIU3R_ABI_VERSION 3 /* 3: view-batched sort-free rasterizer (project/sort/bin/composite/tile_lists), raster_cam.nt_post_blend */
+#define SIU3R_ABI_VERSION 4 /* 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
 int siu3r_abi_version(void);
 
 /* ---- seam 1: curope.rope_2d(tokens, positions, base, fwd)
@@ -100,18 +100,37 @@ typedef struct {
   float* stats_out;
   int64_t st_ldm, st_sz, st_sz_i;
   void* c_aux;                    /* optional bf16 copy of the output (same indexing as c): the next GEMM's A operand in bf16 mode */
-  /* split-K over workgroups (LDS-DMA kernels; splitk > 1): blockIdx.y = K slice; every slice writes its fp32 partial tile to
-     sk_ws [tiles, splitk, 128 * BN] and draws a ticket from sk_cnt [tiles] (int32, ZERO on entry); the last arriver of a tile sums
-     the slabs in slice order (deterministic) and runs the epilogue.  For launches with few tiles and a long K (at batch 1 most of the
-     decoder / head / Mask2Former GEMMs): the K loop of such a tile is a latency chain that more workgroups shorten. */
+  /* split-K over workgroups: blockIdx.y = K slice; every slice writes its fp32 partial tile to sk_ws [tiles, splitk, BM * BN] and draws
+     a ticket from sk_cnt [tiles] (int32, ZERO before the first launch that uses them); the last arriver of a tile sums the slabs in
+     slice order (deterministic), runs the epilogue and resets the ticket, so one zero-initialised counter array serves any number
+     of launches ON ONE STREAM.  For launches with few tiles and a long K (at batch 1 most of the decoder / head / Mask2Former GEMMs).
+     splitk: 0 = the launcher decides (siu3r_gemm_plan; 1 when no workspace is attached), 1 = never, > 1 = this many slices (the
+     workspace must hold siu3r_gemm_plan's ws_floats / counters for it).  sk_ws_floats / sk_cnt_n: capacities of the workspace. */
   int32_t splitk;
   float* sk_ws;
   int32_t* sk_cnt;
-  int32_t sk_pp;                  /* set by siu3r_gemm_plan: splitk / sk_ws were sized for the tile of the ping-pong kernels */
+  int64_t sk_ws_floats;
+  int32_t sk_cnt_n;
+  int32_t tile_cfg;               /* 0 = the launcher decides; SIU3R_TILE_* forces a kernel family / tile (tools, tests) */
+  int32_t m_main;                 /* internal (launcher): rows covered by the tiled kernel when a skinny launch multiplies the last <= 32 rows */
 } siu3r_gemm_params;
+#define SIU3R_TILE_AUTO 0
+#define SIU3R_TILE_128x64 -1   /* the 128 x 64 LDS-DMA / register-staged kernels (gemm_dma.hip, gemm.hip) */
+#define SIU3R_TILE_PP_256x256 1 /* 8-wave ping-pong kernels (gemm_pp.hip) */
+#define SIU3R_TILE_PP_256x128 2
+#define SIU3R_TILE_PP_128x128 3
 int siu3r_gemm(const siu3r_gemm_params* p, void* stream);
-/* tuning aid (tools/, tests): key 0 = tile selection of the 8-wave ping-pong kernels: 0 auto (default), -1 never, 1 = 256 x 256,
- * 2 = 256 x 128, 3 = 128 x 128 wherever the problem is inside their range.  Process-wide; not for concurrent use. */
+/* What siu3r_gemm will launch for these parameters (same decision function): tile family, tile, split-K slices, whether the last
+ * rows go to the skinny kernel, the split-K workspace it needs (fp32 elements / int32 counters) and the kernel's name as rocprofv3
+ * prints it.  Callers that attach a workspace of at least this size get the split; smaller workspaces reduce splitk. */
+typedef struct {
+  int32_t tile_cfg, bm, bn, splitk, skinny_rows, counters;
+  int64_t ws_floats;
+  char kernel[160];
+} siu3r_gemm_plan_t;
+int siu3r_gemm_plan(const siu3r_gemm_params* p, siu3r_gemm_plan_t* out);
+/* tuning aid (tools/, tests): key 0 = process-wide default of siu3r_gemm_params.tile_cfg (SIU3R_TILE_*; also env SIU3R_GEMM_PP), key 1 =
+ * 1 disables the skinny remainder-row launch.  Not for concurrent use. */
 int siu3r_gemm_tune(int key, int value);
 
 /* ---- LayerNorm over the last dim (fp32 in, act-dtype out); reference: nn.LayerNorm call sites

@@ -37,7 +37,16 @@ class GemmParams(C.Structure):
         ("ln_ldm", C.c_int64), ("ln_sz", C.c_int64), ("ln_sz_i", C.c_int64),
         ("stats_out", C.c_void_p), ("st_ldm", C.c_int64), ("st_sz", C.c_int64), ("st_sz_i", C.c_int64),
         ("c_aux", C.c_void_p),
-        ("splitk", C.c_int32), ("sk_ws", C.c_void_p), ("sk_cnt", C.c_void_p), ("sk_pp", C.c_int32),
+        ("splitk", C.c_int32), ("sk_ws", C.c_void_p), ("sk_cnt", C.c_void_p),
+        ("sk_ws_floats", C.c_int64), ("sk_cnt_n", C.c_int32), ("tile_cfg", C.c_int32), ("m_main", C.c_int32),
+    ]
+
+
+class GemmPlan(C.Structure):
+    """siu3r_gemm_plan_t: what siu3r_gemm launches for a parameter block."""
+    _fields_ = [
+        ("tile_cfg", C.c_int32), ("bm", C.c_int32), ("bn", C.c_int32), ("splitk", C.c_int32), ("skinny_rows", C.c_int32),
+        ("counters", C.c_int32), ("ws_floats", C.c_int64), ("kernel", C.c_char * 160),
     ]
 
 
@@ -74,13 +83,14 @@ class RasterCam(C.Structure):
 
 # name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/siu3r_hip.h.
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
-ABI_VERSION = 3  # SIU3R_ABI_VERSION of include/siu3r_hip.h these ctypes declarations mirror
+ABI_VERSION = 4  # SIU3R_ABI_VERSION of include/siu3r_hip.h these ctypes declarations mirror
 
 SIGNATURES = {
     "siu3r_last_error": [],
     "siu3r_abi_version": [],
     "siu3r_rope2d": [_P, _I, _I, _I, _I, _I, _L, _L, _L, _P, _F, _F, _P],
     "siu3r_gemm": [C.POINTER(GemmParams), _P],
+    "siu3r_gemm_plan": [C.POINTER(GemmParams), C.POINTER(GemmPlan)],
     "siu3r_gemm_tune": [_I, _I],
     "siu3r_layernorm": [_P, _P, _I, _P, _P, _L, _I, _L, _L, _F, _P],
     "siu3r_layernorm2": [_P, _P, _I, _P, _P, _P, _L, _I, _L, _L, _L, _F, _P],

@@ -19,7 +19,12 @@
 
 int siu3r_gemm_dma_launch(const siu3r_gemm_params& p, int ni, void* stream);  // gemm_dma.hip (bf16 LDS-DMA fast path)
 int siu3r_gemm_dma_x3_launch(const siu3r_gemm_params& p, void* stream);       // gemm_dma.hip (bf16x3 LDS-DMA path, fp32 A)
-int siu3r_gemm_pp_launch(const siu3r_gemm_params& p, void* stream);           // gemm_pp.hip (8-wave ping-pong kernels, 256 x 256 / 256 x 128 tiles)
+int siu3r_gemm_dma_mode(const siu3r_gemm_params& p);                          // -1: outside the bf16 LDS-DMA kernels' range
+int siu3r_gemm_dma_x3_mode(const siu3r_gemm_params& p);
+int siu3r_gemm_pp_mode(const siu3r_gemm_params& p);                           // gemm_pp.hip (8-wave ping-pong kernels); -1: outside their range
+void siu3r_gemm_pp_name(const siu3r_gemm_params& p, int cfg, char* buf, int n);
+int siu3r_gemm_pp_launch(const siu3r_gemm_params& p, int cfg, void* stream);
+int siu3r_gemm_skinny_launch(const siu3r_gemm_params& p, void* stream);
 static const bool g_disable_dma = getenv("SIU3R_GEMM_NO_DMA") != nullptr;     // debugging / A-B switch
 // 128x64 tiles (two workgroups per CU) beat 128x128 (one per CU: 96 KiB ring) at every size measured on gfx950 --
 // finer wave quantisation and a second workgroup to overlap prologue/epilogue; 128x128 stays reachable for A/B runs
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const siu3r_gemm_params p) {
   // region row-major, so that the ~32 workgroups co-resident on an XCD form a compact patch that shares A-row
   // and W-column panels in that XCD's private 4 MiB L2 instead of re-fetching them over the fabric.
   const int tiles_m = (p.m + BM - 1) / BM, tiles_n = (p.n + BN - 1) / BN;
-  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+  const int xcd = (blockIdx.x + blockIdx.z) & 7, li = blockIdx.x >> 3;  // (regions rotate with the batch item: few tiles per item x many items still load all XCDs)
   const int ry = xcd / p.map_gx, rx = xcd - ry * p.map_gx;
   const int lm = li / p.map_rn, ln = li - lm * p.map_rn;
   const int tile_m = ry * p.map_rm + lm, tile_n = rx * p.map_rn + ln;
@@ -289,12 +294,15 @@ int launch(const siu3r_gemm_params& pin, hipStream_t s) {
   siu3r_gemm_params p = pin;
   const int tm = (p.m + BM - 1) / BM, tn = (p.n + BN - 1) / BN;
   // choose the 8-region factorisation (gy x gx) with the smallest per-XCD operand footprint
+  // 8 regions (gy x gx), one per XCD: first the factorisation whose largest region holds the fewest tiles (an XCD with more workgroups
+  // than CUs runs a second round while the others idle: 5 row tiles cut 2 x 4 put 18 tiles per batch item on four XCDs and 12 on the
+  // rest), then the smallest per-XCD operand footprint
   int best = -1;
   long best_cost = 0;
   for (int gx = 1; gx <= 8; gx *= 2) {
     const int gy = 8 / gx;
     const int rm = (tm + gy - 1) / gy, rn = (tn + gx - 1) / gx;
-    const long cost = (long)rm * BM + (long)rn * BN + (long)rm * rn;  // last term: prefer fewer idle slots
+    const long cost = (long)rm * rn * 1000000 + (long)rm * BM + (long)rn * BN;
     if (best < 0 || cost < best_cost) {
       best = gx;
       best_cost = cost;
@@ -305,7 +313,7 @@ int launch(const siu3r_gemm_params& pin, hipStream_t s) {
   p.map_rn = (tn + best - 1) / best;
   const int tiles = 8 * p.map_rm * p.map_rn;
   dim3 grid(tiles, 1, p.batch > 0 ? p.batch : 1), block(256);
-  if (p.splitk > 1 && NI != 1) p.splitk = 0;  // (slabs are sized for 128 x 64 tiles)
+  if (p.splitk <= 1 || NI != 1) p.splitk = 0;  // (slabs are sized for 128 x 64 tiles)
   if (!p.w_lo && p.a_dtype == SIU3R_BF16 && p.a_mode != 2 && !g_disable_dma) {
     const int rc = siu3r_gemm_dma_launch(p, NI, s);
     if (rc <= 0) return rc;  // 1: outside the buffer-addressed kernels' range -> register-staged kernel below
@@ -331,6 +339,124 @@ int launch(const siu3r_gemm_params& pin, hipStream_t s) {
 }
 
 }  // namespace
+
+
+// ---- what to launch.  One decision function for siu3r_gemm and siu3r_gemm_plan: kernel family, tile, split-K slices, skinny rows.
+static int g_tile_default = getenv("SIU3R_GEMM_PP") ? atoi(getenv("SIU3R_GEMM_PP")) : 0;
+static int g_no_skinny = getenv("SIU3R_GEMM_NO_SKINNY") ? 1 : 0;
+static int g_no_splitk = getenv("SIU3R_NO_SPLITK") ? atoi(getenv("SIU3R_NO_SPLITK")) : 0;
+extern "C" int siu3r_gemm_tune(int key, int value) {
+  if (key == 0) g_tile_default = value;
+  else if (key == 1) g_no_skinny = value;
+  else if (key == 2) g_no_splitk = value;
+  else return 1;
+  return 0;
+}
+
+namespace {
+// Cost model (microseconds), fitted to graph-timed replays of the 495 GEMM launches of a real 2 x 512^2 step under every tile
+// configuration (tools/gemm_replay.py; mean error ~15 %): a launch runs ceil(workgroups / slots) rounds; a round costs t0 (prologue
+// latency plus the epilogue, which the one-workgroup-per-CU ping-pong kernels expose in full every round while the two co-resident
+// workgroups of the 128 x 64 kernels hide each other's) plus its K steps (a step = 64 bytes of every operand row: 16 fp32 or 32 bf16);
+// split-K adds a fixed ~2.5 us and its slab traffic (~5 TB/s: written and read once).  Slots: 256 for the 8-wave ping-pong kernels
+// (one workgroup per CU), 512 for the 128 x 64 kernels.  Separate constants for the bf16 kernels (32 bf16 per step).
+struct Cand { int cfg, bm, bn, slots; float t0_x3, t_step_x3, t0_bf, t_step_bf; };
+const Cand kCands[] = {{SIU3R_TILE_PP_256x256, 256, 256, 256, 27.5f, 1.21f, 21.0f, 1.06f},
+                       {SIU3R_TILE_PP_256x128, 256, 128, 256, 16.8f, 0.67f, 12.1f, 0.52f},
+                       {SIU3R_TILE_PP_128x128, 128, 128, 256, 7.7f, 0.42f, 7.8f, 0.30f},
+                       {SIU3R_TILE_128x64, 128, 64, 512, 6.2f, 0.46f, 6.8f, 0.31f}};
+
+void plan(const siu3r_gemm_params& p, siu3r_gemm_plan_t& pl) {
+  memset(&pl, 0, sizeof(pl));
+  const bool x3 = p.w_x3 != nullptr && p.a_dtype == SIU3R_F32;
+  const int pp_mode = (g_disable_dma || p.a_mode == 2) ? -1 : siu3r_gemm_pp_mode(p);
+  const int dma_mode = g_disable_dma ? -1 : (x3 ? siu3r_gemm_dma_x3_mode(p) : siu3r_gemm_dma_mode(p));
+  const int force = p.tile_cfg ? p.tile_cfg : g_tile_default;
+  const int64_t Z = p.batch > 0 ? p.batch : 1;
+  const int ksteps = p.kpad / (x3 ? 16 : 32);  // steps of 64 operand-row bytes
+  const bool may_split = !g_no_splitk && p.splitk != 1 && p.sk_ws && p.sk_cnt;
+  float best_t = 0.f;
+  int best = -1, best_s = 1, best_skinny = 0;
+  for (int ci = 0; ci < 4; ++ci) {
+    const Cand& c = kCands[ci];
+    const bool is_pp = c.cfg > 0;
+    if (is_pp && pp_mode < 0) continue;
+    if (force != 0 && force != c.cfg && !(force > 0 && !is_pp && pp_mode < 0)) continue;  // a forced ping-pong tile falls back to 128 x 64 outside its range
+    // the last <= 32 rows of a dense problem may go to the skinny kernel instead of opening a row of tiles of their own: worth it when
+    // that row of tiles would cost another round of workgroups (both options are priced)
+    const int rem = p.m % c.bm;
+    const bool skinny_ok = is_pp && !g_no_skinny && p.a_mode == 0 && rem != 0 && rem <= 32 && p.n >= 64;
+    for (int sk = 0; sk <= (skinny_ok ? 1 : 0); ++sk) {
+      const int skinny = sk ? rem : 0;
+      const int mrows = p.m - skinny;
+      const int64_t tiles = (int64_t)((mrows + c.bm - 1) / c.bm) * ((p.n + c.bn - 1) / c.bn) * Z;
+      const bool can_split = may_split && (is_pp || (dma_mode >= 0 && c.bn == 64));
+      const int smax = p.splitk > 1 ? p.splitk : (can_split ? 8 : 1);
+      for (int S = (p.splitk > 1 ? p.splitk : 1); S <= smax; S *= 2) {
+        if (S > 1) {
+          if (ksteps / S < (is_pp ? 8 : 16) && p.splitk <= 1) break;  // every slice keeps a few steps (and whole phases)
+          if (tiles * S * c.bm * c.bn > p.sk_ws_floats || tiles > p.sk_cnt_n) break;
+          if (tiles >= 2 * c.slots && p.splitk <= 1) break;
+        }
+        const int64_t wgs = tiles * S;
+        const int64_t rounds = (wgs + c.slots - 1) / c.slots;
+        float t = rounds * ((x3 ? c.t0_x3 : c.t0_bf) + (float)((ksteps + S - 1) / S) * (x3 ? c.t_step_x3 : c.t_step_bf));
+        if (mrows == 0) t = 0.f;
+        // skinny launch: a kernel boundary plus its K loop (its fragment-shaped loads are address-bound: ~9 us per 1024 k in bf16x3)
+        if (skinny) t += 3.5f + (x3 ? 9.3f : 5.0f) * (float)p.kpad / 1024.f;
+        if (S > 1) t += 2.5f + (float)(2.0 * S * tiles * c.bm * c.bn * 4.0 / 5.0e6);
+        // bf16: the 128 x 64 LDS-DMA kernel is already within a few per cent of the best tile on almost every shape of the network and
+        // shares a CU with the other chains' kernels; end to end the ping-pong tiles LOSE 7-11 % there (same-box A/B of bench.py at
+        // B = 1 and 8), so they must promise a clear gain
+        if (!x3 && is_pp && force == 0) t *= 1.3f;
+        if (best < 0 || t < best_t) {
+          best = ci;
+          best_t = t;
+          best_s = S;
+          best_skinny = skinny;
+        }
+      }
+    }
+  }
+  if (best < 0) best = 3;
+  const Cand& c = kCands[best];
+  pl.tile_cfg = c.cfg;
+  pl.bm = c.bm;
+  pl.bn = c.bn;
+  pl.splitk = best_s;
+  pl.skinny_rows = best_skinny;
+  if (c.cfg < 0) {
+    // the 128 x 64 family: 128 x 128 tiles only for A/B runs (SIU3R_GEMM_NARROW_MAX); register-staged kernels never split
+    const int64_t tiles128 = (int64_t)((p.m + BM - 1) / BM) * ((p.n + 127) / 128) * Z;
+    const bool narrow = (p.n <= 64) || (tiles128 < g_narrow_max && p.n > 64) || p.w_x3 != nullptr;
+    pl.bn = narrow ? 64 : 128;
+    if (!narrow || dma_mode < 0) pl.splitk = 1;
+  }
+  if (pl.splitk > 1) {
+    const int64_t tiles = (int64_t)((p.m - pl.skinny_rows + pl.bm - 1) / pl.bm) * ((p.n + pl.bn - 1) / pl.bn) * Z;
+    pl.ws_floats = tiles * pl.splitk * pl.bm * pl.bn;
+    pl.counters = (int32_t)tiles;
+  }
+  // the kernel's name as rocprofv3 prints it (bench.py's roofline leg keys its HIP-event averages by it)
+  auto tf = [](bool b) { return b ? "true" : "false"; };
+  if (c.cfg > 0) {
+    siu3r_gemm_pp_name(p, c.cfg, pl.kernel, sizeof(pl.kernel));
+  } else if (x3 && dma_mode >= 0 && pl.bn == 64) {
+    snprintf(pl.kernel, sizeof(pl.kernel), "siu3r_gemm_dma::gemm_dma_x3_kernel<%d, %s, 2, %s>", dma_mode, tf(dma_mode == 1 && p.relu_in), tf(dma_mode == 0 && p.ln_stats));
+  } else if (!x3 && !p.w_lo && dma_mode >= 0) {
+    snprintf(pl.kernel, sizeof(pl.kernel), "siu3r_gemm_dma::gemm_dma_kernel<%d, %d, %s, 2, %s>", pl.bn / 64, dma_mode, tf(dma_mode == 1 && p.relu_in), tf(dma_mode == 0 && p.ln_stats));
+  } else {
+    snprintf(pl.kernel, sizeof(pl.kernel), "gemm_kernel<%d, %d, %d%s>", p.a_dtype == SIU3R_F32 ? 1 : 0, p.w_lo ? 1 : 0, pl.bn / 64, p.ln_stats ? ", true" : "");
+  }
+}
+}  // namespace
+
+extern "C" int siu3r_gemm_plan(const siu3r_gemm_params* pp, siu3r_gemm_plan_t* out) {
+  SIU3R_CHECK(pp && out, "siu3r_gemm_plan: null argument");
+  SIU3R_CHECK(pp->m > 0 && pp->n > 0 && pp->k > 0 && pp->kpad % BK == 0, "siu3r_gemm_plan: bad problem");
+  plan(*pp, *out);
+  return 0;
+}
 
 extern "C" int siu3r_gemm(const siu3r_gemm_params* pp, void* stream) {
   const siu3r_gemm_params& p = *pp;
@@ -364,14 +490,26 @@ extern "C" int siu3r_gemm(const siu3r_gemm_params* pp, void* stream) {
   if (p.c_aux) SIU3R_CHECK(p.out_mode == 0, "siu3r_gemm: c_aux needs a plain row-major output");
   if (p.splitk > 1)
     SIU3R_CHECK(p.sk_ws && p.sk_cnt && p.splitk <= 64 && p.splitk <= p.kpad / 64, "siu3r_gemm: split-K needs a workspace, zeroed counters and splitk <= kpad / 64 (splitk=%d)", p.splitk);
+  SIU3R_CHECK(p.tile_cfg >= -1 && p.tile_cfg <= 3, "siu3r_gemm: bad tile_cfg %d", p.tile_cfg);
   if (p.bmod > 0) SIU3R_CHECK(p.batch > 0 && p.batch % p.bmod == 0, "siu3r_gemm: batch %d is not a multiple of bmod %d", p.batch, p.bmod);
-  if (!g_disable_dma && p.a_mode != 2) {
-    const int rc = siu3r_gemm_pp_launch(p, stream);
-    if (rc != 1) return rc;  // 1: left to the 128 x 64 kernels below
-  }
-  // narrow tiles when 128x128 tiling would leave most of the 256 CUs without a workgroup, or N <= 64
-  const int64_t tiles128 = (int64_t)((p.m + BM - 1) / BM) * ((p.n + 127) / 128) * (p.batch > 0 ? p.batch : 1);
-  const bool narrow = (p.n <= 64) || (tiles128 < g_narrow_max && p.n > 64) || p.w_x3 != nullptr;
+  siu3r_gemm_plan_t pl;
+  plan(p, pl);
   hipStream_t s = (hipStream_t)stream;
-  return narrow ? launch<1>(p, s) : launch<2>(p, s);
+  siu3r_gemm_params q = p;
+  q.splitk = pl.splitk;
+  if (pl.splitk > 1) SIU3R_CHECK(p.sk_ws && p.sk_cnt && p.sk_ws_floats >= pl.ws_floats && p.sk_cnt_n >= pl.counters,
+                                 "siu3r_gemm: split-K workspace too small (%ld floats / %d counters needed)", (long)pl.ws_floats, pl.counters);
+  if (pl.tile_cfg > 0) {
+    q.m_main = pl.skinny_rows > 0 ? p.m - pl.skinny_rows : 0;
+    if (!(pl.skinny_rows > 0 && q.m_main == 0)) {
+      const int rc = siu3r_gemm_pp_launch(q, pl.tile_cfg, stream);
+      if (rc) return rc;
+    }
+    if (pl.skinny_rows > 0) {
+      q.splitk = 0;
+      return siu3r_gemm_skinny_launch(q, stream);
+    }
+    return 0;
+  }
+  return pl.bn == 64 ? launch<1>(q, s) : launch<2>(q, s);
 }

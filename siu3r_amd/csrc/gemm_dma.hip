@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256 * KSPL, NI == 1 ? 2 * KSPL : 1) void gemm_dma_k
 
   const int M = p.m, N = p.n, K = p.k, kpad = p.kpad;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+  const int xcd = (blockIdx.x + blockIdx.z) & 7, li = blockIdx.x >> 3;  // (regions rotate with the batch item: few tiles per item x many items still load all XCDs)
 #ifndef SIU3R_GEMM_DBG
 #define SIU3R_GEMM_DBG 0  // tuning builds only (tools/ab_build.sh): 1 no epilogue, 2 no in-loop DMA, 4 no MFMA, 8 no barrier, 16 no reads
 #endif
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256 * KSPL, 2 * KSPL) void gemm_dma_x3_kernel(const
 
   const int M = p.m, N = p.n, K = p.k, kpad = p.kpad;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+  const int xcd = (blockIdx.x + blockIdx.z) & 7, li = blockIdx.x >> 3;  // (regions rotate with the batch item: few tiles per item x many items still load all XCDs)
   const int map_gx = p.map_gx;
   const int ry = xcd / map_gx, rx = xcd - ry * map_gx;
   const int lm = li / p.map_rn, ln = li - lm * p.map_rn;
@@ -761,6 +761,29 @@ __global__ __launch_bounds__(256 * KSPL, 2 * KSPL) void gemm_dma_x3_kernel(const
 }
 
 }  // namespace siu3r_gemm_dma
+
+// A-mode the bf16 LDS-DMA kernels run this problem in, or -1 (outside their range: the register-staged kernel of gemm.hip takes it)
+int siu3r_gemm_dma_mode(const siu3r_gemm_params& p) {
+  const int64_t lim = 0xfffff000ll;
+  if (p.w_lo || p.a_dtype != SIU3R_BF16 || p.a_mode == 2) return -1;
+  if ((int64_t)p.n * p.kpad * 2 >= lim) return -1;
+  if (p.a_mode == 0) return (((int64_t)(p.m - 1) * p.lda + p.k) * 2 >= lim || p.relu_in) ? -1 : 0;
+  const int64_t img = (int64_t)(p.m / (p.oh * p.ow)) * p.ih * p.iw * p.cin * 2 + (int64_t)(p.pad * p.iw + p.pad) * p.cin * 2;
+  if (img >= lim) return -1;
+  const int mode = (p.cin % 64 == 0 && p.kh * p.kw <= 32 && p.kpad == p.k) ? 1 : 2;
+  return (mode == 2 && p.relu_in) ? -1 : mode;
+}
+// ... and of the bf16x3 LDS-DMA kernel (fp32 activations, p.w_x3)
+int siu3r_gemm_dma_x3_mode(const siu3r_gemm_params& p) {
+  const int64_t lim = 0xfffff000ll;
+  if (!p.w_x3 || p.a_dtype != SIU3R_F32 || (int64_t)p.n * p.kpad * 4 >= lim) return -1;
+  if (p.a_mode == 0) return (((int64_t)(p.m - 1) * p.lda + p.k) * 4 >= lim || p.relu_in) ? -1 : 0;
+  if (p.a_mode != 1) return -1;
+  const int64_t img = (int64_t)(p.m / (p.oh * p.ow)) * p.ih * p.iw * p.cin * 4 + (int64_t)(p.pad * p.iw + p.pad) * p.cin * 4;
+  if (img >= lim || p.cin % 4 != 0) return -1;
+  if (p.cin % 32 == 0 && p.kh * p.kw <= 31) return 1;
+  return p.relu_in ? -1 : 2;
+}
 
 // Called by siu3r_gemm() (gemm.hip) for bf16 activations without the bf16x3 split, dense or conv gather.
 // Returns 1 when the problem is outside what the buffer-addressed kernels cover (the caller then uses the

@@ -239,6 +239,7 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[2]
     if (t == 0) *s_flag = __hip_atomic_fetch_add(p.sk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (*s_flag != S - 1) return;  // (uniform) an earlier slice: done
+    if (t == 0) __hip_atomic_store(p.sk_cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
     if (kh == 0) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)

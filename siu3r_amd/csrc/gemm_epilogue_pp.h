@@ -18,33 +18,16 @@ constexpr int LDW = 68;                           // floats per staged row (64 +
 constexpr int WAVE_STAGE_BYTES = 32 * LDW * 4 + 64 * 2 * 4;  // 32 x 64 block pair + (mean, rstd) of the wave's 64 rows
 constexpr int staging_bytes() { return 8 * WAVE_STAGE_BYTES + 64; }
 
-template <int MI, int NJ, bool LNF>
-__device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[MI][NJ], unsigned char* smem, int tile_m, int tile_n, int z,
-                                    int t, int wave, int wm, int wn) {
+// Split-K over workgroups (deterministic): slabs as 16-byte write-through stores, relaxed ticket; the tile's last arriver sums the slabs
+// in slice order into acc, resets the ticket for the next launch that uses this counter (same stream: see ops.py) and returns true;
+// the other slices return false.
+template <int MI, int NJ>
+__device__ __forceinline__ bool splitk_reduce(const siu3r_gemm_params& p, f32x16 (&acc)[MI][NJ], unsigned char* smem, int64_t tile_id, int t) {
   constexpr int BN = 64 * NJ, BM = 128 * MI;
-  static_assert(NJ % 2 == 0, "block pairs");
-  const int lane = t & 63;
-  const int l31 = lane & 31, lh = lane >> 5;
-  unsigned char* Cb = (unsigned char*)p.c;
-  const unsigned char* Rb = (const unsigned char*)p.residual;
-  const siu3r_zoff zof = siu3r_batch_offsets(p, z);
-  const int64_t c_boff = zof.c, r_boff = zof.r;
-  const float* biasp = p.bias ? p.bias + zof.bias : nullptr;
-  constexpr bool ln = LNF;
-  const float* c1p = ln ? p.ln_c1 + zof.bias : nullptr;
-  const float* c2p = ln ? p.ln_c2 + zof.bias : nullptr;
-  const float* addp = ln ? c2p : biasp;
-  const int c_esz = p.c_dtype == SIU3R_F32 ? 4 : 2;
-  const int r_esz = p.r_dtype == SIU3R_F32 ? 4 : 2;
-  const int M = p.m, N = p.n;
   int* s_flag = (int*)(smem + 8 * WAVE_STAGE_BYTES);
-
-  // ---- split-K over workgroups (deterministic): slabs as 16-byte write-through stores, relaxed ticket, the tile's last arriver sums
-  // the slabs in slice order and resets the ticket for the next launch that uses this counter (same stream: see ops.py)
 #if __HIP_DEVICE_COMPILE__
-  if (p.splitk > 1) {
-    const int S = p.splitk, tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-    const int64_t tile_id = ((int64_t)z * tiles_m + tile_m) * tiles_n + tile_n;
+  {
+    const int S = p.splitk;
     float* slabs = p.sk_ws + tile_id * S * (BM * BN);
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
     constexpr int NV = MI * NJ * 4;
@@ -65,7 +48,7 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[MI
     __syncthreads();
     if (t == 0) *s_flag = __hip_atomic_fetch_add(p.sk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (*s_flag != S - 1) return;
+    if (*s_flag != S - 1) return false;
     if (t == 0) __hip_atomic_store(p.sk_cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -89,10 +72,31 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[MI
     }
   }
 #endif
+  return true;
+}
 
-  float* ws = (float*)(smem + wave * WAVE_STAGE_BYTES);  // this wave's [32][LDW] block pair
+
+// Row pass of ONE wave: its 32 MI x 32 NJ accumulator blocks start at (row_w0, col_w0) of the output; rows >= m_end are not stored
+// (they belong to another launch or lie beyond M).  ws: the wave's WAVE_STAGE_BYTES of LDS.
+template <int MI, int NJ, bool LNF>
+__device__ __forceinline__ void wave_rows(const siu3r_gemm_params& p, f32x16 (&acc)[MI][NJ], float* ws, int row_w0, int col_w0, int m_end, int z,
+                                          int lane) {
+  static_assert(NJ % 2 == 0, "block pairs");
+  const int l31 = lane & 31, lh = lane >> 5;
+  unsigned char* Cb = (unsigned char*)p.c;
+  const unsigned char* Rb = (const unsigned char*)p.residual;
+  const siu3r_zoff zof = siu3r_batch_offsets(p, z);
+  const int64_t c_boff = zof.c, r_boff = zof.r;
+  const float* biasp = p.bias ? p.bias + zof.bias : nullptr;
+  constexpr bool ln = LNF;
+  const float* c1p = ln ? p.ln_c1 + zof.bias : nullptr;
+  const float* c2p = ln ? p.ln_c2 + zof.bias : nullptr;
+  const float* addp = ln ? c2p : biasp;
+  const int c_esz = p.c_dtype == SIU3R_F32 ? 4 : 2;
+  const int r_esz = p.r_dtype == SIU3R_F32 ? 4 : 2;
+  const int M = m_end, N = p.n;
+  const int Mtot = p.m;  // rows per batch item (RoPE position index)
   float* w_ln = ws + 32 * LDW;                           // (mean, rstd) of the wave's 32 MI rows
-  const int row_w0 = tile_m * BM + wm * (32 * MI);       // first row of the wave
   const int prow = lane >> 3, chunk = lane & 7;          // row pass: 8 rows x 8 chunks per step
 
   if (ln) {
@@ -128,7 +132,7 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[MI
 #pragma unroll
   for (int jp = 0; jp < NJ / 2; ++jp) {
     // ---- column invariants of this 64-column group
-    const int n0 = tile_n * BN + wn * (32 * NJ) + jp * 64 + chunk * 8;
+    const int n0 = col_w0 + jp * 64 + chunk * 8;
     const bool col_ok = n0 < N;
     const int nv = col_ok ? min(8, N - n0) : 0;
     int co0 = n0, kidx = 0;
@@ -191,7 +195,7 @@ __device__ __forceinline__ void run(const siu3r_gemm_params& p, f32x16 (&acc)[MI
               if (e < nv) res[k].v[e] = load_as_f32(Rb, p.r_dtype, ridx + e);
           }
         }
-        if (rope) pos[k] = p.rope_pos[((int64_t)z * M + m) * 2 + axis];
+        if (rope) pos[k] = p.rope_pos[((int64_t)z * Mtot + m) * 2 + axis];
       }
       // ---- transpose the pair through the wave's LDS (same wave: LDS operations of a wave complete in order, a counted wait is the
       // only synchronisation needed; the previous pair's reads were waited for before its last use)

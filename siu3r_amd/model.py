@@ -977,9 +977,11 @@ class SIU3RModel:
                 def capture(name, fn):
                     g = torch.cuda.CUDAGraph()
                     # thread_local: only this thread's calls belong to the capture (a RCCL watchdog thread of a multi-GPU job
-                    # must not be able to invalidate it)
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                        fn()
+                    # must not be able to invalidate it).  The chain's split-K workspace is its own (the chain graphs replay
+                    # concurrently) and exists before the capture starts (no fill node in the graph).
+                    with ops.splitk_scope((id(self), key, name), ctx.dev):
+                        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                            fn()
                     ent["graphs"][name] = g
 
                 try:

@@ -192,73 +192,83 @@ def kernel_timer_active() -> bool:
     return _timer is not None
 
 
-_SPLITK = __import__("os").environ.get("SIU3R_NO_SPLITK", "0") != "1"
-SPLITK_FILL = 512      # workgroup slots of the 128 x 64 kernels on the chip (256 CUs x 2)
-SPLITK_MAX_TILES = 160  # launches with at least this many tiles keep the whole K in one workgroup
+# ---- split-K workspace.  The library decides tile and K split (siu3r_gemm_plan); the caller lends it one workspace per STREAM: fp32
+# slabs plus int32 tickets that are zero at allocation and that every split launch leaves zero again (the tile's last arriver resets its
+# ticket), so launches on one stream reuse them back to back without a fill kernel; launches on different streams may overlap and get
+# different workspaces.
+# A HIP-graph capture is its own scope (splitk_scope): torch captures every graph on the same internal stream, and the chain graphs of a
+# forward replay concurrently.
+SPLITK_WS_FLOATS = 16 * 1024 * 1024   # 64 MiB of slabs per stream / scope
+SPLITK_COUNTERS = 8192
+_sk_pool: dict = {}
+_sk_scope = None
 
 
-def _x3_dma(p: GemmParams) -> bool:
-    """does the launcher put this bf16x3 problem on the LDS-DMA kernel? (mirrors siu3r_gemm_dma_x3_launch, sizes below 4 GiB assumed)"""
-    if not p.w_x3 or p.a_dtype != F32:
-        return False
-    if p.a_mode == 0:
-        return not p.relu_in
-    if p.a_mode == 1:
-        return p.cin % 4 == 0 and ((p.cin % 32 == 0 and p.kh * p.kw <= 31) or not p.relu_in)
-    return False
+class splitk_scope:
+    """with splitk_scope(tag): GEMMs launched inside use the split-K workspace of `tag` (allocated and zeroed on entry, i.e. BEFORE a
+    graph capture that the caller opens inside the block) instead of the current stream's."""
+
+    def __init__(self, tag, dev):
+        self.tag, self.dev = ("scope", tag), dev
+
+    def __enter__(self):
+        global _sk_scope
+        self.prev, _sk_scope = _sk_scope, self.tag
+        _splitk_workspace(self.dev)
+        return self
+
+    def __exit__(self, *exc):
+        global _sk_scope
+        _sk_scope = self.prev
 
 
-def _pick_splitk(p: GemmParams, dev):
-    """Few tiles and a long K: cut K over several workgroups (siu3r_gemm_params.splitk).  Mirrors the launcher's choice of the
-    LDS-DMA kernels (the register-staged fallbacks ignore the request).  Returns the tensors that must stay alive."""
-    if not _SPLITK:
-        return None
-    x3 = _x3_dma(p)
-    bf = p.a_dtype == BF16 and not p.w_lo and not (p.relu_in and not (p.a_mode == 1 and p.cin % 64 == 0 and p.kh * p.kw <= 32 and p.kpad == p.k))
-    if not (x3 or bf):
-        return None
-    tiles = ((p.m + 127) // 128) * ((p.n + 63) // 64) * max(1, p.batch)
-    if tiles >= SPLITK_MAX_TILES:
-        return None
-    nkt = p.kpad // 64  # (the x3 kernel's tiles are 32 deep, but the split is validated against kpad / 64)
-    S = min(8, nkt // (4 if x3 else 8), (SPLITK_FILL + tiles - 1) // tiles)  # every slice keeps >= 8 K steps
-    if S < 2:
-        return None
-    ws = torch.empty((tiles * S * 8192,), dtype=torch.float32, device=dev)
-    cnt = torch.zeros((tiles,), dtype=torch.int32, device=dev)
-    p.splitk, p.sk_ws, p.sk_cnt = S, ws.data_ptr(), cnt.data_ptr()
-    return ws, cnt
+def _splitk_workspace(dev):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _sk_scope or torch.cuda.current_stream().cuda_stream)
+    ws = _sk_pool.get(key)
+    if ws is None:
+        ws = (torch.empty((SPLITK_WS_FLOATS,), dtype=torch.float32, device=dev), torch.zeros((SPLITK_COUNTERS,), dtype=torch.int32, device=dev))
+        _sk_pool[key] = ws
+    return ws
+
+
+def gemm_plan(p: GemmParams) -> "_lib.GemmPlan":
+    pl = _lib.GemmPlan()
+    check(_lib.lib().siu3r_gemm_plan(C.byref(p), C.byref(pl)))
+    return pl
+
+
+_plan_log: Optional[list] = None  # tests / tools: when a list, every GEMM launch appends its siu3r_gemm_plan_t
+
+
+def set_plan_log(log: Optional[list]):
+    global _plan_log
+    _plan_log = log
+
+
+def gemm_tune(key: int, value: int):
+    """siu3r_gemm_tune: 0 = default tile_cfg (0 auto, -1 128x64 family, 1..3 ping-pong 256x256 / 256x128 / 128x128), 1 = no skinny rows, 2 = no split-K"""
+    check(_lib.lib().siu3r_gemm_tune(key, value))
 
 
 def _gemm_launch(p: GemmParams, dev=None):
-    keep = _pick_splitk(p, dev if dev is not None else torch.device("cuda", torch.cuda.current_device()))
+    if p.splitk == 0:
+        ws, cnt = _splitk_workspace(dev if dev is not None else torch.device("cuda", torch.cuda.current_device()))
+        p.sk_ws, p.sk_cnt, p.sk_ws_floats, p.sk_cnt_n = ws.data_ptr(), cnt.data_ptr(), ws.numel(), cnt.numel()
+    if _plan_log is not None:
+        _plan_log.append(gemm_plan(p))
     if _timer is None:
         check(_lib.lib().siu3r_gemm(C.byref(p), _stream()))
-        del keep
         return
-    # label with the kernel the launcher will pick (mirrors gemm.hip / gemm_dma.hip dispatch) so that the event
-    # averages line up with rocprofv3's per-kernel rows
-    tf = lambda b: "true" if b else "false"
-    lnf = bool(p.ln_stats)
-    if _x3_dma(p):
-        mode = 0 if p.a_mode == 0 else (1 if (p.cin % 32 == 0 and p.kh * p.kw <= 31) else 2)
-        variant = f"gemm_dma_x3_kernel<{mode}, {tf(p.relu_in and mode == 1)}, 2, {tf(lnf and mode == 0)}>"
-    elif p.w_lo:
-        variant = "gemm_kernel<1, 1, 1>"
-    elif p.a_dtype == F32 or p.a_mode == 2:
-        variant = "gemm_kernel<1, 0, 1>"
-    elif p.a_mode == 0:
-        variant = f"gemm_dma_kernel<1, 0, false, 2, {tf(lnf)}>" if not p.relu_in else "gemm_kernel<0, 0, 1>"
-    elif p.cin % 64 == 0 and p.kh * p.kw <= 32 and p.kpad == p.k:
-        variant = f"gemm_dma_kernel<1, 1, {tf(p.relu_in)}, 2, false>"
-    else:
-        variant = "gemm_dma_kernel<1, 2, false, 2, false>" if not p.relu_in else "gemm_kernel<0, 0, 1>"
+    # label with the kernel the launcher picks, so that the event averages line up with rocprofv3's per-kernel rows
+    pl = gemm_plan(p)
+    variant = pl.kernel.decode()
     flops = 2.0 * p.m * p.n * p.k * max(1, p.batch)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     check(_lib.lib().siu3r_gemm(C.byref(p), _stream()))
     e1.record()
-    _timer.records.append((variant, flops, e0, e1, (p.m, p.n, p.k, max(1, p.batch), p.a_mode, p.out_mode, p.kh)))
+    _timer.records.append((variant, flops, e0, e1, (p.m, p.n, p.k, max(1, p.batch), p.a_mode, p.out_mode, p.kh, pl.tile_cfg, pl.splitk, pl.skinny_rows,
+                                                    int(bool(p.ln_stats)), int(bool(p.rope_cos)), int(bool(p.residual)))))
 
 
 _trace_buf: Optional[torch.Tensor] = None  # tools/gemm_trace.py: int64 [workgroups, 8] stamp buffer (tuning only)

@@ -625,43 +625,50 @@ def test_gemm_grouped_two_sides(mode):
     assert float((part[:, :, 0].mean(1) - o2.cpu().view(-1, N).mean(1)).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("tile", [-1, 2, 3], ids=["t128x64", "pp256x128", "pp128x128"])
 @pytest.mark.parametrize("mode", [MODES[0], MODES[2]], ids=["bf16", "bf16x3"])
-def test_gemm_split_k(mode):
+def test_gemm_split_k(mode, tile):
     """Few tiles + long K -> K is cut over several workgroups (slabs + ticket, slices summed in order): same values as the unsplit
-    kernel up to fp32 summation order, bit-identical run to run, every epilogue feature still applied once (bias, GELU, residual,
-    row statistics), dense and 3x3-conv addressing."""
-    import os
-
+    kernel up to fp32 summation order, bit-identical run to run (the tickets reset themselves: the second launch reuses the stream's
+    workspace), every epilogue feature still applied once (bias, GELU, residual, row statistics), dense and 3x3-conv addressing;
+    for the 128 x 64 kernels and the ping-pong tiles."""
     ops = _ops()
     name, adt, split, tol = mode
     M, N, K = 200, 136, 4608
     a, w, b, r = gen(M, K, seed=71), gen(N, K, seed=72, scale=0.05), gen(N, seed=73), gen(M, N, seed=74)
     pw = ops.pack_linear(w.cuda(), b.cuda(), split)
     ref = F.gelu(a.to(adt).float() @ w.t() + b) + r
-    assert ops._SPLITK
-    p = ops.GemmParams()
-    p.m, p.n, p.kpad, p.batch, p.a_dtype, p.w_x3, p.a_mode = M, N, pw.kpad, 1, ops._dt(a.to(adt)), (1 if split else 0), 0
-    assert ops._pick_splitk(p, torch.device("cuda")) is not None and p.splitk >= 2, "this shape is meant to take the split-K path"
-    out = torch.empty(M, N, device="cuda")
-    st = ops.RowStats(out)
-    ops.linear(a.cuda().to(adt), pw, act=ops.ACT_GELU, residual=r.cuda(), out=out, stats_out=st)
-    check(f"split_k[{name}] dense gelu+residual", out, ref, tol)
-    out2 = ops.linear(a.cuda().to(adt), pw, out_dtype=torch.float32, act=ops.ACT_GELU, residual=r.cuda())
-    assert torch.equal(out, out2), "split-K must be deterministic"
-    part = st.buf.cpu()
-    cnt = torch.tensor([64, 64, 8.0])
-    assert float(((part[:, :, 0] * cnt).sum(1) / N - out.cpu().mean(1)).abs().max()) <= 1e-5
-    ops._SPLITK = False
+    log = []
+    ops.gemm_tune(0, tile)
+    ops.set_plan_log(log)
     try:
-        whole = ops.linear(a.cuda().to(adt), pw, out_dtype=torch.float32, act=ops.ACT_GELU, residual=r.cuda())
+        out = torch.empty(M, N, device="cuda")
+        st = ops.RowStats(out)
+        ops.linear(a.cuda().to(adt), pw, act=ops.ACT_GELU, residual=r.cuda(), out=out, stats_out=st)
+        assert log[-1].tile_cfg == tile and log[-1].splitk >= 2, f"this shape is meant to take the split-K path ({log[-1].tile_cfg}, {log[-1].splitk})"
+        check(f"split_k[{name}] dense gelu+residual", out, ref, tol)
+        out2 = ops.linear(a.cuda().to(adt), pw, out_dtype=torch.float32, act=ops.ACT_GELU, residual=r.cuda())
+        assert torch.equal(out, out2), "split-K must be deterministic"
+        part = st.buf.cpu()
+        cnt = torch.tensor([64, 64, 8.0])
+        assert float(((part[:, :, 0] * cnt).sum(1) / N - out.cpu().mean(1)).abs().max()) <= 1e-5
+        ops.gemm_tune(2, 1)
+        try:
+            whole = ops.linear(a.cuda().to(adt), pw, out_dtype=torch.float32, act=ops.ACT_GELU, residual=r.cuda())
+            assert log[-1].splitk == 1
+        finally:
+            ops.gemm_tune(2, 0)
+        assert float((out - whole).abs().max()) <= 1e-4 * float(whole.abs().max())
+        # 3x3 convolution, 256 input channels, small image: 8 tiles, K = 2304
+        x = gen(2, 256, 16, 16, seed=75)
+        wc, bc = gen(96, 256, 3, 3, seed=76, scale=0.05), gen(96, seed=77)
+        pc = ops.pack_conv(wc.cuda(), bc.cuda(), split)
+        xg = x.permute(0, 2, 3, 1).contiguous().cuda().to(adt)
+        refc = F.conv2d(F.relu(x.to(adt).float()), wc, bc, padding=1).permute(0, 2, 3, 1)
+        outc = ops.conv2d(xg, pc, pad=1, out_dtype=torch.float32, relu_in=True)
+        check(f"split_k[{name}] conv3x3 relu_in", outc, refc, tol)
+        assert log[-1].splitk >= 2
     finally:
-        ops._SPLITK = True
-    assert float((out - whole).abs().max()) <= 1e-4 * float(whole.abs().max())
-    # 3x3 convolution, 256 input channels, small image: 8 tiles, K = 2304
-    x = gen(2, 256, 16, 16, seed=75)
-    wc, bc = gen(96, 256, 3, 3, seed=76, scale=0.05), gen(96, seed=77)
-    pc = ops.pack_conv(wc.cuda(), bc.cuda(), split)
-    xg = x.permute(0, 2, 3, 1).contiguous().cuda().to(adt)
-    refc = F.conv2d(F.relu(x.to(adt).float()), wc, bc, padding=1).permute(0, 2, 3, 1)
-    outc = ops.conv2d(xg, pc, pad=1, out_dtype=torch.float32, relu_in=True)
-    check(f"split_k[{name}] conv3x3 relu_in", outc, refc, tol)
+        ops.set_plan_log(None)
+        ops.gemm_tune(0, 0)
+

@@ -1,5 +1,2 @@
 cd $GRAFT_REPO_ROOT
-L=$PWD/siu3r_amd/libsiu3r_hip_
-for t in xw1 xw0; do for sh in "4096 4096 4096" "8192 8192 1024"; do SIU3R_LIB_OVERRIDE=${L}$t.so python tools/mb_one.py bf16x3 $sh 1 2>&1 | tail -1; done; done
-for t in bw1 bw0; do for sh in "4096 4096 4096" "8192 8192 1024"; do SIU3R_LIB_OVERRIDE=${L}$t.so python tools/mb_one.py bf16 $sh 1 2>&1 | tail -1; done; done
-python tools/mb_pp.py check 2>&1 | grep -v " ok$" | tail -5
+for sh in "1025 3072 768" "1024 3072 768" "1025 2304 768" "2050 3072 768" "1281 3072 768"; do for c in -1 2 3; do python tools/mb_one.py bf16x3 $sh $c 2>&1 | tail -1; done; done

@@ -13,6 +13,14 @@ a = (torch.rand(M, K, device="cuda") * 2 - 1).to(adt)
 pw = ops.pack_linear((torch.rand(N, K, device="cuda") * 2 - 1) * 0.1, torch.zeros(N, device="cuda"), split)
 out = torch.empty(M, N, device="cuda", dtype=adt)
 _lib.check(_lib.lib().siu3r_gemm_tune(0, cfg))
+log = []
+ops.set_plan_log(log)
+ops.linear(a, pw, out=out)
+ops.set_plan_log(None)
+pl = log[-1]
+print(f"plan: tile_cfg={pl.tile_cfg} {pl.bm}x{pl.bn} splitk={pl.splitk} skinny_rows={pl.skinny_rows} {pl.kernel.decode()}")
+if len(sys.argv) > 6:
+    ops.gemm_tune(int(sys.argv[6]), int(sys.argv[7]))
 ts = [graph_time(lambda: ops.linear(a, pw, out=out), n=10) for _ in range(3)]
 t = min(ts)
 print(f"{os.environ.get('SIU3R_LIB_OVERRIDE', 'base'):>40} {mode} {M}x{N}x{K} cfg={cfg}: {t*1e6:8.1f} us {2.0*M*N*K/t/1e12:7.1f} TF/s (runs {[round(x*1e6,1) for x in ts]})")

@@ -10,7 +10,7 @@ import torch
 from siu3r_amd import _lib, ops
 from mb_gemm import graph_time
 
-CFG = {-1: "128x64", 1: "pp256x256", 2: "pp256x128", 3: "pp128x128"}
+CFG = {0: "auto", -1: "128x64", 1: "pp256x256", 2: "pp256x128", 3: "pp128x128"}
 
 
 def tune(v):
@@ -29,7 +29,8 @@ def check():
         adt = torch.float32 if split else torch.bfloat16
         tol = 2e-5 if split else 1.5e-2
         for (M, N, K, act, res) in [(512, 512, 256, 0, False), (300, 520, 1024, 1, True), (2050, 1024, 1024, 0, True), (1025, 768, 3072, 0, False),
-                                    (256, 256, 64, 0, False), (777, 264, 136, 2, False), (4096, 4096, 512, 0, False)]:
+                                    (256, 256, 64, 0, False), (777, 264, 136, 2, False), (4096, 4096, 512, 0, False), (2050, 520, 1024, 1, True),
+                                    (1025, 768, 768, 0, True), (30, 256, 512, 0, False), (2, 136, 4096, 0, True), (16400, 256, 128, 0, False)]:
             a = (torch.rand(M, K, device="cuda") * 2 - 1)
             w = (torch.rand(N, K, device="cuda") * 2 - 1) * 0.1
             b = torch.rand(N, device="cuda")
@@ -43,7 +44,7 @@ def check():
                 ref = torch.relu(ref)
             if res:
                 ref = ref + r
-            for cfg in (1, 2, 3):
+            for cfg in (0, 1, 2, 3):
                 tune(cfg)
                 out = ops.linear(ax, pw, act=act, residual=r, out_dtype=torch.float32)
                 e = rel(out, ref)
@@ -83,7 +84,7 @@ def bench(big):
             a = (torch.rand(M, K, device="cuda") * 2 - 1).to(adt)
             pw = ops.pack_linear((torch.rand(N, K, device="cuda") * 2 - 1) * 0.1, torch.zeros(N, device="cuda"), split)
             out = torch.empty(M, N, device="cuda", dtype=adt)
-            for cfg in (-1, 1, 2, 3):
+            for cfg in (0, -1, 1, 2, 3):
                 tune(cfg)
                 t = graph_time(lambda: ops.linear(a, pw, out=out), n=10)
                 tf = 2.0 * M * N * K / t / 1e12
@@ -92,7 +93,7 @@ def bench(big):
         # the full-resolution 3x3 convolution of the Gaussian heads
         x = (torch.rand(1, 512, 512, 256, device="cuda") * 2 - 1).to(adt)
         pw = ops.pack_conv((torch.rand(256, 256, 3, 3, device="cuda") * 2 - 1) * 0.1, torch.zeros(256, device="cuda"), split)
-        for cfg in (-1, 1, 2, 3):
+        for cfg in (0, -1, 1, 2, 3):
             tune(cfg)
             t = graph_time(lambda: ops.conv2d(x, pw, pad=1, out_dtype=adt), n=5)
             tf = 2.0 * 262144 * 256 * 2304 / t / 1e12

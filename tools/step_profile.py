@@ -30,8 +30,12 @@ ops.set_kernel_timer(None)
 rows = sorted(tm.by_shape().items(), key=lambda kv: -kv[1]["ms"])
 tot = sum(v["ms"] for _, v in rows)
 print(f"gemm total {tot:.2f} ms in {sum(v['launches'] for _, v in rows)} launches")
-print("variant        M      N      K   Z am om kh |  n   ms_tot  us_each  TFLOP/s  tiles128x64")
-for k, v in rows[:45]:
-    var, m, n, kk, z, am, om, kh = k
-    tiles = ((m + 127) // 128) * ((n + 63) // 64) * z
-    print(f"{var:11s} {m:6d} {n:6d} {kk:6d} {z:3d} {am:2d} {om:2d} {kh:2d} | {v['launches']:3d} {v['ms']:7.3f} {v['ms']/v['launches']*1e3:8.1f} {v['flops']/v['ms']/1e9:8.1f} {tiles:6d}")
+print("     M      N      K   Z am om kh cfg  S sk ln rp rs |  n   ms_tot  us_each  TFLOP/s")
+import json
+out = []
+for k, v in rows[:60]:
+    var, m, n, kk, z, am, om, kh, cfg, S, sk, ln, rp, rs = k
+    print(f"{m:6d} {n:6d} {kk:6d} {z:3d} {am:2d} {om:2d} {kh:2d} {cfg:3d} {S:2d} {sk:2d} {ln:2d} {rp:2d} {rs:2d} | {v['launches']:3d} {v['ms']:7.3f} {v['ms']/v['launches']*1e3:8.1f} {v['flops']/v['ms']/1e9:8.1f}")
+    out.append(dict(m=m, n=n, k=kk, z=z, a_mode=am, out_mode=om, kh=kh, cfg=cfg, splitk=S, skinny=sk, ln=ln, rope=rp, res=rs, launches=v['launches'], ms=v['ms']))
+if len(sys.argv) > 3:
+    json.dump(out, open(sys.argv[3], "w"), indent=0)
