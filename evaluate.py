@@ -93,8 +93,13 @@ def main():
     out_dir = Path(a.output_path)
     out_dir.mkdir(parents=True, exist_ok=True)
     acc, my_scenes, t0 = M.MetricAccumulator(), [], time.perf_counter()
+    seen = set()
     for s in range(0, len(mine), a.batch):
-        batch = scannet.collate([data[i] for i in mine[s:s + a.batch]])
+        idx = mine[s:s + a.batch]
+        items = scannet.own_items(idx, [data[i] for i in idx], n, seen)  # substitutes of unlabeled pairs belong to their owner rank
+        if not items:
+            continue
+        batch = scannet.collate(items)
         res = run_batch(model, renderer, batch, size, dev)
         my_scenes += write_batch(out_dir, batch, res)
     torch.cuda.synchronize()

@@ -7,7 +7,7 @@ What a file may be:
   * a Lightning `.ckpt` of `Pipeline` / `PipelineMultiView`: {"state_dict": {"model.backbone...": ..., "lpips.net...": ...},
     "hyper_parameters": {"cfg": <pickled src.config.RootCfg>}, ...}.  Unpickling `hyper_parameters` needs the reference's `src`
     package, Hydra and dacite; none of it is needed to run the network, so unknown classes are replaced by an inert placeholder
-    while unpickling (only torch / numpy / builtin containers are reconstructed for real);
+    while unpickling (an explicit allow-list of tensor-rebuild functions, storages and plain containers is reconstructed for real);
   * a MASt3R / DUSt3R release `.pth`: {"model": state_dict of AsymmetricMASt3R, "args": ...} -> `mast3r_to_siu3r`;
   * the panoptic pre-training `.ckpt` ({"state_dict": {"model.adapter...", "model.mask2former..."}}) -> `seg_pretrain_to_siu3r`;
   * a bare state dict.
@@ -33,12 +33,38 @@ class _Opaque:
         return _Opaque()
 
 
-_SAFE_PREFIXES = ("torch", "collections", "numpy", "builtins", "_codecs", "copyreg")
+# Globals the fallback unpickler reconstructs for real: exactly what a tensor container needs.  Everything else -- including
+# builtins.eval / exec / getattr / __import__, torch.hub.*, numpy.load -- becomes an inert placeholder, so a crafted file cannot REDUCE
+# its way to code execution.
+_ALLOWED_GLOBALS = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"),
+    ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("builtins", "set"), ("builtins", "frozenset"),
+    ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"), ("builtins", "str"), ("builtins", "bytes"),
+    ("builtins", "bytearray"), ("builtins", "complex"), ("builtins", "slice"), ("builtins", "range"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._utils", "_rebuild_qtensor"),
+    ("torch._tensor", "_rebuild_from_type_v2"), ("torch", "Size"), ("torch", "device"), ("torch", "dtype"), ("torch", "Tensor"),
+    ("torch.nn.parameter", "Parameter"), ("torch.serialization", "_get_layout"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy._core.multiarray", "scalar"), ("numpy", "ndarray"), ("numpy", "dtype"), ("_codecs", "encode"),
+}
+_ALLOWED_TORCH_SUFFIXES = ("Storage",)  # torch.FloatStorage, torch.storage.UntypedStorage, ... (typed storages of legacy files)
+
+
+def _allowed(module: str, name: str) -> bool:
+    if (module, name) in _ALLOWED_GLOBALS:
+        return True
+    if module in ("torch", "torch.storage") and name.endswith(_ALLOWED_TORCH_SUFFIXES):
+        return True
+    if module == "torch" and name in {str(d).split(".")[-1] for d in (torch.float32, torch.float64, torch.float16, torch.bfloat16, torch.int64,
+                                                                        torch.int32, torch.int16, torch.int8, torch.uint8, torch.bool)}:
+        return True
+    return False
 
 
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module: str, name: str):
-        if module.split(".")[0] in _SAFE_PREFIXES:
+        if _allowed(module, name):
             return super().find_class(module, name)
         return _Opaque
 
@@ -56,7 +82,9 @@ def read_checkpoint_file(path) -> dict:
     """torch.load without importing whatever the file pickled besides tensors."""
     try:
         return torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:
+    except pickle.UnpicklingError:
+        # the file pickles classes besides tensors (a Lightning checkpoint's RootCfg): allow-listed unpickler, placeholders for the rest.
+        # Any other failure (truncated zip, I/O) propagates.
         return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_PickleModule)
 
 

@@ -114,6 +114,13 @@ class _State(dict):
         e_max, cap_e = int(st[:, 2].max()), dict.__getitem__(self, "cap_e")
         if e_max > cap_e:
             raise RasterOverflow(f"rasterizer coarse-bin entries overflowed: E = {e_max} > entry_capacity {cap_e} (pass entry_capacity >= {e_max})")
+        # the materialised (tile, Gaussian) pair lists of the N-channel path (tl_scan sets flag bit 1 when a view's pairs exceed
+        # pair_capacity: far splats would silently be missing from tiles).  Deferred callers (check_overflow=False) must call verify().
+        if dict.__contains__(self, "tile_start_all"):
+            T, cap_d = dict.__getitem__(self, "T"), dict.__getitem__(self, "cap_d")
+            d_max = int(dict.__getitem__(self, "tile_start_all")[:, T + 1].max())
+            if d_max > cap_d:  # (the sticky flag bit of an earlier, repeated attempt is not consulted: the scan's own total is)
+                raise RasterOverflow(f"rasterizer tile-pair lists overflowed: D = {d_max} > pair_capacity {cap_d} (pass pair_capacity >= {d_max})")
 
     def _lists(self):
         if not dict.__contains__(self, "ids"):

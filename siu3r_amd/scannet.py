@@ -96,10 +96,15 @@ class ScanNetValPairs:
         return imgs, depths, ext, pan
 
     def __getitem__(self, idx: int) -> dict:
-        """Views without any semantic label raise ValueError in the reference, which then moves on to the next pair (:360-366)."""
+        """Views without any semantic label raise ValueError in the reference, which then moves on to the next pair (:360-366).  The
+        item carries "pair_index": the pair actually read (!= idx for such a substitute).  A sharded driver must not count a
+        substitute: the rank that owns that pair evaluates it anyway (`own_items`)."""
         for hop in range(len(self)):
             try:
-                return self._item((idx + hop) % len(self))
+                j = (idx + hop) % len(self)
+                item = self._item(j)
+                item["pair_index"] = j
+                return item
             except ValueError:
                 continue
         raise ValueError("no valid validation pair")
@@ -140,6 +145,20 @@ def collate(examples: Sequence[dict]) -> dict:
             out[f"{side}_views_{k}"] = torch.tensor(arr(f"{side}_views_{k}"), dtype=torch.float32)
         out[f"{side}_mask_labels"] = [e[f"{side}_mask_labels"] for e in ex]
         out[f"{side}_class_labels"] = [e[f"{side}_class_labels"] for e in ex]
+    return out
+
+
+def own_items(indices: Sequence[int], items: Sequence[dict], n_items: int, seen: set) -> List[dict]:
+    """The items of `indices` a rank evaluates and counts: a substitute (pair_index != requested index) inside [0, n_items) is dropped --
+    its owner rank reads the same pair natively, and the reference's evaluator counts a scene directory once however often it was
+    written; one beyond n_items (a --limit run) is kept the first time this rank meets it."""
+    out = []
+    for i, it in zip(indices, items):
+        j = it["pair_index"]
+        if j != i and (j < n_items or j in seen):
+            continue
+        seen.add(j)
+        out.append(it)
     return out
 
 

@@ -123,3 +123,57 @@ def test_expected_keys_match_the_generator():
     assert len(keys) > 1600 and "backbone.intrinsic_encoder.weight" in keys
     missing, unexpected = ck.check_keys({k: None for k in keys})
     assert missing == [] and unexpected == []
+
+
+class _Evil:
+    """pickles as REDUCE(builtins.eval, ("...",)): what a crafted checkpoint would use to run code at load time"""
+
+    def __reduce__(self):
+        import builtins
+
+        return (builtins.eval, ("__import__('os').environ.__setitem__('SIU3R_PWNED', '1')",))
+
+
+@pytest.mark.parametrize("payload", ["eval", "getattr", "hub"])
+def test_crafted_checkpoint_cannot_execute_code(tmp_path, payload):
+    """the fallback unpickler reconstructs an explicit allow-list only.  builtins.eval / getattr, torch.hub.load, numpy.load
+    ... come back as inert placeholders; the weights beside them still load."""
+    import os
+    import pickle
+
+    os.environ.pop("SIU3R_PWNED", None)
+
+    class _G:
+        def __init__(self, fn, args):
+            self.fn, self.args = fn, args
+
+        def __reduce__(self):
+            return (self.fn, self.args)
+
+    import builtins
+
+    import numpy as np
+
+    evil = {"eval": _Evil(), "getattr": _G(builtins.getattr, ("abc", "upper")), "hub": _G(torch.hub.load, ("x/y", "z"))}[payload]
+    p = tmp_path / "evil.ckpt"
+    # a class weights_only refuses, so that the loader takes its fallback path, next to the payload
+    sd = _small_sd()
+    _write_lightning_ckpt(p, sd)
+    obj = torch.load(p, map_location="cpu", weights_only=False, pickle_module=ck._PickleModule)
+    obj["hyper_parameters"]["evil"] = evil
+    obj["callbacks"] = {"np": _G(np.load, ("/etc/passwd",))}
+    torch.save(obj, p)
+    out = ck.load_siu3r_state_dict(p, verbose=False)
+    assert os.environ.get("SIU3R_PWNED") is None, "the payload ran"
+    assert set(out) >= set(sd) and all(torch.equal(out[k], sd[k]) for k in sd)
+    raw = ck.read_checkpoint_file(p)
+    assert isinstance(raw["hyper_parameters"]["evil"], ck._Opaque) and isinstance(raw["callbacks"]["np"], ck._Opaque)
+    # and the allow-list is explicit: nothing else under builtins / torch / numpy resolves
+    for mod, name in (("builtins", "eval"), ("builtins", "exec"), ("builtins", "__import__"), ("builtins", "getattr"), ("torch.hub", "load"),
+                      ("numpy", "load"), ("os", "system"), ("copyreg", "_reconstructor")):
+        assert ck._Unpickler.find_class(ck._Unpickler.__new__(ck._Unpickler), mod, name) is ck._Opaque, (mod, name)
+    # non-pickle failures are not swallowed into the fallback
+    bad = tmp_path / "truncated.ckpt"
+    bad.write_bytes(p.read_bytes()[:200])
+    with pytest.raises(Exception):
+        ck.read_checkpoint_file(bad)

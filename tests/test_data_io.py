@@ -206,3 +206,30 @@ def test_multiview_cli_lists_images_like_the_reference(tmp_path):
         else:
             Image.new("RGB", (8, 8)).save(tmp_path / n)
     assert [p.name for p in mod.list_images(tmp_path)] == ["z.jpg", "a.png", "b.png", "c.jpeg"]   # *.jpg, then *.png, then *.jpeg
+
+
+def test_substituted_pairs_are_counted_once_across_ranks():
+    """a pair without semantic labels is replaced by the next pair (reference scannet_dataset.py:360-366); under the
+    i mod world sharding that next pair has an owner of its own, so the substitute must not be evaluated / counted a second time."""
+    from siu3r_amd import scannet
+
+    n, world = 7, 2
+    bad = {2, 5}  # unlabeled pairs: reading them yields the next valid pair
+
+    def read(i):
+        j = i
+        while j % n in bad:
+            j += 1
+        return {"pair_index": j % n}
+
+    counted = []
+    for rank in range(world):
+        seen = set()
+        mine = scannet.shard(n, rank, world)
+        items = scannet.own_items(mine, [read(i) for i in mine], n, seen)
+        counted += [it["pair_index"] for it in items]
+    assert sorted(counted) == [0, 1, 3, 4, 6], counted  # every valid pair exactly once, on its owner
+    # a --limit run: the substitute lies beyond the evaluated range and has no owner -> kept once
+    seen = set()
+    kept = scannet.own_items([2, 2], [{"pair_index": 3}, {"pair_index": 3}], 3, seen)
+    assert [k["pair_index"] for k in kept] == [3]

@@ -249,8 +249,9 @@ def test_multiview_eight_views_and_batched_views_against_oracle():
         for f in ("means", "covariances", "harmonics", "opacities", "scales", "rotations"):
             _report(f"multi B={B} V={V} {f}", getattr(g, f), ref[f], 1e-3, 1e-3, fails)
         # (the logits pass through nine thresholded attention masks: a borderline pixel may flip between fp32 evaluation orders)
-        _report(f"multi B={B} V={V} class logits", seg.class_queries_logits, ref["class_queries_logits"], 1e-2, 1e-2, fails)
-        _report(f"multi B={B} V={V} mask logits", seg.masks_queries_logits, ref["masks_queries_logits"], 1e-2, 1e-2, fails)
+        # (the smallest bound that holds: 5e-3, the thresholded-mask caveat of test_parity_sweep; the measured value is printed)
+        _report(f"multi B={B} V={V} class logits", seg.class_queries_logits, ref["class_queries_logits"], 5e-3, 5e-3, fails)
+        _report(f"multi B={B} V={V} mask logits", seg.masks_queries_logits, ref["masks_queries_logits"], 5e-3, 5e-3, fails)
         assert not fails, fails
         assert torch.equal(outs[0][0].means, g.means) and torch.equal(outs[0][1].masks_queries_logits, seg.masks_queries_logits)
         agree = float((g.semantic_labels.cpu() == ref["semantic_labels"]).float().mean())
@@ -260,7 +261,8 @@ def test_multiview_eight_views_and_batched_views_against_oracle():
         torch.cuda.empty_cache()
 
 
-def test_inference_cli_writes_ply(tmp_path):
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_inference_cli_writes_ply(tmp_path, precision):
     """inference.py (reference inference.py:41-150 counterpart) end to end: two image files -> output.ply with the
     reference's vertex schema and one vertex per pixel of both views."""
     import subprocess
@@ -277,7 +279,7 @@ def test_inference_cli_writes_ply(tmp_path):
     for i in (0, 1):
         Image.fromarray(np.ascontiguousarray(pair[i])).resize((320, 288)).save(tmp_path / f"v{i}.png")
     out = subprocess.run([sys.executable, os.path.join(root, "inference.py"), "--image_path1", str(tmp_path / "v0.png"), "--image_path2", str(tmp_path / "v1.png"),
-                          "--output_path", str(tmp_path / "out"), "--size", "128", "--precision", "bf16"], capture_output=True, text=True, timeout=600, cwd=root)
+                          "--output_path", str(tmp_path / "out"), "--size", "128", "--precision", precision], capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stdout + out.stderr
     v = read_ply_vertices(tmp_path / "out" / "output.ply")
     assert len(v) == 2 * 128 * 128
@@ -339,5 +341,76 @@ def test_batch_of_pairs_matches_single_pairs():
         assert float((gb.semantic_labels[i] == gs_.semantic_labels[0]).float().mean()) >= 0.995
         assert float((gb.instance_labels[i] == gs_.instance_labels[0]).float().mean()) >= 0.995
         assert [(s_["id"], s_["label_id"], s_["was_fused"]) for s_ in outs[0][3][i]] == [(s_["id"], s_["label_id"], s_["was_fused"]) for s_ in singles[i][3][0]]
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_forward_through_the_checkpoint_loader(tmp_path):
+    """SURVEY 8(f)1 on the GPU (reference inference.py:119-136: Pipeline.load_from_checkpoint -> pipeline.model(images, intrinsics)): the
+    655 M-parameter synthetic state dict is written as a Lightning-shaped .ckpt (`model.` prefix, metric modules, a pickled config class
+    that cannot be imported), read back by load_siu3r_state_dict, and the loaded weights drive SIU3RModel at 256^2 in the benchmarked
+    bf16x3 mode to the REFERENCE's golden outputs at 1e-3."""
+    from golden_utils import FIELDS, compare_summary, default_K, fixture_images, load_model_fixture, segments_match
+    from oracle import weights as OW
+    from siu3r_amd import checkpoint as ck
+    from siu3r_amd.model import SIU3RModel
+    from test_checkpoint import _write_lightning_ckpt
+
+    if "sd" not in _STATE:
+        _STATE["sd"] = OW.make_weights(0)
+    path = tmp_path / "siu3r_epoch100.ckpt"
+    _write_lightning_ckpt(path, _STATE["sd"])
+    sd = ck.load_siu3r_state_dict(path, verbose=False)
+    assert set(sd) == set(_STATE["sd"]) and not any(k.startswith(("lpips.", "psnr.", "model.")) for k in sd)
+    z, meta = load_model_fixture(256)
+    model = SIU3RModel(sd, image_size=(256, 256), precision="bf16x3")
+    with torch.no_grad():
+        g, seg, masks, infos, qs = model(fixture_images(256).cuda(), default_K().cuda(), enable_query_class_logit_lift=True)
+    for f in FIELDS:
+        compare_summary(f, getattr(g, f), z, 1e-3)
+    compare_summary("class_queries_logits", seg.class_queries_logits, z, 1e-3)
+    compare_summary("masks_queries_logits", seg.masks_queries_logits, z, 1e-3)
+    segments_match(infos, meta["seg_infos"], 2e-6 + 1e-3 * 0.05)
+
+
+SWEEP = [(1, 2, 64, 64, 1), (1, 2, 96, 160, 2), (1, 2, 160, 96, 3), (2, 2, 64, 96, 4), (1, 3, 96, 96, 5), (1, 4, 64, 64, 6), (1, 2, 224, 224, 7)]
+
+
+@pytest.mark.parametrize("case", SWEEP, ids=[f"B{b}V{v}_{h}x{w}" for (b, v, h, w, _) in SWEEP])
+def test_parity_sweep(case):
+    """The parity statement of bench.py's `config.parity`, driver-verified on seven shapes / seeds (odd aspect ratios, B = 2, V = 3 and 4)
+    against the pinned CPU oracle in the benchmarked bf16x3 mode:
+      * every Gaussian field <= 1e-3 max-normalised (north_star's bar; measured <= 8e-5);
+      * Mask2Former class / mask logits <= 1e-3 on most inputs, and <= 5e-3 when one of the nine THRESHOLDED attention masks
+        (sigmoid(mask) < 0.5, reference video_seg_decoder.py:1306-1308, 1461-1478) flips a borderline pixel between two fp32 evaluation
+        orders -- both logit tensors then move together (measured 1-3e-3 in 3 of 7 cases);
+      * graph replay bit-identical to eager; label maps agree >= 0.995 (argmax over fp32 scores at segment borders)."""
+    from oracle import siu3r_oracle as O
+    from oracle import weights as OW
+    from siu3r_amd.model import SIU3RModel, SIU3RMultiViewModel
+
+    B, V, H, W, seed = case
+    if "sd" not in _STATE:
+        _STATE["sd"] = OW.make_weights(0)
+    sd = _STATE["sd"]
+    gen = torch.Generator().manual_seed(seed)
+    img = torch.rand(B, V, 3, H, W, generator=gen)
+    K = torch.tensor([[318 / 256, 0, 0.5], [0, 318 / 256, 0.5], [0, 0, 1]])[None, None].repeat(B, V, 1, 1)
+    K[:, :, 0, 0] *= 1.0 + 0.1 * torch.rand(B, V, generator=gen)
+    model = (SIU3RModel if V == 2 else SIU3RMultiViewModel)(sd, image_size=(H, W), precision="bf16x3")
+    with torch.no_grad():
+        ref = (O.model_forward if V == 2 else O.model_forward_multi)(sd, img, K, keep_intermediates=False)
+        outs = [model(img.cuda(), K.cuda()) for _ in range(3)]  # eager, capture, replay
+    gs, seg = outs[2][0], outs[2][1]
+    err = lambda a, b: float((a.float().cpu() - b).abs().max() / (b.abs().max() + 1e-30))
+    fields = {f: err(getattr(gs, f), ref[f]) for f in ("means", "covariances", "harmonics", "opacities", "scales", "rotations")}
+    logits = {"class": err(seg.class_queries_logits, ref["class_queries_logits"]), "mask": err(seg.masks_queries_logits, ref["masks_queries_logits"])}
+    agree = min(float((gs.semantic_labels.cpu() == ref["semantic_labels"]).float().mean()), float((gs.instance_labels.cpu() == ref["instance_labels"]).float().mean()))
+    print(f"[parity-sweep] B={B} V={V} {H}x{W}: fields max {max(fields.values()):.2e} ({max(fields, key=fields.get)}), class {logits['class']:.2e}, "
+          f"mask {logits['mask']:.2e}, labels agree {agree:.5f}")
+    assert max(fields.values()) <= 1e-3, fields
+    assert max(logits.values()) <= 5e-3, logits
+    assert agree >= 0.995
+    assert torch.equal(outs[0][0].means, gs.means) and torch.equal(outs[0][1].masks_queries_logits, seg.masks_queries_logits)
     del model
     torch.cuda.empty_cache()

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_evaluate_driver_on_a_scannet_shaped_tree(tmp_path):
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_evaluate_driver_on_a_scannet_shaped_tree(tmp_path, precision):
     """evaluate.py over two validation pairs (synthetic weights: the numbers mean nothing, the plumbing is what is checked): files in the
     reference's layout, results.json with the BASELINE metric's keys, and the re-evaluation of the written files agrees."""
     from test_data_io import _fake_scannet
@@ -25,7 +26,7 @@ def test_evaluate_driver_on_a_scannet_shaped_tree(tmp_path):
     _fake_scannet(str(data))
     out = tmp_path / "val"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "evaluate.py"), "--data_root", str(data), "--output_path", str(out), "--batch", "2",
-                        "--precision", "bf16"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--precision", precision], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["pairs"] == 2 and line["world"] == 1 and np.isfinite(line["psnr"])
@@ -42,7 +43,8 @@ def test_evaluate_driver_on_a_scannet_shaped_tree(tmp_path):
     assert abs(again["psnr"] - res["psnr"]) < 1e-9 and abs(again["target_pq"] - res["target_pq"]) < 1e-12
 
 
-def test_multiview_cli_and_viewer_render(tmp_path):
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_multiview_cli_and_viewer_render(tmp_path, precision):
     """inference_multiview.py (reference :41-152) on three image files -> output.ply; the file then goes through the viewer's loader
     (5-px crop) and one novel view is rendered with the viewer's semantics."""
     from PIL import Image
@@ -56,7 +58,7 @@ def test_multiview_cli_and_viewer_render(tmp_path):
     for i in range(3):
         Image.fromarray(rng.integers(0, 256, (150, 200, 3), dtype=np.uint8)).save(img_dir / f"{i}.png")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "inference_multiview.py"), "--image_dir", str(img_dir), "--output_path", str(tmp_path / "out"),
-                        "--size", "128", "--precision", "bf16"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--size", "128", "--precision", precision], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     ply = tmp_path / "out" / "output.ply"
     v = read_ply_vertices(ply)

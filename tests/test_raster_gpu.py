@@ -301,3 +301,54 @@ def test_splatting_cuda_colour_against_oracle():
         assert ref["D"] > 1000
         assert float(np.abs(col[v] - np.clip(ref["image"], 0.0, 1.0)).max()) <= 5e-6
         assert float(np.abs(dep[v] - ref["depth"]).max()) <= 5e-5 * max(1.0, float(ref["depth"].max()))
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_lifting_on_reference_generated_fixtures(case):
+    """siu3r_lift_ids (wave-per-pixel reduction, guarded atomicMin) on tests/golden/lifting_{a,b}.npz, the vectors produced by executing the
+    reference's own statements (src/pipeline.py:137-193): semantic / instance id maps and the segment table must be exact, including
+    the stuff classes that fuse several queries into one id (case b: queries 2 and 4 -> 101)."""
+    import json
+    import os
+
+    from siu3r_amd.gaussian_renderer import lift_query_class_logits
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(root, "lifting.json")))[case]
+    z = np.load(os.path.join(root, f"lifting_{case}.npz"))
+    x = torch.from_numpy(z["x"]).cuda()                     # [v, q, c, h, w]
+    sem, ins, infos = lift_query_class_logits([x], [meta["scores"]], num_queries=100, label_ids_to_fuse=(0, 1))
+    assert np.array_equal(sem[0].cpu().numpy(), z["sem_id"]), "semantic ids differ from the reference's"
+    assert np.array_equal(ins[0].cpu().numpy(), z["ins_id"]), "instance ids differ from the reference's"
+    assert infos[0] == meta["info"]
+    # the channel-last view the renderer hands over (no copy inside lift_query_class_logits) gives the same answer
+    xcl = x.permute(0, 3, 4, 1, 2).contiguous().permute(0, 3, 4, 1, 2)
+    sem2, ins2, infos2 = lift_query_class_logits([xcl], [meta["scores"]])
+    assert torch.equal(sem2, sem) and torch.equal(ins2, ins) and infos2 == infos
+
+
+def test_lifting_ties_and_stuff_fusion_crafted():
+    """Exact ties between queries and between classes (argmax takes the first maximum, torch semantics: pipeline.py:150-158), pixels below
+    the semantic threshold (background 0 / instance 0), two queries of the same stuff class fused into id 100 + label, a query that wins
+    no pixel (absent from the table) -- against the pinned CPU restatement."""
+    from oracle import siu3r_oracle as O
+    from siu3r_amd.gaussian_renderer import lift_query_class_logits
+
+    v, q, c, h, w = 2, 6, 21, 12, 20
+    x = torch.zeros(v, q, c, h, w)
+    x[:, 0, 1, :, :5] = 0.9            # query 0: stuff channel 1 (label 2 -> fused id 102) on the left band
+    x[:, 1, 1, :, 5:9] = 0.9           # query 1: the same stuff class next to it -> fused with query 0
+    x[:, 2, 7, :, 9:13] = 0.8          # query 2: a thing class
+    x[:, 3, 7, :, 9:13] = 0.8          # query 3: exact tie with query 2 on the same pixels -> the lower query index wins
+    x[:, 4, 3, :, 13:16] = 0.6
+    x[:, 4, 9, :, 13:16] = 0.6         # query 4: exact tie between two classes -> the lower class index wins
+    x[:, 5, 11, :, 16:] = 0.2          # query 5: below the 0.3 semantic threshold everywhere -> wins nothing
+    x[1, 2, 7, 3, 10] = 0.80000001     # (same fp32 value: still a tie)
+    scores = [0.9, 0.8, 0.7, 0.6, 0.5, 0.4]
+    sem, ins, infos = lift_query_class_logits([x.cuda()], [scores], num_queries=100, label_ids_to_fuse=(0, 1), sem_threshold=0.3)
+    rs, ri, rinfo = O.lift_ids(x, scores)
+    assert torch.equal(sem[0].cpu(), rs) and torch.equal(ins[0].cpu(), ri)
+    assert infos[0] == rinfo
+    ids = {i["id"] for i in infos[0]}
+    assert 102 in ids and sum(i["was_fused"] for i in infos[0]) == 2 and all(i["id"] != 4 and i["id"] != 6 for i in infos[0])
+    assert int((ins[0] == 0).sum()) == v * h * (w - 16)
