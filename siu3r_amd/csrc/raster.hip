@@ -31,6 +31,8 @@
 // Arithmetic matches oracle/raster_ref.c operation for operation (same expression order, contraction off, explicit fused
 // multiply-adds in the blend loop on both sides, and a shared polynomial exp) so that integer outputs are bit-exact and the
 // maps agree to fp32 rounding.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -99,28 +101,46 @@ enum { ST_GV = 0, ST_D = 1, ST_E = 2, ST_FLAGS = 3, ST_N = 4 };
 // cov_stride 6: upper-triangular covariances (xx,xy,xz,yy,yz,zz); 9: full row-major 3x3 (Gaussians.covariances as stored).
 // sh_planar 0: colors [G, ncoef, 3] (the layout the reference hands to the CUDA rasterizer, cuda_splatting.py:65); 1: [G, 3, ncoef]
 // (Gaussians.harmonics as stored: no repacking copy in front of the renderer).
-__global__ __launch_bounds__(256) void project_kernel(const Cam* __restrict__ cams, int64_t G, const float* __restrict__ means,
+constexpr int PV = 16;  // views per projection chunk (blockIdx.y)
+__global__ __launch_bounds__(256) void project_kernel(const Cam* __restrict__ cams, int nviews, int nf_chunk, int64_t G, const float* __restrict__ means,
                                                       const float* __restrict__ cov, int cov_stride, const float* __restrict__ opac,
                                                       const float* __restrict__ colors, int channels, int sh_planar, float* __restrict__ rec,
                                                       int32_t* __restrict__ radii, int32_t* __restrict__ rect, int32_t* __restrict__ tiles_touched,
                                                       uint32_t* __restrict__ keys, unsigned long long* __restrict__ stats) {
-  const int v = blockIdx.y;
-  const Cam& c = cams[v];
+  // One thread per Gaussian, looping over the (up to PV) views of blockIdx.y's chunk: mean, covariance, opacity and the 300-byte SH
+  // block are read ONCE per chunk instead of once per view (six target views of a pair scene re-read 1.26 GB of SH coefficients
+  // before: the kernel was HBM-bound on traffic that the algorithm does not need).  The SH block is fetched at the first view that
+  // sees the Gaussian; per-view totals go through LDS (one atomic pair per view and workgroup, as before).
+  __shared__ int s_cnt[PV][4], s_pairs[PV][4];
+  const int v_begin = blockIdx.y * PV, v_end = min(nviews, v_begin + PV);
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const float SH_C0 = 0.28209479177387814f, SH_C1 = 0.4886025119029199f;
+  const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+  float sh[76];
+  bool sh_loaded = false;
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f, opacity = 0.f, sxx = 0.f, sxy = 0.f, sxz = 0.f, syy = 0.f, syz = 0.f, szz = 0.f;
+  if (g < G) {
+    m0 = means[3 * g];
+    m1 = means[3 * g + 1];
+    m2 = means[3 * g + 2];
+    opacity = opac[g];
+    const float* cg = cov + (size_t)g * cov_stride;
+    const bool tri = cov_stride == 6;
+    sxx = cg[0]; sxy = cg[1]; sxz = cg[2]; syy = cg[tri ? 3 : 4]; syz = cg[tri ? 4 : 5]; szz = cg[tri ? 5 : 8];
+  }
+  for (int v = v_begin; v < v_end; ++v) {
+  const Cam& c = cams[v];
   int ntiles = 0;
   bool valid = false;
   if (g < G) {
     const int64_t o = (int64_t)v * G + g;
     const float* V = c.w2c;
-    const float m0 = means[3 * g], m1 = means[3 * g + 1], m2 = means[3 * g + 2];
     int rx_i = 0, ry_i = 0, tx0 = 0, ty0 = 0, tx1 = 0, ty1 = 0;
     float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
     const float tx = V[0] * m0 + V[1] * m1 + V[2] * m2 + V[3];
     const float ty = V[4] * m0 + V[5] * m1 + V[6] * m2 + V[7];
     const float tz = V[8] * m0 + V[9] * m1 + V[10] * m2 + V[11];
     const int gw = (c.width + TILE - 1) / TILE, gh = (c.height + TILE - 1) / TILE;
-    const float opacity = opac[g];
     do {
       float fx, fy;
       if (c.mode == 0) {
@@ -150,9 +170,6 @@ __global__ __launch_bounds__(256) void project_kernel(const Cam* __restrict__ ca
       const float j00 = fx * rz, j02 = -(fx * ctx) * rz * rz, j11 = fy * rz, j12 = -(fy * cty) * rz * rz;
       const float m00 = j00 * V[0] + j02 * V[8], m01 = j00 * V[1] + j02 * V[9], m02 = j00 * V[2] + j02 * V[10];
       const float m10 = j11 * V[4] + j12 * V[8], m11 = j11 * V[5] + j12 * V[9], m12 = j11 * V[6] + j12 * V[10];
-      const float* cg = cov + (size_t)g * cov_stride;
-      const bool tri = cov_stride == 6;
-      const float sxx = cg[0], sxy = cg[1], sxz = cg[2], syy = cg[tri ? 3 : 4], syz = cg[tri ? 4 : 5], szz = cg[tri ? 5 : 8];
       const float a0 = m00 * sxx + m01 * sxy + m02 * sxz, a1 = m00 * sxy + m01 * syy + m02 * syz, a2 = m00 * sxz + m01 * syz + m02 * szz;
       const float b0 = m10 * sxx + m11 * sxy + m12 * sxz, b1 = m10 * sxy + m11 * syy + m12 * syz, b2 = m10 * sxz + m11 * syz + m12 * szz;
       float c00 = a0 * m00 + a1 * m01 + a2 * m02;
@@ -218,6 +235,11 @@ __global__ __launch_bounds__(256) void project_kernel(const Cam* __restrict__ ca
     rp[1] = make_float4(ca, cb, cc, opacity);
     // positive floats order like their bit patterns; culled Gaussians sort behind every visible one
     keys[o] = valid ? __float_as_uint(tz) : 0xffffffffu;
+    if (valid && c.mode == 1 && colors && channels == 3) {
+      // gsplat family with three precomputed colour channels (the viewer's view-dependent RGB): the colour travels in the record, so
+      // that the fused sort-free composite (no per-tile lists in HBM) serves this path too
+      rp[2] = make_float4(colors[3 * g], colors[3 * g + 1], colors[3 * g + 2], 0.f);
+    }
     if (valid && c.mode == 0) {
       const float dx = m0 - c.campos[0], dy = m1 - c.campos[1], dz = m2 - c.campos[2];
       const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
@@ -227,10 +249,13 @@ __global__ __launch_bounds__(256) void project_kernel(const Cam* __restrict__ ca
       // block is contiguous, so 12 (19 with band 4) wide loads replace 48 (75) scalar ones that each touched 64 cache lines
       struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
       const float* shp = colors + (size_t)g * channels * 3;
-      float sh[76], col[3];
+      float col[3];
+      // (the coefficients every view of the chunk may need: the views of a call share sh_degree / sh_band4 in practice; the largest
+      // request is loaded)
       const int ncf = (deg > 3 && c.sh_band4) ? 25 : (deg > 2 ? 16 : (deg > 1 ? 9 : (deg > 0 ? 4 : 1)));
-      const int nf = ncf * 3;
-      if (!sh_planar) {
+      const int nf = max(ncf * 3, nf_chunk);
+      if (sh_loaded) {
+      } else if (!sh_planar) {
 #pragma unroll
         for (int q = 0; q < 19; ++q) {
           if (4 * q < nf) {
@@ -264,6 +289,7 @@ __global__ __launch_bounds__(256) void project_kernel(const Cam* __restrict__ ca
           }
         }
       }
+      sh_loaded = true;
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
 #define S(i) sh[(i) * 3 + ch]
@@ -293,25 +319,25 @@ __global__ __launch_bounds__(256) void project_kernel(const Cam* __restrict__ ca
       rp[2] = make_float4(col[0], col[1], col[2], 0.f);
     }
   }
-  // per-view totals: wave reduction, then one atomic pair per workgroup
-  __shared__ int s_cnt[4], s_pairs[4];
+  // per-view totals: wave reduction into LDS; one atomic pair per view and workgroup after the loop
   int cnt = valid ? 1 : 0, pairs = ntiles;
 #pragma unroll
   for (int o_ = 32; o_ > 0; o_ >>= 1) {
     cnt += __shfl_xor(cnt, o_);
     pairs += __shfl_xor(pairs, o_);
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
-    s_cnt[wave] = cnt;
-    s_pairs[wave] = pairs;
+  if (lane_ == 0) {
+    s_cnt[v - v_begin][wave_] = cnt;
+    s_pairs[v - v_begin][wave_] = pairs;
   }
+  }  // views of the chunk
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const int c4 = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    const long long p4 = (long long)s_pairs[0] + s_pairs[1] + s_pairs[2] + s_pairs[3];
-    if (c4) atomicAdd(&stats[v * ST_N + ST_GV], (unsigned long long)c4);
-    if (p4) atomicAdd(&stats[v * ST_N + ST_D], (unsigned long long)p4);
+  if ((int)threadIdx.x < v_end - v_begin) {
+    const int i = threadIdx.x;
+    const int c4 = s_cnt[i][0] + s_cnt[i][1] + s_cnt[i][2] + s_cnt[i][3];
+    const long long p4 = (long long)s_pairs[i][0] + s_pairs[i][1] + s_pairs[i][2] + s_pairs[i][3];
+    if (c4) atomicAdd(&stats[(v_begin + i) * ST_N + ST_GV], (unsigned long long)c4);
+    if (p4) atomicAdd(&stats[(v_begin + i) * ST_N + ST_D], (unsigned long long)p4);
   }
 }
 
@@ -553,6 +579,9 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(Geo geo, const uint32_
   }
 }
 
+#ifndef SIU3R_COMP_DBG
+#define SIU3R_COMP_DBG 0  // tuning builds (tools/ab_raster.sh): 1 = no blend walk (scan + stage only), 2 = no per-wave list building either
+#endif
 // does the packed bin-relative rect cover tile (rtx, rty) of the bin?
 __device__ __forceinline__ bool entry_covers(uint32_t pr, int rtx, int rty) {
   const int x0 = pr & 31, y0 = (pr >> 5) & 31, x1 = (pr >> 10) & 31, y1 = (pr >> 15) & 31;
@@ -563,7 +592,9 @@ __device__ __forceinline__ bool entry_covers(uint32_t pr, int rtx, int rty) {
 constexpr int STG = 512;       // staging capacity (survivors awaiting the blend)
 constexpr int STG_PULL = 192;  // refill while fewer than this are staged (<= STG - 256: one more slice always fits)
 constexpr int FK = 4;          // slices of 256 entries tested per refill round
-template <bool NT>
+// K3 (compile time): the gsplat family's conventions on the same walk -- pixel centres at +0.5, saturation test nT <= t_min, channel-last
+// [H,W,3] output without background or depth (siu3r_raster_composite_rgb with mode-1 cameras: the viewer's RGB render).
+template <bool NT, bool K3 = false>
 __global__ __launch_bounds__(256) void composite_rgb_kernel(const Cam* __restrict__ cams, Geo geo, const int32_t* __restrict__ bin_start,
                                                             const uint2* __restrict__ entries, int64_t cap_e, const float* __restrict__ rec, int64_t G,
                                                             float* __restrict__ image, float* __restrict__ out_depth, float* __restrict__ out_alpha,
@@ -587,7 +618,7 @@ __global__ __launch_bounds__(256) void composite_rgb_kernel(const Cam* __restric
   const int lx = (lane & 7) + 8 * (wave & 1), ly = (lane >> 3) + 8 * (wave >> 1);  // wave = 8x8 quadrant
   const int px = tx * TILE + lx, py = ty * TILE + ly;
   const bool inside = px < c.width && py < c.height;
-  const float pxf = (float)px, pyf = (float)py;
+  const float pxf = (float)px + (K3 ? 0.5f : 0.0f), pyf = (float)py + (K3 ? 0.5f : 0.0f);
   const int64_t ebeg = bin_start[v * (geo.NB + 1) + bin];
   const int64_t eend = min((int64_t)bin_start[v * (geo.NB + 1) + bin + 1], cap_e);
   const uint2* ep = entries + (int64_t)v * cap_e;
@@ -655,7 +686,8 @@ __global__ __launch_bounds__(256) void composite_rgb_kernel(const Cam* __restric
           if (L <= 0.f) {
             mk = 0;  // opacity below alpha_min: alpha = min(alpha_max, opacity * exp(<= 0)) can never reach it
           } else if (det > 0.f) {
-            const float ex = sqrtf(2.f * L * r1.z / det) * 1.01f + 0.05f, ey = sqrtf(2.f * L * r1.x / det) * 1.01f + 0.05f;
+            // (K3: pixel centres sit half a pixel further: the box grows by that much)
+            const float ex = sqrtf(2.f * L * r1.z / det) * 1.01f + (K3 ? 0.55f : 0.05f), ey = sqrtf(2.f * L * r1.x / det) * 1.01f + (K3 ? 0.55f : 0.05f);
             const float x0 = r0.x - ex - tile_x0, x1 = r0.x + ex - tile_x0, y0 = r0.y - ey - tile_y0, y1 = r0.y + ey - tile_y0;
             const int cx = (x0 <= 7.f && x1 >= 0.f ? 1 : 0) | (x0 <= 15.f && x1 >= 8.f ? 2 : 0);
             const int cy = (y0 <= 7.f && y1 >= 0.f ? 1 : 0) | (y0 <= 15.f && y1 >= 8.f ? 2 : 0);
@@ -672,24 +704,33 @@ __global__ __launch_bounds__(256) void composite_rgb_kernel(const Cam* __restric
     // this wave's own list (order kept) of the staged survivors that can reach its quadrant: ballot + prefix popcount again, wave-local
     // (LDS operations of one wave complete in order: no barrier)
     int nq = 0;
-    for (int b = 0; b < staged; b += 64) {
+    for (int b = 0; b < ((SIU3R_COMP_DBG & 2) ? 0 : staged); b += 64) {
       const int i = b + lane;
       const bool hit = i < staged && (s_m[i] & wbit);
       const unsigned long long mh = __ballot(hit);
       if (hit) s_list[wave][nq + __popcll(mh & ((1ull << lane) - 1ull))] = (unsigned short)i;
       nq += __popcll(mh);
     }
+    // The walk is a chain of dependent LDS reads (list index -> record) in front of ~50 cycles of arithmetic per entry: the NEXT entry's
+    // index and record are fetched while the current one is evaluated (registers only; same entries, same order, same arithmetic)
+    if (SIU3R_COMP_DBG & 1) nq = 0;
+    int jn = nq > 0 ? (int)s_list[wave][0] : 0;
+    float4 An = *(const float4*)s_a[jn], Qn = *(const float4*)s_co[jn];
+    int jnn = nq > 1 ? (int)s_list[wave][1] : 0;
     for (int ii = 0; !done && ii < nq; ++ii) {
-      const int j = s_list[wave][ii];
-      const float4 A = *(const float4*)s_a[j];
-      const float4 Q = *(const float4*)s_co[j];
+      const int j = jn;
+      const float4 A = An, Q = Qn;
+      jn = jnn;
+      An = *(const float4*)s_a[jn];
+      Qn = *(const float4*)s_co[jn];
+      jnn = ii + 2 < nq ? (int)s_list[wave][ii + 2] : 0;
       const float dx = A.x - pxf, dy = A.y - pyf;
       const float power = -conic_sigma(Q.x, Q.y, Q.z, dx, dy);
       if (power > 0.0f) continue;
       const float a = fminf(alpha_max, Q.w * exp_det(power));
       if (a < alpha_min) continue;
       const float nT = __builtin_fmaf(-T, a, T);  // T (1 - a)
-      if (nT < t_min) {
+      if (K3 ? (nT <= t_min) : (nT < t_min)) {
         done = true;
         continue;
       }
@@ -717,7 +758,14 @@ __global__ __launch_bounds__(256) void composite_rgb_kernel(const Cam* __restric
     }
     staged = 0;
   }
-  if (inside) {
+  if (inside && K3) {
+    const size_t hw = (size_t)c.width * c.height, pix = (size_t)py * c.width + px;
+    float* o = image + ((size_t)v * hw + pix) * 3;
+    o[0] = C0;
+    o[1] = C1;
+    o[2] = C2;
+    out_alpha[(size_t)v * hw + pix] = O;
+  } else if (inside) {
     const size_t hw = (size_t)c.width * c.height, pix = (size_t)py * c.width + px;
     float* img = image + (size_t)v * 3 * hw;
     img[pix] = __builtin_fmaf(T, c.bg[0], C0);
@@ -930,8 +978,25 @@ __global__ void quat_scale_cov6_kernel(int64_t G, const float* quats, const floa
     for (int c = r; c < 3; ++c) cov6[6 * g + o++] = M[3 * r] * M[3 * c] + M[3 * r + 1] * M[3 * c + 1] + M[3 * r + 2] * M[3 * c + 2];
 }
 
+// The workgroup's 256 coefficient blocks ([coef][rgb], 12 * ncoef bytes each, contiguous) are copied to LDS with coalesced 16-byte
+// loads and read back lane by lane: a lane reading its own 300-byte block straight from global memory touches 64 cache lines per load
+// instruction (the kernel then ran at 1.6 TB/s; the algorithm reads every byte once).
 template <int DEG>
-__global__ void sh_eval_kernel(int64_t G, int ncoef, const float* means, float cx, float cy, float cz, const float* sh, float* rgb) {
+__global__ __launch_bounds__(256) void sh_eval_kernel(int64_t G, int ncoef, const float* means, float cx, float cy, float cz, const float* sh, float* rgb) {
+  extern __shared__ __attribute__((aligned(16))) float s_sh[];
+  const int nf = ncoef * 3;
+  {
+    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t nfl = (int64_t)min((int64_t)blockDim.x, G - g0) * nf;  // floats of this workgroup
+    const float* blk = sh + g0 * nf;
+    if ((((uintptr_t)blk) & 15) == 0) {
+      for (int64_t i = threadIdx.x; i < nfl / 4; i += blockDim.x) ((float4*)s_sh)[i] = ((const float4*)blk)[i];
+      for (int64_t i = (nfl & ~3ll) + threadIdx.x; i < nfl; i += blockDim.x) s_sh[i] = blk[i];
+    } else {
+      for (int64_t i = threadIdx.x; i < nfl; i += blockDim.x) s_sh[i] = blk[i];
+    }
+  }
+  __syncthreads();
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
   const float dx = means[3 * g] - cx, dy = means[3 * g + 1] - cy, dz = means[3 * g + 2] - cz;
@@ -962,20 +1027,9 @@ __global__ void sh_eval_kernel(int64_t G, int ncoef, const float* means, float c
     b[20] = 1.984313483298443f * z * b[12] - 1.006230589874905f * b[6]; b[21] = fTmp0D * x; b[19] = fTmp0D * y; b[22] = fTmp1C * fC1; b[18] = fTmp1C * fS1;
     b[23] = fTmp2B * fC2; b[17] = fTmp2B * fS2; b[24] = 0.6258357354491763f * fC3; b[16] = 0.6258357354491763f * fS3;
   }
-  // the coefficient block ([coef][rgb], 4-byte aligned) as 16-byte loads
-  struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
-  const float* shp = sh + (size_t)g * ncoef * 3;
-  float c[NB * 3 + 3];
+  float c[NB * 3];
 #pragma unroll
-  for (int q = 0; q < (NB * 3 + 3) / 4; ++q) {
-    if (4 * q + 4 <= ncoef * 3) {
-      const f4u t4 = *(const f4u*)(shp + 4 * q);
-      c[4 * q] = t4.v[0]; c[4 * q + 1] = t4.v[1]; c[4 * q + 2] = t4.v[2]; c[4 * q + 3] = t4.v[3];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) c[4 * q + e] = (4 * q + e < ncoef * 3) ? shp[4 * q + e] : 0.f;
-    }
-  }
+  for (int i = 0; i < NB * 3; ++i) c[i] = s_sh[(size_t)threadIdx.x * nf + i];  // (nf is odd for 25 coefficients: consecutive lanes, distinct banks)
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) {
     float r = 0.0f;
@@ -1025,9 +1079,16 @@ extern "C" int siu3r_raster_project(const siu3r_raster_cam* cams_host, int V, vo
     siu3r_set_error("raster_project: camera upload / stats reset failed");
     return 2;
   }
+  // SH floats the views of the call may read (the block is loaded once per Gaussian, at the first view that sees it)
+  int nf_chunk = 0;
+  for (int v = 0; v < V; ++v) {
+    const int deg = cams_host[v].sh_degree;
+    const int ncf = (deg > 3 && cams_host[v].sh_band4) ? 25 : (deg > 2 ? 16 : (deg > 1 ? 9 : (deg > 0 ? 4 : 1)));
+    if (cams_host[v].mode == 0 && ncf * 3 > nf_chunk) nf_chunk = ncf * 3;
+  }
   if (G > 0)
-    hipLaunchKernelGGL(project_kernel, dim3((unsigned)cdiv64(G, 256), V), dim3(256), 0, s, (const Cam*)cams_dev, G, means, cov, cov_stride, opacities, colors,
-                       channels, sh_planar, rec, radii, rect, tiles_touched, keys, (unsigned long long*)stats);
+    hipLaunchKernelGGL(project_kernel, dim3((unsigned)cdiv64(G, 256), (V + PV - 1) / PV), dim3(256), 0, s, (const Cam*)cams_dev, V, nf_chunk, G, means, cov,
+                       cov_stride, opacities, colors, channels, sh_planar, rec, radii, rect, tiles_touched, keys, (unsigned long long*)stats);
   SIU3R_LAUNCH_CHECK("siu3r_raster_project");
   return 0;
 }
@@ -1081,14 +1142,19 @@ extern "C" int siu3r_raster_composite_rgb(const siu3r_raster_cam* cams_host, int
                                           const void* entries, int64_t cap_e, const float* rec, float* image, float* out_depth, float* out_alpha,
                                           int32_t* n_touched, void* stream) {
   if (int rc = check_views(cams_host, V, "raster_composite_rgb")) return rc;
-  SIU3R_CHECK(cams_dev && bin_start && image && out_depth && out_alpha && (G == 0 || (entries && rec)), "raster_composite_rgb: null pointer");
+  const bool k3 = cams_host[0].mode == 1;  // gsplat family: image is [V,H,W,3] channel-last, no background, out_depth unused (may be NULL)
+  SIU3R_CHECK(cams_dev && bin_start && image && (out_depth || k3) && out_alpha && (G == 0 || (entries && rec)), "raster_composite_rgb: null pointer");
+  SIU3R_CHECK(!(k3 && n_touched), "raster_composite_rgb: n_touched belongs to the 3DGS family (mode 0)");
   hipStream_t s = (hipStream_t)stream;
   const Geo geo = make_geo(cams_host[0].width, cams_host[0].height);
   if (n_touched && G > 0 && hipMemsetAsync(n_touched, 0, sizeof(int32_t) * (size_t)V * G, s) != hipSuccess) {
     siu3r_set_error("raster_composite_rgb: memset failed");
     return 2;
   }
-  if (n_touched)
+  if (k3)
+    hipLaunchKernelGGL((composite_rgb_kernel<false, true>), dim3(geo.T, V), dim3(256), 0, s, (const Cam*)cams_dev, geo, bin_start, (const uint2*)entries, cap_e, rec, G,
+                       image, out_depth, out_alpha, n_touched);
+  else if (n_touched)
     hipLaunchKernelGGL(composite_rgb_kernel<true>, dim3(geo.T, V), dim3(256), 0, s, (const Cam*)cams_dev, geo, bin_start, (const uint2*)entries, cap_e, rec, G,
                        image, out_depth, out_alpha, n_touched);
   else
@@ -1148,12 +1214,24 @@ extern "C" int siu3r_sh_eval(const float* means, const float* campos3_host, cons
   if (G == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const float cx = campos3_host[0], cy = campos3_host[1], cz = campos3_host[2];
+  SIU3R_CHECK(ncoef <= 49, "sh_eval: at most 49 coefficients (got %d)", ncoef);
+  const size_t lds = (size_t)256 * ncoef * 3 * sizeof(float);  // <= 147 KiB
+  static bool attr_set = false;
+  if (!attr_set) {  // dynamic LDS beyond 64 KiB has to be requested once per kernel
+    const int cap = 160 * 1024;
+    hipFuncSetAttribute((const void*)sh_eval_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    hipFuncSetAttribute((const void*)sh_eval_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    hipFuncSetAttribute((const void*)sh_eval_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    hipFuncSetAttribute((const void*)sh_eval_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    hipFuncSetAttribute((const void*)sh_eval_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    attr_set = true;
+  }
   switch (degree) {
-    case 0: hipLaunchKernelGGL(sh_eval_kernel<0>, g1(G), dim3(256), 0, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
-    case 1: hipLaunchKernelGGL(sh_eval_kernel<1>, g1(G), dim3(256), 0, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
-    case 2: hipLaunchKernelGGL(sh_eval_kernel<2>, g1(G), dim3(256), 0, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
-    case 3: hipLaunchKernelGGL(sh_eval_kernel<3>, g1(G), dim3(256), 0, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
-    default: hipLaunchKernelGGL(sh_eval_kernel<4>, g1(G), dim3(256), 0, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
+    case 0: hipLaunchKernelGGL(sh_eval_kernel<0>, g1(G), dim3(256), lds, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
+    case 1: hipLaunchKernelGGL(sh_eval_kernel<1>, g1(G), dim3(256), lds, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
+    case 2: hipLaunchKernelGGL(sh_eval_kernel<2>, g1(G), dim3(256), lds, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
+    case 3: hipLaunchKernelGGL(sh_eval_kernel<3>, g1(G), dim3(256), lds, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
+    default: hipLaunchKernelGGL(sh_eval_kernel<4>, g1(G), dim3(256), lds, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
   }
   SIU3R_LAUNCH_CHECK("siu3r_sh_eval");
   return 0;

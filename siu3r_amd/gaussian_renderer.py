@@ -119,10 +119,17 @@ def rasterize_splats(splats: dict, camtoworlds: torch.Tensor, Ks: torch.Tensor, 
     Returns (render_colors [C,H,W,3], render_alphas [C,H,W,1], info)."""
     from . import raster
 
-    means = splats["means"].float()
-    cov6 = raster.quat_scale_to_cov6(splats["quats"], torch.exp(splats["scales"].float()))
-    opac = torch.sigmoid(splats["opacities"].float())
-    coeffs = torch.cat([splats["sh0"], splats["shN"]], 1).float() if "shN" in splats and splats["shN"] is not None else splats["sh0"].float()
+    # view-independent preparation (covariances from quats / scales, activations, the concatenated coefficient block): computed once per
+    # splat set and kept with it -- a viewer renders many frames of one scene (the block alone is 600 MB for 2 M Gaussians)
+    key = tuple(splats[k].data_ptr() if k in splats and splats[k] is not None else 0 for k in ("means", "quats", "scales", "opacities", "sh0", "shN"))
+    prep = splats.get("_prepared")
+    if prep is None or prep[0] != key:
+        means = splats["means"].float()
+        cov6 = raster.quat_scale_to_cov6(splats["quats"], torch.exp(splats["scales"].float()))
+        opac = torch.sigmoid(splats["opacities"].float())
+        coeffs = torch.cat([splats["sh0"], splats["shN"]], 1).float() if "shN" in splats and splats["shN"] is not None else splats["sh0"].float()
+        prep = splats["_prepared"] = (key, means, cov6, opac, coeffs)
+    _, means, cov6, opac, coeffs = prep
     assert coeffs.shape[1] >= (sh_degree + 1) ** 2
     cols, alphas, visible, pairs = [], [], [], []
     for c2w, K in zip(camtoworlds.cpu().float(), Ks.cpu().float()):  # colours are view-dependent (SH): one call per camera
@@ -130,7 +137,8 @@ def rasterize_splats(splats: dict, camtoworlds: torch.Tensor, Ks: torch.Tensor, 
         cam = raster.make_cam_k3(w2c, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), width, height, near_plane, far_plane,
                                  radius_clip=radius_clip)
         rgb = raster.sh_eval(means, c2w[:3, 3].tolist(), coeffs, sh_degree)
-        o = raster.rasterize_k3(cam, means, cov6, opac, rgb)
+        o = raster.rasterize_views_k3_rgb([cam], means, cov6, opac, rgb)  # three channels: the fused composite, no tile lists in HBM
+        o = dict(colors=o["colors"][0], alphas=o["alphas"][0], state=o["state"])
         raster.blend_background_(o["colors"], o["alphas"], backgrounds)
         cols.append(o["colors"])
         alphas.append(o["alphas"][..., None])

@@ -272,6 +272,27 @@ def rasterize_views_k3(cams: Sequence[RasterCam], means, cov6, opacities, feats,
     return _with_retry(run, entry_capacity, check_overflow)
 
 
+def rasterize_views_k3_rgb(cams: Sequence[RasterCam], means, cov6, opacities, rgb, entry_capacity=None, check_overflow=True) -> Dict[str, torch.Tensor]:
+    """gsplat semantics with THREE precomputed colour channels (rgb [G,3]) -> colors [V,H,W,3], alphas [V,H,W] (+ state), through the
+    fused sort-free composite: the colour travels in the per-Gaussian record and no per-tile list is written to HBM (the N-channel
+    path materialises the lists because every 32-channel chunk re-walks them)."""
+    _gpu(means, cov6, opacities, rgb)
+    means, cov6, opacities, rgb = (t.contiguous().float() for t in (means, cov6, opacities, rgb))
+    assert rgb.shape[1] == 3
+    V, G, dev = len(cams), means.shape[0], means.device
+    H, W = cams[0].height, cams[0].width
+
+    def run(cap):
+        st = _project_sort_bin(cams, means, cov6, opacities, rgb, 3, cap, check_overflow)
+        out = torch.empty((V, H, W, 3), dtype=torch.float32, device=dev)
+        alpha = torch.empty((V, H, W), dtype=torch.float32, device=dev)
+        check(_lib.lib().siu3r_raster_composite_rgb(st["cams"], V, _p(st["cams_dev"]), G, _p(st["bin_start"]), _p(st["entries"]), st["cap_e"],
+                                                    _p(st["rec"]), _p(out), None, _p(alpha), None, _stream()))
+        return dict(colors=out, alphas=alpha, radii=st["radii"], state=st)
+
+    return _with_retry(run, entry_capacity, check_overflow)
+
+
 def rasterize_k3(cam: RasterCam, means, cov6, opacities, feats, **kw) -> Dict[str, torch.Tensor]:
     o = rasterize_views_k3([cam], means, cov6, opacities, feats, **kw)
     return dict(colors=o["colors"][0], alphas=o["alphas"][0], radii=o["radii"][0], state=o["state"])

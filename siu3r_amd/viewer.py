@@ -60,7 +60,10 @@ def render_view(splats: Dict[str, torch.Tensor], camtoworld: torch.Tensor, K: to
     from .gaussian_renderer import rasterize_splats
 
     dev = "cuda"
-    s = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in splats.items()}
+    if all(v.is_cuda for v in splats.values() if isinstance(v, torch.Tensor)):
+        s = splats  # (rasterize_splats keeps its view-independent preparation with the dict: frame after frame of one scene)
+    else:
+        s = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in splats.items()}
     deg = s.get("max_sh_degree", 4) if sh_degree is None else sh_degree
     colors, alphas, info = rasterize_splats(s, camtoworld[None].float(), K[None].float(), width, height, sh_degree=deg, radius_clip=radius_clip)
     return colors[0].clamp(0.0, 1.0), alphas[0], info
