@@ -30,8 +30,22 @@ sys.path.insert(0, ROOT)
 FLOPS_PER_PAIR_512 = 4059.0e9  # algorithmic 2*MAC of one pair @512^2 (torch flop counter on the reference)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
-PARITY = {"bf16x3": "<= 1e-3 max-norm on every Gaussian field vs the fp32 oracle (tests/test_model_gpu.py, tools/parity_sweep.py)",
+
+
+def _latest_profile(suffix):
+    """newest committed round of a counter summary (profiles/rNN_<suffix>)"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return found[-1] if found else os.path.join(ROOT, "profiles", "r00_" + suffix)
+
+
+PMC_FILE = _latest_profile("pmc_summary.json")
+BUSY_FILE = _latest_profile("mfma_busy.json")
+PMC_NAME = "profiles/" + os.path.basename(PMC_FILE)
+# the exact statement tests/test_model_gpu.py::test_parity_sweep asserts on seven shapes / seeds (-m gpu, driver-run)
+PARITY = {"bf16x3": "vs the pinned fp32 oracle, max-normalised: every Gaussian field <= 1e-3 (measured <= 8e-5); Mask2Former class / mask logits "
+                    "<= 5e-3 (<= 1e-3 on most inputs; 1-3e-3 when a thresholded attention mask flips a borderline pixel between fp32 evaluation "
+                    "orders); label maps agree >= 0.995; graph replay bit-identical to eager (tests/test_model_gpu.py::test_parity_sweep)",
           "bf16": "bf16 operand rounding: 2e-2 .. 1e-1 on the fields (covariances worst), label agreement 0.85-0.93"}
 
 
@@ -49,7 +63,7 @@ def pmc_bytes(section, kernels):
         if not e or "FETCH_SIZE" not in e or "WRITE_SIZE" not in e:
             return None, None
         total += per_unit * (2.0 * e["FETCH_SIZE"]["per_launch"] + e["WRITE_SIZE"]["per_launch"]) * 1024.0
-    return total, f"profiles/r02_pmc_summary.json[{section}]"
+    return total, f"{PMC_NAME}[{section}]"
 
 
 def pmc_frame_bytes(section, views_per_call):
@@ -65,7 +79,7 @@ def pmc_frame_bytes(section, views_per_call):
         return None, None
     frames = sum(e["FETCH_SIZE"]["launches"] for e in comp) * views_per_call
     tot = sum(2.0 * e.get("FETCH_SIZE", {}).get("total", 0.0) + e.get("WRITE_SIZE", {}).get("total", 0.0) for e in sec.values()) * 1024.0
-    return tot / frames, f"profiles/r02_pmc_summary.json[{section}] (all kernels of the command / {frames} frames)"
+    return tot / frames, f"{PMC_NAME}[{section}] (all kernels of the command / {frames} frames)"
 
 
 def timed_steps(step, steps, D, dev):
@@ -213,7 +227,7 @@ def gemm_roofline(model, step, precision, B, H, W):
     if B == 1 and (H, W) == (512, 512):
         traffic, traffic_src = pmc_bytes(f"bench_{precision}", [(name, 1.0)])
     busy = None
-    bf = os.path.join(ROOT, "profiles", "r02_mfma_busy.json")
+    bf = BUSY_FILE
     if os.path.exists(bf):
         busy = json.load(open(bf)).get(f"bench_{precision}", {}).get("kernels", {}).get(name, {}).get("mfma_busy_frac")
     return {
@@ -221,7 +235,7 @@ def gemm_roofline(model, step, precision, B, H, W):
         "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
         "mfma_passes_per_product": passes, "mfma_issue_frac": achieved * passes / MFMA_BF16_PEAK_TFLOPS,
-        "mfma_busy_counter_frac": busy, "mfma_busy_source": "profiles/r02_mfma_busy.json (SQ_VALU_MFMA_BUSY_CYCLES pass)" if busy is not None else None,
+        "mfma_busy_counter_frac": busy, "mfma_busy_source": "profiles/" + os.path.basename(BUSY_FILE) + " (SQ_VALU_MFMA_BUSY_CYCLES pass)" if busy is not None else None,
         "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
         "algorithmic_flops_per_launch_avg": d["flops"] / d["launches"],
         "gemm_time_ms_per_step": sum(v["ms"] for v in summ.values()),

@@ -27,8 +27,7 @@ def _sources():
 
 def _digest(path):
     h = hashlib.sha1()
-    for f in [path, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(CSRC, "gemm_epilogue_pp.h"),
-              os.path.join(HERE, "..", "include", "siu3r_hip.h")]:
+    for f in [path, *sorted(os.path.join(CSRC, h_) for h_ in os.listdir(CSRC) if h_.endswith(".h")), os.path.join(HERE, "..", "include", "siu3r_hip.h")]:
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS + EXTRA_FLAGS.get(os.path.basename(path), [])).encode())

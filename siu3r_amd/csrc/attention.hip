@@ -14,6 +14,10 @@
 
 #include "common.h"
 
+// attention_pipe.hip: the 8-wave software-pipelined kernel of the ViT blocks
+bool siu3r_attn_pipe_ok(const siu3r_attn_params& p);
+int siu3r_attn_pipe_launch(const siu3r_attn_params& p, hipStream_t s);
+
 namespace {
 
 constexpr int KT = 64;           // keys per tile
@@ -823,6 +827,7 @@ extern "C" int siu3r_attention(const siu3r_attn_params* pp, void* stream) {
               "siu3r_attention: q/k/v strides must keep 16-byte alignment");
   hipStream_t s = (hipStream_t)stream;
   static const bool no_fast = getenv("SIU3R_ATTN_NO_FAST") != nullptr;  // A/B switch
+  if (!no_fast && siu3r_attn_pipe_ok(p)) return siu3r_attn_pipe_launch(p, s);
   if (p.dtype == SIU3R_BF16 && !p.split3 && !p.rope_cos && !no_fast) return p.D == 64 ? launch_fast<64, 0>(p, s) : launch_fast<32, 0>(p, s);
   if (p.dtype == SIU3R_F32 && p.split3 && !p.rope_cos && !no_fast) return p.D == 64 ? launch_fast<64, 1>(p, s) : launch_fast<32, 1>(p, s);
   if (p.D == 64) {

@@ -4,6 +4,9 @@ plain fp32 torch on the same seeded inputs.  Tolerances (max |err| / max |ref|):
   bf16x3 / fp32 kernels ...... 2e-4  (well inside the north-star's 1e-3)
 """
 import math
+import os
+import subprocess
+import sys
 
 import pytest
 import torch
@@ -500,6 +503,45 @@ def test_attention_peaky(mode, case):
     o1 = ops.attention(dev(q1), dev(k1), dev(v1), heads=1, head_dim=D, scale=1.0, split3=split).float().cpu()[0]
     assert torch.equal(o1[:, 0].round().long(), torch.arange(Nq) % n1), "one-hot attention selected the wrong keys"
     assert float((o1[:, 1] - 1).abs().max()) < 1e-2
+
+
+PIPE_CASES = [(2, 16, 1025, 1025, 1.0), (1, 4, 1025, 2050, 4.0), (1, 2, 300, 200, 6.0), (1, 3, 129, 70, 6.0), (2, 4, 128, 64, 1.0), (1, 5, 1000, 1025, 2.0)]
+
+
+def _attention_pipe_cases(split):
+    """The 8-wave pipelined ViT attention (attention_pipe.hip): the pair shape with its intrinsics-token side path (Nq = 128 n + 1),
+    a multi-view cross-attention (keys of two other views), ragged query / key tiles, a single key tile, and Nq with no side path
+    next to a ragged key tail.  Strided q / k / v views of one packed projection output, as the model passes them."""
+    ops = _ops()
+    adt, tol = (torch.float32, TOL_F32) if split else (torch.bfloat16, TOL_BF16)
+    D = 64
+    for (B, H, Nq, Nk, scale) in PIPE_CASES:
+        if Nq == Nk:
+            qkv = gen(B, Nq, 3, H, D, seed=50, scale=scale).cuda().to(adt)
+            q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        else:
+            q = gen(B, Nq, H, D, seed=51, scale=scale).cuda().to(adt)
+            kv = gen(B, Nk, 2, H, D, seed=52, scale=scale).cuda().to(adt)
+            k, v = kv[:, :, 0], kv[:, :, 1]
+        out = ops.attention(q, k, v, heads=H, head_dim=D, scale=D ** -0.5, split3=split)
+        ref = _attn_ref(q.float().cpu(), k.float().cpu(), v.float().cpu(), D ** -0.5)
+        check(f"attention_pipe[{'bf16x3' if split else 'bf16'}] {(B, H, Nq, Nk, scale)}", out, ref, tol)
+        # the side-path row on its own: it is 1 of Nq rows, a wrong merge would hide in a max-norm over the whole tensor
+        if Nq % 128 == 1:
+            check("  intrinsics-token row", out[:, -1], ref[:, -1], tol)
+
+
+def test_attention_pipe_bf16x3():
+    _attention_pipe_cases(True)
+
+
+def test_attention_pipe_bf16():
+    """the same kernel on bf16 tensors (opt-in: SIU3R_ATTN_PIPE_BF16=1, read when the library is first used)"""
+    code = "import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); import test_kernels_gpu as T; T._attention_pipe_cases(False); print('PIPE_BF16_OK')"
+    env = dict(os.environ, SIU3R_ATTN_PIPE_BF16="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert "PIPE_BF16_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
 
 
 @pytest.mark.parametrize("mode", [MODES[0], MODES[2]], ids=["bf16", "bf16x3"])

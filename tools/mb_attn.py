@@ -21,6 +21,8 @@ if __name__ == "__main__":
     bench(1, 12, 1025, 1025, 64)
     bench(8, 16, 1025, 1025, 64)
     bench(2, 16, 1025, 1025, 64, torch.float32, True)
+    bench(8, 16, 1025, 1025, 64, torch.float32, True)
+    bench(2, 16, 1025, 2050, 64, torch.float32, True)
     bench(8, 1, 100, 8192, 32, mask=True)
     bench(8, 1, 100, 2048, 32, mask=True)
     bench(2, 12, 1025, 1025, 64, torch.float32, True)
