@@ -130,7 +130,8 @@ typedef struct {
 } siu3r_gemm_plan_t;
 int siu3r_gemm_plan(const siu3r_gemm_params* p, siu3r_gemm_plan_t* out);
 /* tuning aid (tools/, tests): key 0 = process-wide default of siu3r_gemm_params.tile_cfg (SIU3R_TILE_*; also env SIU3R_GEMM_PP), key 1 =
- * 1 disables the skinny remainder-row launch.  Not for concurrent use. */
+ * 1 disables the skinny remainder-row launch, key 2 = 1 disables split-K, key 3 = 1 ignores the table of measured tile choices
+ * (csrc/gemm_tuned.h; also env SIU3R_GEMM_NO_TUNED) so that every problem is priced by the cost model.  Not for concurrent use. */
 int siu3r_gemm_tune(int key, int value);
 
 /* ---- LayerNorm over the last dim (fp32 in, act-dtype out); reference: nn.LayerNorm call sites

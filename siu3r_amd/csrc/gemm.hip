@@ -345,15 +345,29 @@ int launch(const siu3r_gemm_params& pin, hipStream_t s) {
 static int g_tile_default = getenv("SIU3R_GEMM_PP") ? atoi(getenv("SIU3R_GEMM_PP")) : 0;
 static int g_no_skinny = getenv("SIU3R_GEMM_NO_SKINNY") ? 1 : 0;
 static int g_no_splitk = getenv("SIU3R_NO_SPLITK") ? atoi(getenv("SIU3R_NO_SPLITK")) : 0;
+static int g_no_tuned = getenv("SIU3R_GEMM_NO_TUNED") ? 1 : 0;
 extern "C" int siu3r_gemm_tune(int key, int value) {
   if (key == 0) g_tile_default = value;
   else if (key == 1) g_no_skinny = value;
   else if (key == 2) g_no_splitk = value;
+  else if (key == 3) g_no_tuned = value;
   else return 1;
   return 0;
 }
 
+#include "gemm_tuned.h"
+
 namespace {
+// measured tile choice of this exact problem, 0 if it is not in the table
+int tuned_cfg(const siu3r_gemm_params& p, bool x3) {
+  const int Z = p.batch > 0 ? p.batch : 1, ln = p.ln_stats ? 1 : 0;
+  for (const siu3r_tuned_entry* e = kTuned; e->m; ++e)
+    if (e->m == p.m && e->n == p.n && e->k == p.k && e->batch == Z && e->a_mode == p.a_mode && e->out_mode == p.out_mode && e->kh == p.kh &&
+        e->stride == p.stride && e->x3 == (x3 ? 1 : 0) && e->ln == ln)
+      return e->tile_cfg;
+  return 0;
+}
+
 // Cost model (microseconds), fitted to graph-timed replays of the 495 GEMM launches of a real 2 x 512^2 step under every tile
 // configuration (tools/gemm_replay.py; mean error ~15 %): a launch runs ceil(workgroups / slots) rounds; a round costs t0 (prologue
 // latency plus the epilogue, which the one-workgroup-per-CU ping-pong kernels expose in full every round while the two co-resident
@@ -371,7 +385,8 @@ void plan(const siu3r_gemm_params& p, siu3r_gemm_plan_t& pl) {
   const bool x3 = p.w_x3 != nullptr && p.a_dtype == SIU3R_F32;
   const int pp_mode = (g_disable_dma || p.a_mode == 2) ? -1 : siu3r_gemm_pp_mode(p);
   const int dma_mode = g_disable_dma ? -1 : (x3 ? siu3r_gemm_dma_x3_mode(p) : siu3r_gemm_dma_mode(p));
-  const int force = p.tile_cfg ? p.tile_cfg : g_tile_default;
+  int force = p.tile_cfg ? p.tile_cfg : g_tile_default;
+  if (force == 0 && !g_no_tuned) force = tuned_cfg(p, x3);
   const int64_t Z = p.batch > 0 ? p.batch : 1;
   const int ksteps = p.kpad / (x3 ? 16 : 32);  // steps of 64 operand-row bytes
   const bool may_split = !g_no_splitk && p.splitk != 1 && p.sk_ws && p.sk_cnt;

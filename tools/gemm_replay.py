@@ -17,6 +17,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"
 os.environ["SIU3R_NO_STREAMS"] = "1"
 os.environ["SIU3R_NO_GRAPH"] = "1"
+os.environ["SIU3R_GEMM_NO_TUNED"] = "1"  # "auto" below is the cost model
 dev = torch.device("cuda", 0)
 
 keep = []
@@ -136,4 +137,4 @@ for s, ps in sorted(uniq.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2]
     rows.append(dict(sig=list(s), launches=n, auto=dict(cfg=ca, splitk=sa, skinny=ska, us=ta), us={str(c): cands[c] for c in cands}, splitk={str(c): res[c][2] for c in cands}))
 print(f"sum over the step: auto {tot_auto/1e3:.2f} ms, best-per-shape {tot_best/1e3:.2f} ms, 128x64 family {tot_old/1e3:.2f} ms")
 if len(sys.argv) > 3:
-    json.dump(rows, open(sys.argv[3], "w"), indent=0)
+    json.dump(dict(batch=B, precision=prec, rows=rows), open(sys.argv[3], "w"), indent=0)

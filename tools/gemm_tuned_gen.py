@@ -1,0 +1,40 @@
+"""csrc/gemm_tuned.h from tools/gemm_replay.py results: python tools/gemm_tuned_gen.py gpurun_out/replay_*.json
+An entry is written only where a measured tile beats the cost model's choice by a margin (4 % in bf16x3; in bf16 the ping-pong tiles
+must win by 25 %: they lose end to end against the concurrent chains what they win in isolation, see gemm.hip plan())."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+agg = {}
+for f in sys.argv[1:]:
+    d = json.load(open(f))
+    x3 = 1 if d["precision"] == "bf16x3" else 0
+    for r in d["rows"]:
+        m, n, k, z, am, om, kh, ln, rp, rs, act, stride = r["sig"]
+        key = (m, n, k, z, am, om, kh, stride, x3, ln)
+        e = agg.setdefault(key, dict(auto=0.0, auto_cfg={}, us={}, src=os.path.basename(f)))
+        e["auto"] += r["auto"]["us"] * r["launches"]
+        e["auto_cfg"][r["auto"]["cfg"]] = e["auto_cfg"].get(r["auto"]["cfg"], 0) + r["launches"]
+        for c, t in r["us"].items():
+            e["us"][int(c)] = e["us"].get(int(c), 0.0) + t * r["launches"]
+        e["ncfg"] = min(e.get("ncfg", 9), len(r["us"]))
+lines, gain = [], 0.0
+for key, e in sorted(agg.items()):
+    full = {c: t for c, t in e["us"].items()}
+    if not full:
+        continue
+    best = min(full, key=full.get)
+    auto_cfg = max(e["auto_cfg"], key=e["auto_cfg"].get)
+    if best == auto_cfg:
+        continue
+    margin = 0.04 if key[8] else (0.25 if best > 0 else 0.04)
+    if full[best] > e["auto"] * (1.0 - margin):
+        continue
+    gain += e["auto"] - full[best]
+    lines.append("    {%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d},  // %.1f -> %.1f us per step (%s)" % (*key, best, e["auto"], full[best], e["src"]))
+hdr = open(os.path.join(ROOT, "siu3r_amd", "csrc", "gemm_tuned.h")).read()
+head = hdr[:hdr.index("static const siu3r_tuned_entry kTuned[] = {")]
+out = head + "static const siu3r_tuned_entry kTuned[] = {\n" + "\n".join(lines) + ("\n" if lines else "") + "    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},  // (terminator)\n};\n"
+open(os.path.join(ROOT, "siu3r_amd", "csrc", "gemm_tuned.h"), "w").write(out)
+print(f"{len(lines)} entries, {gain / 1e3:.2f} ms of summed launch time over the replayed steps")
