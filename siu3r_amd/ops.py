@@ -251,7 +251,7 @@ def gemm_tune(key: int, value: int):
 
 
 def _gemm_launch(p: GemmParams, dev=None):
-    if p.splitk == 0:
+    if p.splitk != 1:
         ws, cnt = _splitk_workspace(dev if dev is not None else torch.device("cuda", torch.cuda.current_device()))
         p.sk_ws, p.sk_cnt, p.sk_ws_floats, p.sk_cnt_n = ws.data_ptr(), cnt.data_ptr(), ws.numel(), cnt.numel()
     if _plan_log is not None:
@@ -343,12 +343,14 @@ def _apply_ln_stats_aux(p: GemmParams, pw: PackedWeight, x, out, lda, ldc, strid
 
 def linear(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=ACT_NONE,
            residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, relu_in=False,
-           rope=None, ln: Optional[RowStats] = None, stats_out: Optional[RowStats] = None, aux_out: Optional[torch.Tensor] = None):
+           rope=None, ln: Optional[RowStats] = None, stats_out: Optional[RowStats] = None, aux_out: Optional[torch.Tensor] = None,
+           splitk: int = 0):
     """y[..., N] = act(x[..., K] @ W^T + b) (+ residual).  x / out / residual may be strided views whose last
     dim is contiguous and which decompose into Z batches of M rows (e.g. tokens[:, :-1]).
     rope = (cos, sin, positions int64 [rows, 2] contiguous, ncols): fused RoPE2D on output columns [0, ncols).
     ln: x holds UN-normalised rows and pw was packed by pack_linear_ln: the LayerNorm is applied in the epilogue from these row
-    statistics.  stats_out: write the row statistics of the (fp32) output for a later ln=.  aux_out: a bf16 copy of the output."""
+    statistics.  stats_out: write the row statistics of the (fp32) output for a later ln=.  aux_out: a bf16 copy of the output.
+    splitk: siu3r_gemm_params.splitk (0 = the library decides, 1 = never, > 1 = exactly that many K slices)."""
     _gpu(x, residual, out)
     assert x.shape[-1] == pw.k, (x.shape, pw.k)
     if out is None:
@@ -382,6 +384,7 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=AC
         assert pos.dtype == torch.int64 and pos.is_contiguous() and pos.numel() == 2 * total and cos.shape[1] == 16
         p.rope_cos, p.rope_sin, p.rope_pos, p.rope_ncols = _p(cos), _p(sin), _p(pos), ncols
     _apply_ln_stats_aux(p, pw, x, out, lda, ldc, (bsa, 0, bsc, 0), ln, stats_out, aux_out)
+    p.splitk = splitk
     _gemm_launch(p)
     return out
 

@@ -95,3 +95,29 @@ def test_gemm_kernels_keep_two_workgroups_per_cu():
             assert r["Occupancy [waves/SIMD]"] >= 4, (name, r)
             assert 2 * r["LDS Size [bytes/block]"] <= 160 * 1024, (name, r)
     assert checked >= 10, sorted(res)
+
+
+def test_ping_pong_and_pipelined_kernels_fit_one_workgroup_per_cu():
+    """gemm_pp.hip / attention_pipe.hip are 8-wave kernels tuned for ONE workgroup per CU (two waves per SIMD): at most 256 registers,
+    LDS inside 160 KiB, and no scratch in the main-loop variants (the 256 x 256 tile may spill in its epilogue only: bounded here so
+    that a main-loop spill, thousands of bytes, cannot slip in)."""
+    import re
+
+    from siu3r_amd import build as B
+
+    B.build()
+    checked = 0
+    for name, r in B.kernel_resources("gemm_pp.hip").items():
+        m = re.search(r"gemm_pp_kernelILb(\d)ELi(\d)ELi(\d)", name)
+        if not m:
+            continue
+        checked += 1
+        mi, nj = int(m.group(2)), int(m.group(3))
+        assert r["VGPRs"] + r.get("AGPRs", 0) <= 256 and r["Occupancy [waves/SIMD]"] >= 2, (name, r)
+        assert r["LDS Size [bytes/block]"] <= 160 * 1024, (name, r)
+        assert r["ScratchSize [bytes/lane]"] <= (256 if (mi, nj) == (2, 4) else 0), (name, r)
+    assert checked >= 12, checked
+    res = B.kernel_resources("attention_pipe.hip")
+    assert len(res) == 2
+    for name, r in res.items():
+        assert r["VGPRs"] + r.get("AGPRs", 0) <= 256 and r["ScratchSize [bytes/lane]"] == 0 and r["LDS Size [bytes/block]"] <= 160 * 1024, (name, r)

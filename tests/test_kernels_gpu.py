@@ -505,6 +505,70 @@ def test_attention_peaky(mode, case):
     assert float((o1[:, 1] - 1).abs().max()) < 1e-2
 
 
+@pytest.mark.parametrize("tile", [-1, 2, 3], ids=["t128x64", "pp256x128", "pp128x128"])
+def test_gemm_split_k_stress(tile):
+    """Forced 8-way split-K with MANY tiles (every XCD holds slices of several tiles, tickets and slabs of 64+ tiles live at once),
+    launched back to back on one stream with alternating inputs: every launch must be bit-identical to the first launch of its input
+    (a ticket that was not reset, a slab read before its writer's data left the XCD's L2, or a slab shared by two tiles would show
+    as a difference here), and equal to the unsplit kernel up to fp32 summation order."""
+    ops = _ops()
+    M, N, K = 1024, 1024, 4096
+    w = gen(N, K, seed=81, scale=0.05)
+    pw = ops.pack_linear(w.cuda(), gen(N, seed=82).cuda(), True)
+    xs = [gen(M, K, seed=83 + i).cuda() for i in range(2)]
+    log = []
+    ops.gemm_tune(0, tile)
+    ops.set_plan_log(log)
+    try:
+        first = [ops.linear(x, pw, out_dtype=torch.float32, splitk=8) for x in xs]
+        assert log[-1].tile_cfg == tile and log[-1].splitk == 8, (log[-1].tile_cfg, log[-1].splitk)
+        outs = [ops.linear(xs[i % 2], pw, out_dtype=torch.float32, splitk=8) for i in range(40)]
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            assert torch.equal(o, first[i % 2]), f"launch {i} differs from the first launch of the same input"
+        ops.gemm_tune(2, 1)
+        try:
+            whole = ops.linear(xs[0], pw, out_dtype=torch.float32)
+        finally:
+            ops.gemm_tune(2, 0)
+        assert float((first[0] - whole).abs().max()) <= 1e-4 * float(whole.abs().max())
+    finally:
+        ops.set_plan_log(None)
+        ops.gemm_tune(0, 0)
+
+
+@pytest.mark.parametrize("mode", [MODES[0], MODES[2]], ids=["bf16", "bf16x3"])
+def test_gemm_layernorm_fold_outliers(mode):
+    """The folded LayerNorm computes rstd * (x W'^T - mean * c1) + c2: with a large row mean the two products cancel.  Rows with a
+    mean of 50 standard deviations and rows with single 1000-sigma channels (the massive activations ViT blocks develop) must stay
+    inside half of the north-star bar in bf16x3: the split product's error is ~2^-17 of |x| |W|, i.e. it grows with |mean| / sigma
+    (measured 2.1e-4 at 50 sigma, against 1e-5 for centred rows); a checkpoint whose rows sit further out than that should take
+    the unfolded LayerNorm (SIU3R_NO_LNFOLD=1)."""
+    ops = _ops()
+    name, adt, split, tol = mode
+    M, C, N = 300, 1024, 512
+    x = gen(M, C, seed=91)
+    x[:100] += 30.0                      # mean ~ 50 sigma
+    x[100:200, 7] = 600.0                # one massive channel
+    x[200:, 511] = -400.0
+    x[200:, 512] = 400.0
+    gamma, beta = gen(C, seed=92) * 0.5 + 1.0, gen(C, seed=93)
+    w, b = gen(N, C, seed=94, scale=0.05), gen(N, seed=95)
+    # the rows and their statistics come out of a producing GEMM's epilogue, as in the network: 0 @ W + 0 + residual = x exactly
+    xg = torch.empty(M, C, device="cuda")
+    st = ops.RowStats(xg)
+    xb = torch.empty(M, C, device="cuda", dtype=torch.bfloat16)
+    ops.linear(torch.zeros(M, 64, device="cuda").to(adt), ops.pack_linear(gen(C, 64, seed=96).cuda(), torch.zeros(C).cuda(), split), residual=x.cuda(), out=xg,
+               stats_out=st, aux_out=xb)
+    assert torch.equal(xg.cpu(), x)
+    pw = ops.pack_linear_ln(w.cuda(), b.cuda(), gamma.cuda(), beta.cuda(), split)
+    pw.meta["ln_eps"] = 1e-6
+    out = ops.linear(xg if split else xb, pw, out_dtype=torch.float32, ln=st)
+    ref = F.layer_norm(x, (C,), gamma, beta, 1e-6) @ w.t() + b
+    # bf16 mode multiplies the bf16-rounded UN-normalised rows: its error scales with |x| / sigma, not with the output (documented)
+    check(f"layernorm_fold_outliers[{name}]", out, ref, 5e-4 if split else 0.35)
+
+
 PIPE_CASES = [(2, 16, 1025, 1025, 1.0), (1, 4, 1025, 2050, 4.0), (1, 2, 300, 200, 6.0), (1, 3, 129, 70, 6.0), (2, 4, 128, 64, 1.0), (1, 5, 1000, 1025, 2.0)]
 
 
