@@ -20,9 +20,15 @@
 
 #include "common.h"
 
+// tuning aid (tools/ab_attn.sh): 1 = no MFMAs, 2 = no softmax arithmetic, 4 = no K / V refresh (loads, split, stores), 8 = no barrier
+#ifndef SIU3R_AP_DBG
+#define SIU3R_AP_DBG 0
+#endif
+
 namespace siu3r_attn_pipe {
 
-constexpr int KT = 64, D = 64, QT = 128, NT = 512, NSTG = 3;
+constexpr int KT = 64, D = 64, QT = 128, NT = 512;
+constexpr int NKS = 2, NVS = 3;  // K / V stages (K fragments are read one iteration ahead, see the schedule in the kernel)
 constexpr float NEG_BIG = -1.0e30f;
 constexpr int RS = D * 2;       // V row stride in LDS
 constexpr int PL = KT * D * 2;  // one bf16 plane of a K or V tile
@@ -35,15 +41,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
 template <bool X3>
 __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p, const int q_tiles, const int has_x) {
-  constexpr int STAGE = (X3 ? 4 : 2) * PL;  // X3: [K hi | K lo | V hi | V lo], bf16: [K | V]
-  constexpr int KLO = PL;
-  constexpr int VOFF = X3 ? 2 * PL : PL;
-  constexpr int VLO = PL;
+  constexpr int TST = (X3 ? 2 : 1) * PL;    // one staged tile of K or V (X3: [hi | lo])
+  constexpr int KLO = PL, VLO = PL;
+  constexpr int VBASE = NKS * TST;          // LDS: NKS K stages, then NVS V stages
   constexpr int NR = X3 ? 2 : 1;            // 16-byte registers per thread, tile and tensor
   constexpr int KS = D / 16, DT = D / 32;
   constexpr int NM = X3 ? 3 : 1;            // MFMAs per product
   constexpr int MERGE_BYTES = (4 * 32 + 64) * (D + 2) * 4;  // end-of-kernel merge areas (key halves, side-path groups)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTG * STAGE > MERGE_BYTES ? NSTG * STAGE : MERGE_BYTES];
+  constexpr int RING_BYTES = (NKS + NVS) * TST;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES > MERGE_BYTES ? RING_BYTES : MERGE_BYTES];
 
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
@@ -93,18 +99,15 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p
   constexpr int ESZ = X3 ? 4 : 2;
   const unsigned char* kbase = (const unsigned char*)p.k + ((int64_t)b * p.k_sb + (int64_t)h * p.k_sh) * ESZ + ch * (8 * ESZ);
   const unsigned char* vbase = (const unsigned char*)p.v + ((int64_t)b * p.v_sb + (int64_t)h * p.v_sh) * ESZ + ch * (8 * ESZ);
-  struct Regs { u32x4v k[NR], v[NR]; };
-  auto load_tile = [&](int kt, Regs& rg) {
+  auto load_rows = [&](const unsigned char* base, int64_t row_stride, int kt, u32x4v (&r)[NR]) {
     int key = kt * KT + ld_key;
     if (key > p.Nk - 1) key = p.Nk - 1;  // clamped: finite values, their scores are masked / never read
-    const unsigned char* kp = kbase + (int64_t)key * p.k_sn * ESZ;
-    const unsigned char* vp = vbase + (int64_t)key * p.v_sn * ESZ;
+    const unsigned char* rp = base + (int64_t)key * row_stride * ESZ;
 #pragma unroll
-    for (int c = 0; c < NR; ++c) {
-      rg.k[c] = *(const u32x4v*)(kp + 16 * c);
-      rg.v[c] = *(const u32x4v*)(vp + 16 * c);
-    }
+    for (int c = 0; c < NR; ++c) r[c] = *(const u32x4v*)(rp + 16 * c);
   };
+  auto load_k = [&](int kt, u32x4v (&r)[NR]) { load_rows(kbase, p.k_sn, kt, r); };
+  auto load_v = [&](int kt, u32x4v (&r)[NR]) { load_rows(vbase, p.v_sn, kt, r); };
   auto chunk_floats = [&](const u32x4v (&r)[NR], float (&f)[8]) {
     if constexpr (X3) {
       const f32x4v a = __builtin_bit_cast(f32x4v, r[0]), c = __builtin_bit_cast(f32x4v, r[1]);
@@ -120,30 +123,30 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p
   };
   const int k_st = k_off(ld_key, ch);
   const int v_st = ld_key * RS + ((((ch >> 2) ^ ((ld_key >> 1) & 1)) << 2) | (ch & 3)) * 16;  // 64-byte halves swapped by key bit 1
-  auto store_k = [&](int stage, const Regs& rg) {
-    unsigned char* sK = smem + stage * STAGE;
+  auto store_k = [&](int stage, const u32x4v (&r)[NR]) {
+    unsigned char* sK = smem + stage * TST;
     if constexpr (X3) {
       float f[8];
-      chunk_floats(rg.k, f);
+      chunk_floats(r, f);
       uint4 hi, lo;
       split_bf16x8(f, hi, lo);
       *(uint4*)(sK + k_st) = hi;
       *(uint4*)(sK + KLO + k_st) = lo;
     } else {
-      *(u32x4v*)(sK + k_st) = rg.k[0];
+      *(u32x4v*)(sK + k_st) = r[0];
     }
   };
-  auto store_v = [&](int stage, const Regs& rg) {
-    unsigned char* sV = smem + stage * STAGE + VOFF;
+  auto store_v = [&](int stage, const u32x4v (&r)[NR]) {
+    unsigned char* sV = smem + VBASE + stage * TST;
     if constexpr (X3) {
       float f[8];
-      chunk_floats(rg.v, f);
+      chunk_floats(r, f);
       uint4 hi, lo;
       split_bf16x8(f, hi, lo);
       *(uint4*)(sV + v_st) = hi;
       *(uint4*)(sV + VLO + v_st) = lo;
     } else {
-      *(u32x4v*)(sV + v_st) = rg.v[0];
+      *(u32x4v*)(sV + v_st) = r[0];
     }
   };
 
@@ -159,17 +162,22 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p
     chunk_floats(r, qx);
   }
 #define SIU3R_DPP_ADD(x, ctrl) ((x) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), 0xf, 0xf, true)))
-  auto side_path = [&](int tile, const Regs& rg) {
-    float kf_[8], vf_[8];
-    chunk_floats(rg.k, kf_);
-    chunk_floats(rg.v, vf_);
+  // the score of the group's key of a tile is taken while that tile's K row is in the staging registers; it meets the tile's V row
+  // (staged one iteration later) in side_consume
+  auto side_score = [&](int tile, const u32x4v (&rk)[NR]) {
+    float kf_[8];
+    chunk_floats(rk, kf_);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) s = __builtin_fmaf(kf_[e], qx[e], s);
     s = SIU3R_DPP_ADD(s, 0xB1);   // quad_perm [1,0,3,2]
     s = SIU3R_DPP_ADD(s, 0x4E);   // quad_perm [2,3,0,1]
     s = SIU3R_DPP_ADD(s, 0x141);  // row_half_mirror: the other quad of the 8-lane group
-    if (tile * KT + ld_key >= p.Nk) s = NEG_BIG;
+    return tile * KT + ld_key >= p.Nk ? NEG_BIG : s;
+  };
+  auto side_consume = [&](float s, const u32x4v (&rv)[NR]) {
+    float vf_[8];
+    chunk_floats(rv, vf_);
     const float m_new = fmaxf(mx, s);
     const float a = __builtin_amdgcn_exp2f((mx - m_new) * sl2), pw = __builtin_amdgcn_exp2f((s - m_new) * sl2);
     mx = m_new;
@@ -199,11 +207,11 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p
   };
   auto lds_barrier = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(SIU3R_AP_DBG & 8)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
   auto read_k = [&](int stage, bf16x8 (&kf)[KS], bf16x8 (&kfl)[X3 ? KS : 1]) {
-    const unsigned char* sK = smem + stage * STAGE;
+    const unsigned char* sK = smem + stage * TST;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       kf[ks] = as_bf16x8(*(const uint4*)(sK + k_off(k_rd, ks * 2 + lh)));
@@ -213,6 +221,7 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p
   // MFMA i of a score block (X3: lo*hi, hi*lo, hi*hi per k-substep)
   auto s_mfma = [&](int i, f32x16& s, const bf16x8 (&kf)[KS], const bf16x8 (&kfl)[X3 ? KS : 1]) {
     const int ks = i / NM, w = i - ks * NM;
+    if (SIU3R_AP_DBG & 1) { s[i & 15] += __builtin_bit_cast(float, (int)kf[ks][0]); return; }
     if (X3 && w == 0) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl[ks], qf[ks], s, 0, 0, 0);
     else if (X3 && w == 1) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qfl[X3 ? ks : 0], s, 0, 0, 0);
     else s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
@@ -224,6 +233,7 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p
   bool grew = false;
   bf16x8 ph[2], plo[X3 ? 2 : 1];
   auto softmax_group = [&](int g, f32x16& s) {
+    if ((SIU3R_AP_DBG & 2) && g >= 1 && g <= 8) return;
     if (g == 0) {
       float mxv = fmaxf(s[0], s[1]);
 #pragma unroll
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p
   };
   struct VFrag { s16x4 a0, a1, b0, b1; };
   auto read_v = [&](int stage, VFrag (&vf)[2][DT]) {
-    const unsigned char* sV = smem + stage * STAGE + VOFF;
+    const unsigned char* sV = smem + VBASE + stage * TST;
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
@@ -290,6 +300,7 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p
   auto pv_mfma = [&](int i, const VFrag (&vf)[2][DT]) {
     const int blk = i / NM, w = i - blk * NM;
     const int sb = blk / DT, dt = blk - sb * DT;
+    if (SIU3R_AP_DBG & 1) { oacc[dt][i & 15] += (float)vf[sb][dt].a0[0]; return; }
     const bf16x8 vhi = __builtin_bit_cast(bf16x8, __builtin_shufflevector(vf[sb][dt].a0, vf[sb][dt].a1, 0, 1, 2, 3, 4, 5, 6, 7));
     if (X3 && w == 0) {
       const bf16x8 vlo = __builtin_bit_cast(bf16x8, __builtin_shufflevector(vf[sb][dt].b0, vf[sb][dt].b1, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -301,84 +312,100 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p
     }
   };
 
-  // ---- prologue: tiles 0 and 1 in LDS, tile 2 in registers, S of tile 0
-  Regs rg;
-  load_tile(0, rg);
-  store_k(0, rg);
-  store_v(0, rg);
-  if (do_x) side_path(0, rg);
-  load_tile(1, rg);
-  store_k(1, rg);
-  store_v(1, rg);
-  if (do_x) side_path(1, rg);
-  load_tile(2, rg);
+  // ---- schedule.  Iteration kt enters with S(kt) in s_cur and the K fragments of tile kt+1 in registers, and
+  //   reads the V fragments of tile kt (stored two iterations ago)                       -- latency under phase 1
+  //   phase 1: S(kt+1) MFMAs  ||  softmax of S(kt)
+  //   reads the K fragments of tile kt+2 (stored last iteration) for the NEXT iteration  -- latency under phase 2
+  //   phase 2: P V(kt) MFMAs  ||  split / store of K(kt+3) and V(kt+2), side path, global loads of K(kt+4) and V(kt+3)
+  //   barrier
+  // so that no LDS read sits between a barrier and the MFMAs that need it.  K ring: 2 stages (tile kt+2 readable, kt+3 being written:
+  // the stage of tile kt+1, whose fragments left it before the previous barrier); V ring: 3 stages (kt, kt+1, kt+2).
+  u32x4v rk[NR], rv[NR];
+  float s_pend = NEG_BIG;  // side path: score of the tile whose V row is staged next
+  load_k(0, rk);
+  load_v(0, rv);
+  store_k(0, rk);
+  store_v(0, rv);
+  if (do_x) side_consume(side_score(0, rk), rv);
+  load_k(1, rk);
+  load_v(1, rv);
+  store_k(1, rk);
+  store_v(1, rv);
+  if (do_x) side_consume(side_score(1, rk), rv);
+  load_k(2, rk);
+  load_v(2, rv);
   lds_barrier();
   f32x16 s_cur;
 #pragma unroll
   for (int r = 0; r < 16; ++r) s_cur[r] = 0.f;
-  {
-    bf16x8 kf[KS], kfl[X3 ? KS : 1];
-    read_k(0, kf, kfl);
+  bf16x8 kf[KS], kfl[X3 ? KS : 1];
+  read_k(0, kf, kfl);
 #pragma unroll
-    for (int i = 0; i < NSM; ++i) s_mfma(i, s_cur, kf, kfl);
-  }
+  for (int i = 0; i < NSM; ++i) s_mfma(i, s_cur, kf, kfl);
+  read_k(1, kf, kfl);
+  lds_barrier();  // every wave holds its fragments of K(0) and K(1): stage 0 may take K(2)
+  store_k(0, rk);
+  if (do_x) s_pend = side_score(2, rk);
+  load_k(3, rk);
+  lds_barrier();  // K(2) is readable from iteration 0 on
 
-  int st_v = 0, st_k = 1, st_w = 2;  // stage of tile kt (V), kt + 1 (K), kt + 2 (written)
+  int sv_r = 0, sv_w = 2;  // V stage of tile kt / kt + 2
   for (int kt = 0; kt < nkt - 1; ++kt) {
-    // phase 1: S of tile kt + 1  ||  softmax of tile kt
+    VFrag vf[2][DT];
+    // phase 1.  Chunk i = MFMA i + its share of the softmax instructions.  The empty asm statements carry the next MFMA's A operand and
+    // the softmax state: they are ordered among themselves, so neither instruction selection nor the scheduler can regroup the chunks
+    // (sched_group_barrier pipelines left all MFMAs in front of the VALU work here).
     f32x16 s_nxt;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s_nxt[r] = 0.f;
-    {
-      bf16x8 kf[KS], kfl[X3 ? KS : 1];
-      read_k(st_k, kf, kfl);
-      // chunk i = MFMA i + its share of the softmax instructions.  The empty asm statements carry the next MFMA's A operand and the
-      // softmax state: they are ordered among themselves, so neither instruction selection nor the scheduler can regroup the chunks
-      // (sched_group_barrier pipelines left all MFMAs in front of the VALU work here).
 #pragma unroll
-      for (int i = 0; i < NSM; ++i) {
-        s_mfma(i, s_nxt, kf, kfl);
+    for (int i = 0; i < NSM; ++i) {
+      s_mfma(i, s_nxt, kf, kfl);
+      if (i == 0) read_v(sv_r, vf);  // (behind the first MFMA: in front of it, the MFMA would wait for the first of these reads)
 #pragma unroll
-        for (int g = i * NV / NSM; g < (i + 1) * NV / NSM; ++g) softmax_group(g, s_cur);
-        if (i + 1 < NSM) {
-          const int ks1 = (i + 1) / NM;
-          if (X3 && (i + 1) % NM == 0) asm volatile("" : "+v"(kfl[X3 ? ks1 : 0]), "+v"(s_cur), "+v"(nm), "+v"(psum));
-          else asm volatile("" : "+v"(kf[ks1]), "+v"(s_cur), "+v"(nm), "+v"(psum));
-        }
+      for (int g = i * NV / NSM; g < (i + 1) * NV / NSM; ++g) softmax_group(g, s_cur);
+      if (i + 1 < NSM) {
+        const int ks1 = (i + 1) / NM;
+        if (X3 && (i + 1) % NM == 0) asm volatile("" : "+v"(kfl[X3 ? ks1 : 0]), "+v"(s_cur), "+v"(nm), "+v"(psum));
+        else asm volatile("" : "+v"(kf[ks1]), "+v"(s_cur), "+v"(nm), "+v"(psum));
       }
-      // (a side-effecting use above the rescale branch: without it the exponentials sink past the branch, out of the MFMAs' shadow)
-      if constexpr (X3) asm volatile("" ::"v"(ph[0]), "v"(ph[1]), "v"(plo[0]), "v"(plo[1]), "v"(l_run));
-      else asm volatile("" ::"v"(ph[0]), "v"(ph[1]), "v"(l_run));
-      __builtin_amdgcn_sched_barrier(0);
     }
+    // (a side-effecting use above the rescale branch: without it the exponentials sink past the branch, out of the MFMAs' shadow)
+    if constexpr (X3) asm volatile("" ::"v"(ph[0]), "v"(ph[1]), "v"(plo[0]), "v"(plo[1]), "v"(l_run));
+    else asm volatile("" ::"v"(ph[0]), "v"(ph[1]), "v"(l_run));
+    __builtin_amdgcn_sched_barrier(0);
     rescale_o();
-    // phase 2: P V of tile kt  ||  split / store of tile kt + 2, side path, loads of tile kt + 3
-    {
-      VFrag vf[2][DT];
-      read_v(st_v, vf);
+    // phase 2
+    read_k(kt & 1, kf, kfl);  // K(kt+2)
 #pragma unroll
-      for (int i = 0; i < NPV; ++i) {
-        pv_mfma(i, vf);
-        if (i == 0) store_k(st_w, rg);
-        if (i == NPV / 3) store_v(st_w, rg);
-        if (i == 2 * NPV / 3) {
-          if (do_x) side_path(kt + 2, rg);
+    for (int i = 0; i < NPV; ++i) {
+      pv_mfma(i, vf);
+      if (!(SIU3R_AP_DBG & 4)) {
+        if (i == 0) {
+          store_k((kt + 1) & 1, rk);  // K(kt+3)
+          if (do_x) {
+            const float s_new = side_score(kt + 3, rk);
+            side_consume(s_pend, rv);  // tile kt+2
+            s_pend = s_new;
+          }
         }
-        if (i == NPV - 1) load_tile(kt + 3, rg);
-        if (i + 1 < NPV) {
-          const int blk1 = (i + 1) / NM, sb1 = blk1 / DT, dt1 = blk1 - sb1 * DT;
-          if (X3 && (i + 1) % NM == 0) asm volatile("" : "+v"(vf[sb1][dt1].b0)::"memory");
-          else asm volatile("" : "+v"(vf[sb1][dt1].a0)::"memory");
+        if (i == NPV / 3) store_v(sv_w, rv);  // V(kt+2)
+        if (i == NPV - 1) {
+          load_k(kt + 4, rk);
+          load_v(kt + 3, rv);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < NPV) {
+        const int blk1 = (i + 1) / NM, sb1 = blk1 / DT, dt1 = blk1 - sb1 * DT;
+        if (X3 && (i + 1) % NM == 0) asm volatile("" : "+v"(vf[sb1][dt1].b0)::"memory");
+        else asm volatile("" : "+v"(vf[sb1][dt1].a0)::"memory");
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
     s_cur = s_nxt;
-    st_v = st_k;
-    st_k = st_w;
-    st_w = st_w == NSTG - 1 ? 0 : st_w + 1;
-    // (st_w now names the stage tile kt held, whose K was read in iteration kt - 1 and whose V in this one)
+    sv_r = sv_r == NVS - 1 ? 0 : sv_r + 1;
+    sv_w = sv_w == NVS - 1 ? 0 : sv_w + 1;
   }
   {  // last tile: ragged key mask, softmax, P V
     const int kt = nkt - 1;
@@ -391,10 +418,11 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p
     for (int g = 0; g < NV; ++g) softmax_group(g, s_cur);
     rescale_o();
     VFrag vf[2][DT];
-    read_v(st_v, vf);
+    read_v(sv_r, vf);
 #pragma unroll
     for (int i = 0; i < NPV; ++i) pv_mfma(i, vf);
   }
+  // (the side path has consumed tiles 0 .. nkt: every store of the loop met its V row; tiles >= nkt carry masked scores)
 
   // ---- merge the two key halves of every query group (odd wave parks (m, l, O), even wave folds them into its own) and the 64
   // 8-lane groups of the side path; then write O / l
