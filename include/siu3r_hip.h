@@ -181,9 +181,18 @@ int siu3r_pack_image_nhwc(const float* img, void* out, int out_dtype, int N, int
 int siu3r_resize_bilinear(const void* x, int x_dtype, void* y, int y_dtype, const void* addend, int add_dtype,
                           const float* ch_scale, const float* ch_shift, int N, int IH, int IW, int OH, int OW,
                           int C, int align_corners, void* stream);
+/* the same on batch-strided inputs: x [N,IH,IW,C] / addend [N,OH,OW,C] whose batch items lie x_batch_stride / addend_batch_stride
+ * elements apart (token maps that are views of a longer per-item sequence: vit_adapter.py:393-433 reads them in place) */
+int siu3r_resize_bilinear_strided(const void* x, int x_dtype, void* y, int y_dtype, const void* addend, int add_dtype,
+                                  const float* ch_scale, const float* ch_shift, int N, int IH, int IW, int OH, int OW,
+                                  int C, int align_corners, int64_t x_batch_stride, int64_t addend_batch_stride, void* stream);
 /* y = x*scale[c] + shift[c] (+ addend) ; eval-mode BatchNorm folded (vit_adapter.py:436-440) */
 int siu3r_affine_add(const void* x, int x_dtype, const void* addend, int add_dtype, void* y, int y_dtype,
                      const float* ch_scale, const float* ch_shift, int64_t rows, int C, void* stream);
+/* rows = batch items x rows_per_batch; batch items of x / addend lie *_batch_stride elements apart; y is dense */
+int siu3r_affine_add_strided(const void* x, int x_dtype, const void* addend, int add_dtype, void* y, int y_dtype,
+                             const float* ch_scale, const float* ch_shift, int64_t rows, int C, int64_t rows_per_batch,
+                             int64_t x_batch_stride, int64_t addend_batch_stride, void* stream);
 /* 3x3 stride-2 pad-1 max pool, NHWC (vit_adapter.py:226) */
 int siu3r_maxpool3x3s2(const void* x, void* y, int dtype, int N, int IH, int IW, int C, void* stream);
 /* depth-wise 3x3 + bias + GELU over the 3 token scales of the adapter ConvFFN (vit_adapter.py:16-59) */

@@ -99,6 +99,8 @@ SIGNATURES = {
     "siu3r_pack_image_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "siu3r_resize_bilinear": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "siu3r_affine_add": [_P, _I, _P, _I, _P, _I, _P, _P, _L, _I, _P],
+    "siu3r_resize_bilinear_strided": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _L, _P],
+    "siu3r_affine_add_strided": [_P, _I, _P, _I, _P, _I, _P, _P, _L, _I, _L, _L, _L, _P],
     "siu3r_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _I, _P],
     "siu3r_dwconv3x3_gelu": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "siu3r_msdeform_sample": [_P, _I, _P, _P, C.POINTER(C.c_int32), _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],

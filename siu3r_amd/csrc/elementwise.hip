@@ -182,7 +182,7 @@ __device__ __forceinline__ void src_index(int o, int in, int out, int align, int
 
 __global__ void resize_kernel(const void* x, int x_dtype, void* y, int y_dtype, const void* addend, int add_dtype,
                               const float* ch_scale, const float* ch_shift, int N, int IH, int IW, int OH, int OW,
-                              int C, int align) {
+                              int C, int align, int64_t x_bs, int64_t add_bs) {
   const int C4 = C >> 2;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)N * OH * OW * C4;
@@ -197,18 +197,18 @@ __global__ void resize_kernel(const void* x, int x_dtype, void* y, int y_dtype, 
   float ly, lx;
   src_index(oy, IH, OH, align, y0, y1, ly);
   src_index(ox, IW, OW, align, x0, x1, lx);
-  const int64_t base = (int64_t)n * IH * IW;
-  const f32x4v v00 = load4(x, x_dtype, (base + (int64_t)y0 * IW + x0) * C + c);
-  const f32x4v v01 = load4(x, x_dtype, (base + (int64_t)y0 * IW + x1) * C + c);
-  const f32x4v v10 = load4(x, x_dtype, (base + (int64_t)y1 * IW + x0) * C + c);
-  const f32x4v v11 = load4(x, x_dtype, (base + (int64_t)y1 * IW + x1) * C + c);
+  const int64_t base = (int64_t)n * x_bs + c;  // x_bs / add_bs: elements between batch items (a dense map: IH * IW * C)
+  const f32x4v v00 = load4(x, x_dtype, base + ((int64_t)y0 * IW + x0) * C);
+  const f32x4v v01 = load4(x, x_dtype, base + ((int64_t)y0 * IW + x1) * C);
+  const f32x4v v10 = load4(x, x_dtype, base + ((int64_t)y1 * IW + x0) * C);
+  const f32x4v v11 = load4(x, x_dtype, base + ((int64_t)y1 * IW + x1) * C);
   const int64_t oidx = (((int64_t)n * OH + oy) * OW + ox) * C + c;
   f32x4v o;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     o.v[j] = (1.f - ly) * ((1.f - lx) * v00.v[j] + lx * v01.v[j]) + ly * ((1.f - lx) * v10.v[j] + lx * v11.v[j]);
   if (addend) {
-    const f32x4v a = load4(addend, add_dtype, oidx);
+    const f32x4v a = load4(addend, add_dtype, (int64_t)n * add_bs + ((int64_t)oy * OW + ox) * C + c);
 #pragma unroll
     for (int j = 0; j < 4; ++j) o.v[j] += a.v[j];
   }
@@ -219,15 +219,17 @@ __global__ void resize_kernel(const void* x, int x_dtype, void* y, int y_dtype, 
   store4(y, y_dtype, oidx, o);
 }
 
+// rows_pb: rows per batch item; x_bs / add_bs: elements between batch items of x / addend (dense: rows_pb * C); y is dense
 __global__ void affine_add_kernel(const void* x, int x_dtype, const void* addend, int add_dtype, void* y, int y_dtype,
-                                  const float* ch_scale, const float* ch_shift, int64_t rows, int C) {
+                                  const float* ch_scale, const float* ch_shift, int64_t rows, int C, int64_t rows_pb, int64_t x_bs, int64_t add_bs) {
   const int C4 = C >> 2;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * C4) return;
   const int c = (int)(idx % C4) * 4;
-  f32x4v o = load4(x, x_dtype, idx * 4);
+  const int64_t row = idx / C4, n = row / rows_pb, r = row - n * rows_pb;
+  f32x4v o = load4(x, x_dtype, n * x_bs + r * C + c);
   if (addend) {
-    const f32x4v a = load4(addend, add_dtype, idx * 4);
+    const f32x4v a = load4(addend, add_dtype, n * add_bs + r * C + c);
 #pragma unroll
     for (int j = 0; j < 4; ++j) o.v[j] += a.v[j];
   }
@@ -653,22 +655,40 @@ extern "C" int siu3r_pack_image_nhwc(const float* img, void* out, int out_dtype,
   return 0;
 }
 
+extern "C" int siu3r_resize_bilinear_strided(const void* x, int x_dtype, void* y, int y_dtype, const void* addend, int add_dtype,
+                                             const float* ch_scale, const float* ch_shift, int N, int IH, int IW, int OH, int OW, int C,
+                                             int align_corners, int64_t x_batch_stride, int64_t addend_batch_stride, void* stream) {
+  SIU3R_CHECK(x && y && C % 4 == 0, "resize_bilinear: bad arguments (C=%d)", C);
+  SIU3R_CHECK((ch_scale == nullptr) == (ch_shift == nullptr), "resize_bilinear: scale/shift must come together");
+  SIU3R_CHECK(x_batch_stride >= (int64_t)IH * IW * C && x_batch_stride % 4 == 0 && (!addend || (addend_batch_stride >= (int64_t)OH * OW * C && addend_batch_stride % 4 == 0)),
+              "resize_bilinear: batch strides must cover one map and keep 4-element alignment");
+  hipLaunchKernelGGL(resize_kernel, grid1d((int64_t)N * OH * OW * (C / 4)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, addend, add_dtype, ch_scale, ch_shift, N, IH, IW, OH, OW, C, align_corners, x_batch_stride, addend_batch_stride);
+  SIU3R_LAUNCH_CHECK("siu3r_resize_bilinear");
+  return 0;
+}
+
 extern "C" int siu3r_resize_bilinear(const void* x, int x_dtype, void* y, int y_dtype, const void* addend,
                                      int add_dtype, const float* ch_scale, const float* ch_shift, int N, int IH,
                                      int IW, int OH, int OW, int C, int align_corners, void* stream) {
-  SIU3R_CHECK(x && y && C % 4 == 0, "resize_bilinear: bad arguments (C=%d)", C);
-  SIU3R_CHECK((ch_scale == nullptr) == (ch_shift == nullptr), "resize_bilinear: scale/shift must come together");
-  hipLaunchKernelGGL(resize_kernel, grid1d((int64_t)N * OH * OW * (C / 4)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, addend, add_dtype, ch_scale, ch_shift, N, IH, IW, OH, OW, C, align_corners);
-  SIU3R_LAUNCH_CHECK("siu3r_resize_bilinear");
+  return siu3r_resize_bilinear_strided(x, x_dtype, y, y_dtype, addend, add_dtype, ch_scale, ch_shift, N, IH, IW, OH, OW, C, align_corners,
+                                       (int64_t)IH * IW * C, (int64_t)OH * OW * C, stream);
+}
+
+extern "C" int siu3r_affine_add_strided(const void* x, int x_dtype, const void* addend, int add_dtype, void* y, int y_dtype, const float* ch_scale,
+                                        const float* ch_shift, int64_t rows, int C, int64_t rows_per_batch, int64_t x_batch_stride,
+                                        int64_t addend_batch_stride, void* stream) {
+  SIU3R_CHECK(x && y && C % 4 == 0 && rows_per_batch > 0 && rows % rows_per_batch == 0, "affine_add: bad arguments");
+  SIU3R_CHECK(x_batch_stride >= rows_per_batch * C && x_batch_stride % 4 == 0 && (!addend || (addend_batch_stride >= rows_per_batch * C && addend_batch_stride % 4 == 0)),
+              "affine_add: batch strides must cover one batch item and keep 4-element alignment");
+  hipLaunchKernelGGL(affine_add_kernel, grid1d(rows * (C / 4)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, addend, add_dtype, y, y_dtype, ch_scale, ch_shift, rows, C,
+                     rows_per_batch, x_batch_stride, addend_batch_stride);
+  SIU3R_LAUNCH_CHECK("siu3r_affine_add");
   return 0;
 }
 
 extern "C" int siu3r_affine_add(const void* x, int x_dtype, const void* addend, int add_dtype, void* y, int y_dtype,
                                 const float* ch_scale, const float* ch_shift, int64_t rows, int C, void* stream) {
-  SIU3R_CHECK(x && y && C % 4 == 0, "affine_add: bad arguments");
-  hipLaunchKernelGGL(affine_add_kernel, grid1d(rows * (C / 4)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, addend, add_dtype, y, y_dtype, ch_scale, ch_shift, rows, C);
-  SIU3R_LAUNCH_CHECK("siu3r_affine_add");
-  return 0;
+  return siu3r_affine_add_strided(x, x_dtype, addend, add_dtype, y, y_dtype, ch_scale, ch_shift, rows, C, rows, rows * C, rows * C, stream);
 }
 
 extern "C" int siu3r_maxpool3x3s2(const void* x, void* y, int dtype, int N, int IH, int IW, int C, void* stream) {

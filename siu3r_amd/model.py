@@ -615,7 +615,7 @@ class CroCoViTAdapter:
         if i == 3:
             for j in range(2):
                 a["cc"] = self._extractor(f"adapter.interactions.3.extra_extractors.{j}", a["cc"], a["ref"], x, h, w)
-        a["outs"].append(x.contiguous().view(Z, h, w, -1))  # layout plumbing: strip-view -> dense NHWC
+        a["outs"].append(x.view(Z, h, w, -1))  # the block's patch tokens as an NHWC map, read in place (batch-strided: the intrinsics token follows each item)
 
     def finish(self, a):
         ctx = self.ctx
@@ -623,9 +623,10 @@ class CroCoViTAdapter:
         cc, c1 = a["cc"], a["c1"]
         # bf16 mode: the level-2 slice is copied out as bf16, so that the 8192 x 4096 x 1024 conv-transpose below runs on the LDS-DMA
         # GEMM instead of the fp32-A kernel (0.34 -> 0.14 ms on the segmentation chain); bf16x3 keeps fp32
-        c2 = (cc[:, :n2].contiguous() if ctx.split else cc[:, :n2].to(ctx.act)).view(Z, 2 * h, 2 * w, -1)
-        c3 = cc[:, n2:n2 + n3].contiguous().view(Z, h, w, -1)
-        c4 = cc[:, n2 + n3:].contiguous().view(Z, h // 2, w // 2, -1)
+        # the three levels are slices of the token sequence, read in place (batch-strided views)
+        c2 = (cc[:, :n2] if ctx.split else cc[:, :n2].to(ctx.act)).view(Z, 2 * h, 2 * w, -1)
+        c3 = cc[:, n2:n2 + n3].view(Z, h, w, -1)
+        c4 = cc[:, n2 + n3:].view(Z, h // 2, w // 2, -1)
         c1 = ops.conv_transpose2d(c2, ctx.w.convT("adapter.up"), out_dtype=torch.float32, residual=c1)
         x1, x2, x3, x4 = a["outs"]
         s1, b1 = ctx.w.bn_affine("adapter.norm1")

@@ -466,16 +466,23 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride=1, pad=0, out_dtype=torc
 
 
 def conv_transpose2d(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, residual=None):
-    """ConvTranspose2d with kernel == stride (pixel shuffle epilogue): [B,IH,IW,Cin] -> [B,IH*up,IW*up,Cout]."""
+    """ConvTranspose2d with kernel == stride (pixel shuffle epilogue): [B,IH,IW,Cin] -> [B,IH*up,IW*up,Cout].  x may be a view whose
+    batch items are dense but lie further apart: each item is then one batch of the launch (blockIdx.z)."""
     _gpu(x, residual)
-    assert x.is_contiguous()
     B, IH, IW, Cin = x.shape
+    x_bs = _batch_strided(x, IH * IW * Cin)
     up, cout = pw.meta["up"], pw.meta["cout"]
     out = torch.empty((B, IH * up, IW * up, cout), dtype=out_dtype, device=x.device)
     p = GemmParams()
     _fill_common(p, x, pw, out, ACT_NONE, residual, False)
-    p.m, p.lda = B * IH * IW, Cin
     p.out_mode, p.up, p.cout, p.ih, p.iw = 1, up, cout, IH, IW
+    if B == 1 or x_bs == IH * IW * Cin:
+        p.m, p.lda = B * IH * IW, Cin
+    else:
+        assert residual is None or residual.is_contiguous()
+        p.m, p.lda = IH * IW, Cin
+        p.batch, p.sa, p.sw, p.sc = B, x_bs, 0, out[0].numel()
+        p.sr = out[0].numel() if residual is not None else 0
     _gemm_launch(p)
     return out
 
@@ -617,28 +624,44 @@ def image_channels(split: bool) -> int:
     return 4 if split else 8
 
 
+def _batch_strided(t: torch.Tensor, inner: int) -> int:
+    """element stride between the batch items of a [N, ..., C] tensor whose items are dense (`inner` elements each)"""
+    dense = list(torch.empty(t.shape[1:], device="meta").stride())
+    assert list(t.stride()[1:]) == dense and (t.shape[0] == 1 or t.stride(0) >= inner), (t.shape, t.stride())
+    return t.stride(0) if t.shape[0] > 1 else inner
+
+
 def resize_bilinear(x: torch.Tensor, size, align_corners: bool, *, addend=None, ch_scale=None, ch_shift=None,
                     out_dtype=None):
+    """x [N,IH,IW,C] / addend [N,OH,OW,C]: dense, or views whose batch items are dense but lie further apart (token maps cut out of a
+    longer per-item sequence are read in place)."""
     _gpu(x, addend)
-    assert x.is_contiguous()
     N, IH, IW, Cc = x.shape
     OH, OW = size
     out = torch.empty((N, OH, OW, Cc), dtype=out_dtype or x.dtype, device=x.device)
+    x_bs = _batch_strided(x, IH * IW * Cc)
+    a_bs = OH * OW * Cc
     if addend is not None:
-        assert addend.is_contiguous() and addend.shape == out.shape
-    check(_lib.lib().siu3r_resize_bilinear(_p(x), _dt(x), _p(out), _dt(out), _p(addend),
-                                           _dt(addend) if addend is not None else F32, _p(ch_scale), _p(ch_shift),
-                                           N, IH, IW, OH, OW, Cc, int(align_corners), _stream()))
+        assert addend.shape == out.shape
+        a_bs = _batch_strided(addend, OH * OW * Cc)
+    check(_lib.lib().siu3r_resize_bilinear_strided(_p(x), _dt(x), _p(out), _dt(out), _p(addend), _dt(addend) if addend is not None else F32,
+                                                   _p(ch_scale), _p(ch_shift), N, IH, IW, OH, OW, Cc, int(align_corners), x_bs, a_bs, _stream()))
     return out
 
 
 def affine_add(x: torch.Tensor, addend, ch_scale, ch_shift, out_dtype=None):
+    """y = x * scale[c] + shift[c] (+ addend); x / addend [N, ..., C] dense or batch-strided views (see resize_bilinear)."""
     _gpu(x, addend)
-    assert x.is_contiguous() and (addend is None or (addend.is_contiguous() and addend.numel() == x.numel()))
     Cc = x.shape[-1]
+    rows_pb = x[0].numel() // Cc
+    x_bs = _batch_strided(x, rows_pb * Cc)
+    a_bs = rows_pb * Cc
+    if addend is not None:
+        assert addend.numel() == x.numel()
+        a_bs = _batch_strided(addend.view(x.shape) if addend.is_contiguous() else addend, rows_pb * Cc)
     out = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
-    check(_lib.lib().siu3r_affine_add(_p(x), _dt(x), _p(addend), _dt(addend) if addend is not None else F32, _p(out),
-                                      _dt(out), _p(ch_scale), _p(ch_shift), x.numel() // Cc, Cc, _stream()))
+    check(_lib.lib().siu3r_affine_add_strided(_p(x), _dt(x), _p(addend), _dt(addend) if addend is not None else F32, _p(out), _dt(out), _p(ch_scale),
+                                              _p(ch_shift), x.shape[0] * rows_pb, Cc, rows_pb, x_bs, a_bs, _stream()))
     return out
 
 

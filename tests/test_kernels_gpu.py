@@ -466,6 +466,35 @@ print("WIDE_OK")
     assert "WIDE_OK" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["bf16", "bf16x3"])
+def test_batch_strided_views_are_read_in_place(split):
+    """The ViT-Adapter's maps are slices of per-item token sequences (vit_adapter.py:393-433): resize / affine / conv-transpose read the
+    batch-strided views directly and must give what they give on dense copies."""
+    ops = _ops()
+    Z, h, w, C = 2, 8, 6, 64
+    n2, n3, n4 = 4 * h * w, h * w, h * w // 4
+    seq = gen(Z, n2 + n3 + n4, C, seed=101).cuda()
+    tok = gen(Z, h * w + 1, C, seed=102).cuda()          # patch tokens + one trailing token per item
+    c2, c3, c4 = seq[:, :n2].view(Z, 2 * h, 2 * w, C), seq[:, n2:n2 + n3].view(Z, h, w, C), seq[:, n2 + n3:].view(Z, h // 2, w // 2, C)
+    x = tok[:, :-1].view(Z, h, w, C)
+    assert not c3.is_contiguous() and not x.is_contiguous()
+    sc, sh = gen(C, seed=103).cuda() + 1.5, gen(C, seed=104).cuda()
+    for (src, size, add) in [(x, (2 * h, 2 * w), c2), (x, (h // 2, w // 2), c4), (x, (4 * h, 4 * w), None)]:
+        got = ops.resize_bilinear(src, size, False, addend=add, ch_scale=sc, ch_shift=sh)
+        ref = ops.resize_bilinear(src.contiguous(), size, False, addend=None if add is None else add.contiguous(), ch_scale=sc, ch_shift=sh)
+        assert torch.equal(got, ref)
+    assert torch.equal(ops.affine_add(x, c3, sc, sh), ops.affine_add(x.contiguous(), c3.contiguous(), sc, sh))
+    wt, bt = gen(C, 32, 2, 2, seed=105, scale=0.1).cuda(), gen(32, seed=106).cuda()
+    pw = ops.pack_conv_transpose(wt, bt, split)
+    a = c2 if split else c2.to(torch.bfloat16)
+    res = gen(Z, 4 * h, 4 * w, 32, seed=107).cuda()
+    got = ops.conv_transpose2d(a, pw, residual=res)
+    ref = ops.conv_transpose2d(a.contiguous(), pw, residual=res)
+    assert torch.equal(got, ref)
+    check("conv_transpose on a strided view", got, F.conv_transpose2d(a.float().permute(0, 3, 1, 2), wt if split else wt.to(torch.bfloat16).float(), bt, stride=2).permute(0, 2, 3, 1) + res,
+          TOL_F32 if split else TOL_BF16)
+
+
 @pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
 @pytest.mark.parametrize("case", [(2, 3, 257, 300, 64, False), (2, 8, 100, 520, 32, True), (1, 2, 128, 64, 64, True), (1, 8, 100, 2100, 32, True), (2, 4, 37, 1100, 64, False)],
                          ids=["d64", "d32mask", "d64mask1tile", "d32mask_splitkv", "d64_splitkv"])
