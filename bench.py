@@ -49,21 +49,26 @@ PARITY = {"bf16x3": "vs the pinned fp32 oracle, max-normalised: every Gaussian f
           "bf16": "bf16 operand rounding: 2e-2 .. 1e-1 on the fields (covariances worst), label agreement 0.85-0.93"}
 
 
-def pmc_bytes(section, kernels):
-    """HBM-side bytes per launch from the committed counter passes (tools/pmc_cmd.sh: separate FETCH_SIZE / WRITE_SIZE runs, both in
-    KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  kernels: names to sum (each with its launches per unit)."""
+def _family(name):
+    """source-level kernel of an instantiation: `ns::kernel<args>` -> `ns::kernel`"""
+    return name.split("<")[0].strip()
+
+
+def pmc_bytes(section, family):
+    """HBM-side bytes per launch of one source-level kernel (all its template instantiations) from the committed counter passes
+    (tools/pmc_cmd.sh: separate FETCH_SIZE / WRITE_SIZE runs, both in KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950): sum over the instantiations / their launches."""
     if not os.path.exists(PMC_FILE):
         return None, None
     sec = json.load(open(PMC_FILE)).get(section)
     if not sec:
         return None, None
-    total = 0.0
-    for name, per_unit in kernels:
-        e = sec.get(name)
-        if not e or "FETCH_SIZE" not in e or "WRITE_SIZE" not in e:
-            return None, None
-        total += per_unit * (2.0 * e["FETCH_SIZE"]["per_launch"] + e["WRITE_SIZE"]["per_launch"]) * 1024.0
-    return total, f"{PMC_NAME}[{section}]"
+    rows = [e for n, e in sec.items() if _family(n) == family and "FETCH_SIZE" in e and "WRITE_SIZE" in e]
+    launches = sum(e["FETCH_SIZE"]["launches"] for e in rows)
+    if not launches:
+        return None, None
+    total = sum(2.0 * e["FETCH_SIZE"]["total"] + e["WRITE_SIZE"]["total"] for e in rows) * 1024.0
+    return total / launches, f"{PMC_NAME}[{section}] (all instantiations of {family}: {launches} launches)"
 
 
 def pmc_frame_bytes(section, views_per_call):
@@ -208,8 +213,11 @@ def main():
 
 
 def gemm_roofline(model, step, precision, B, H, W):
-    """roofline object of the mode's dominant kernel (largest summed launch time): HIP events around every GEMM launch of one eager
-    single-stream step, queued behind a sleep kernel so that the pairs time the kernels back to back (after the timed region)"""
+    """roofline object of the mode's dominant kernel: HIP events around every GEMM launch of one eager single-stream step, queued behind
+    a sleep kernel so that the pairs time the kernels back to back (after the timed region).  "Kernel" = the source-level kernel (a
+    function template: rocprofv3 lists each instantiation -- tile shape, A-operand mode, fused LayerNorm -- as its own row, and the
+    ping-pong GEMM runs as a dozen of them); the dominant one is the one with the largest summed launch time.  achieved = its
+    launches' 2 M N K / their summed durations; `instantiations` lists the rows it is made of."""
     from siu3r_amd import ops
 
     timer = ops.KernelTimer()
@@ -220,26 +228,38 @@ def gemm_roofline(model, step, precision, B, H, W):
     model._ctx.concurrent = conc
     ops.set_kernel_timer(None)
     summ = timer.summary()
-    name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+    fams = {}
+    for k, v in summ.items():
+        f = fams.setdefault(_family(k), dict(launches=0, flops=0.0, ms=0.0))
+        for key in f:
+            f[key] += v[key]
+    name, d = max(fams.items(), key=lambda kv: kv[1]["ms"])
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-    passes = 3 if "x3" in name else 1
+    passes = 3 if precision == "bf16x3" else 1
     traffic, traffic_src = (None, None)
     if B == 1 and (H, W) == (512, 512):
-        traffic, traffic_src = pmc_bytes(f"bench_{precision}", [(name, 1.0)])
+        traffic, traffic_src = pmc_bytes(f"bench_{precision}", name)
     busy = None
-    bf = BUSY_FILE
-    if os.path.exists(bf):
-        busy = json.load(open(bf)).get(f"bench_{precision}", {}).get("kernels", {}).get(name, {}).get("mfma_busy_frac")
+    if os.path.exists(BUSY_FILE):
+        rows = [v for n, v in json.load(open(BUSY_FILE)).get(f"bench_{precision}", {}).get("kernels", {}).items() if _family(n) == name]
+        act = sum(v["GRBM_GUI_ACTIVE"] for v in rows)
+        if act > 0:
+            busy = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] for v in rows) / (act / 8.0 * 1024.0)
+    variants = lambda pred: {k: {"launches": v["launches"], "ms": v["ms"], "avg_launch_us": v["ms"] * 1e3 / v["launches"],
+                                 "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]) if pred(k)}
     return {
         "kernel": name,
         "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
         "mfma_passes_per_product": passes, "mfma_issue_frac": achieved * passes / MFMA_BF16_PEAK_TFLOPS,
-        "mfma_busy_counter_frac": busy, "mfma_busy_source": "profiles/" + os.path.basename(BUSY_FILE) + " (SQ_VALU_MFMA_BUSY_CYCLES pass)" if busy is not None else None,
+        "mfma_busy_counter_frac": busy, "mfma_busy_source": "profiles/" + os.path.basename(BUSY_FILE) + " (SQ_VALU_MFMA_BUSY_CYCLES pass, all instantiations)" if busy is not None else None,
         "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
         "algorithmic_flops_per_launch_avg": d["flops"] / d["launches"],
+        "share_of_gemm_time": d["ms"] / sum(v["ms"] for v in summ.values()),
         "gemm_time_ms_per_step": sum(v["ms"] for v in summ.values()),
-        "all_variants": {k: {"launches": v["launches"], "ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()},
+        "gemm_tflops_all_kernels": sum(v["flops"] for v in summ.values()) / (sum(v["ms"] for v in summ.values()) * 1e-3) / 1e12,
+        "instantiations": variants(lambda k: _family(k) == name),
+        "other_gemm_kernels": variants(lambda k: _family(k) != name),
     }
 
 

@@ -902,6 +902,9 @@ class VideoMask2FormerForVideoSegmentation:
 # ==================================================================================================
 # whole model (model.py:31-389)
 # ==================================================================================================
+_PTS0_MAIN = os.environ.get("SIU3R_PTS0_MAIN", "0") == "1"
+
+
 class _Run:
     """State of one pass through the network body (the static buffers of a captured shape, in graph mode)."""
 
@@ -1121,7 +1124,13 @@ class SIU3RModel:
         for s_ in hs:
             if s_ is not main:
                 s_.wait_stream(main)
-        for name, s_ in zip(("gs0", "gsr", "ptsr", "pts0"), hs + [main, main]):
+        # pts0 rides on the segmentation stream, behind Mask2Former: that chain ends ~2.5 ms after the heads start, and the head of view 0
+        # then overlaps the other three instead of running alone after them (21.8 -> 20.9 ms body at B = 1; SIU3R_PTS0_MAIN=1 restores
+        # the two pts3d heads back to back on the main stream)
+        pts0_stream = seg_stream if (par and not _PTS0_MAIN) else main
+        if pts0_stream is not main:
+            pts0_stream.wait_stream(main)  # the decoder's outputs
+        for name, s_ in zip(("gs0", "gsr", "ptsr", "pts0"), hs + [main, pts0_stream]):
             with torch.cuda.stream(s_):
                 run(name, stages[name])
         for s_ in hs + [seg_stream]:
