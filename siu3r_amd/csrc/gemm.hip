@@ -358,14 +358,14 @@ extern "C" int siu3r_gemm_tune(int key, int value) {
 #include "gemm_tuned.h"
 
 namespace {
-// measured tile choice of this exact problem, 0 if it is not in the table
-int tuned_cfg(const siu3r_gemm_params& p, bool x3) {
+// measured (tile, split-K) choice of this exact problem, nullptr if it is not in the table
+const siu3r_tuned_entry* tuned_entry(const siu3r_gemm_params& p, bool x3) {
   const int Z = p.batch > 0 ? p.batch : 1, ln = p.ln_stats ? 1 : 0;
   for (const siu3r_tuned_entry* e = kTuned; e->m; ++e)
     if (e->m == p.m && e->n == p.n && e->k == p.k && e->batch == Z && e->a_mode == p.a_mode && e->out_mode == p.out_mode && e->kh == p.kh &&
         e->stride == p.stride && e->x3 == (x3 ? 1 : 0) && e->ln == ln)
-      return e->tile_cfg;
-  return 0;
+      return e;
+  return nullptr;
 }
 
 // Cost model (microseconds), fitted to graph-timed replays of the 495 GEMM launches of a real 2 x 512^2 step under every tile
@@ -386,10 +386,16 @@ void plan(const siu3r_gemm_params& p, siu3r_gemm_plan_t& pl) {
   const int pp_mode = (g_disable_dma || p.a_mode == 2) ? -1 : siu3r_gemm_pp_mode(p);
   const int dma_mode = g_disable_dma ? -1 : (x3 ? siu3r_gemm_dma_x3_mode(p) : siu3r_gemm_dma_mode(p));
   int force = p.tile_cfg ? p.tile_cfg : g_tile_default;
-  if (force == 0 && !g_no_tuned) force = tuned_cfg(p, x3);
+  const bool may_split = !g_no_splitk && p.splitk != 1 && p.sk_ws && p.sk_cnt;
+  int want_s = p.splitk;  // 0 auto, 1 never, > 1 exactly
+  if (force == 0 && !g_no_tuned) {
+    if (const siu3r_tuned_entry* e = tuned_entry(p, x3)) {
+      force = e->tile_cfg;
+      if (e->splitk > 0 && p.splitk == 0) want_s = (e->splitk > 1 && !may_split) ? 1 : e->splitk;
+    }
+  }
   const int64_t Z = p.batch > 0 ? p.batch : 1;
   const int ksteps = p.kpad / (x3 ? 16 : 32);  // steps of 64 operand-row bytes
-  const bool may_split = !g_no_splitk && p.splitk != 1 && p.sk_ws && p.sk_cnt;
   float best_t = 0.f;
   int best = -1, best_s = 1, best_skinny = 0;
   for (int ci = 0; ci < 4; ++ci) {
@@ -406,12 +412,13 @@ void plan(const siu3r_gemm_params& p, siu3r_gemm_plan_t& pl) {
       const int mrows = p.m - skinny;
       const int64_t tiles = (int64_t)((mrows + c.bm - 1) / c.bm) * ((p.n + c.bn - 1) / c.bn) * Z;
       const bool can_split = may_split && (is_pp || (dma_mode >= 0 && c.bn == 64));
-      const int smax = p.splitk > 1 ? p.splitk : (can_split ? 8 : 1);
-      for (int S = (p.splitk > 1 ? p.splitk : 1); S <= smax; S *= 2) {
+      const bool fixed_s = want_s >= 1 && (want_s == 1 || can_split);
+      const int smax = fixed_s ? want_s : (can_split ? 8 : 1);
+      for (int S = (fixed_s ? want_s : 1); S <= smax; S *= 2) {
         if (S > 1) {
-          if (ksteps / S < (is_pp ? 8 : 16) && p.splitk <= 1) break;  // every slice keeps a few steps (and whole phases)
+          if (ksteps / S < (is_pp ? 8 : 16) && !fixed_s) break;  // every slice keeps a few steps (and whole phases)
           if (tiles * S * c.bm * c.bn > p.sk_ws_floats || tiles > p.sk_cnt_n) break;
-          if (tiles >= 2 * c.slots && p.splitk <= 1) break;
+          if (tiles >= 2 * c.slots && !fixed_s) break;
         }
         const int64_t wgs = tiles * S;
         const int64_t rounds = (wgs + c.slots - 1) / c.slots;

@@ -1,6 +1,6 @@
 """Replay tuner: record every siu3r_gemm parameter block of one real model step (all step buffers kept alive), then graph-time each
 unique launch under every tile configuration (siu3r_gemm_params.tile_cfg) and print what the library's cost model picks next to the
-measured best.  python tools/gemm_replay.py [B] [precision] [out.json]"""
+measured best.  python tools/gemm_replay.py [B] [precision] [out.json] [--sweep-s]   (--sweep-s: also every split-K count per tile)"""
 import ctypes as C
 import json
 import os
@@ -84,14 +84,15 @@ for p in records:
     uniq.setdefault(sig(p), []).append(p)
 
 
-def time_launch(p, cfg, n=10):
+def time_launch(p, cfg, S=0, n=10):
+    """cfg: tile configuration (0 = the library's choice); S: split-K slices (0 = the library's choice for that tile)"""
     q = _lib.GemmParams()
     C.memmove(C.byref(q), C.byref(p), C.sizeof(q))
     q.tile_cfg = cfg
-    q.splitk = 0
+    q.splitk = S
     q.sk_ws, q.sk_cnt, q.sk_ws_floats, q.sk_cnt_n = ws.data_ptr(), cnt.data_ptr(), ws.numel(), cnt.numel()
     pl = ops.gemm_plan(q)
-    if cfg != 0 and pl.tile_cfg != cfg:
+    if (cfg != 0 and pl.tile_cfg != cfg) or (S != 0 and pl.splitk != S):
         return None, pl
     st = torch.cuda.current_stream().cuda_stream
     lib = _lib.lib()
@@ -116,25 +117,46 @@ def time_launch(p, cfg, n=10):
 
 
 rows = []
-print("     M      N      K   Z am om kh ln rp rs |  n | auto: cfg S sk   us | 128x64 us | pp256^2 | pp256x128 | pp128^2 | best")
+SWEEP_S = "--sweep-s" in sys.argv
+print("     M      N      K   Z am om kh ln rp rs |  n | auto: cfg S sk   us | 128x64 us | pp256^2 | pp256x128 | pp128^2 | best (cfg, S)")
 tot_auto = tot_best = tot_old = 0.0
 for s, ps in sorted(uniq.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * kv[0][3] * len(kv[1])):
     p = ps[0]
+    x3 = bool(p.w_x3) and p.a_dtype == _lib.F32
+    ksteps = p.kpad // (16 if x3 else 32)
     res = {}
-    for cfg in (0, -1, 1, 2, 3):
+    ta, pla = time_launch(p, 0)
+    for cfg in (-1, 1, 2, 3):
         t, pl = time_launch(p, cfg)
-        res[cfg] = (t, pl.tile_cfg, pl.splitk, pl.skinny_rows)
-    ta, ca, sa, ska = res[0]
-    cands = {c: res[c][0] for c in (-1, 1, 2, 3) if res[c][0] is not None}
-    bc = min(cands, key=cands.get)
+        if t is None:
+            continue
+        res[(cfg, pl.splitk)] = t
+        if SWEEP_S:
+            for S in (1, 2, 4, 8):
+                if S == pl.splitk or (S > 1 and ksteps // S < (8 if cfg > 0 else 16)):
+                    continue
+                t2, pl2 = time_launch(p, cfg, S)
+                if t2 is not None:
+                    res[(cfg, S)] = t2
+    ca, sa, ska = pla.tile_cfg, pla.splitk, pla.skinny_rows
+    bk = min(res, key=res.get)
     n = len(ps)
     tot_auto += ta * n
-    tot_best += cands[bc] * n
-    tot_old += (cands.get(-1) or ta) * n
-    f = lambda c: f"{cands[c]:8.1f}({res[c][2]})" if c in cands else "       -   "
-    flag = "" if ta <= cands[bc] * 1.06 else "  <-- model picks worse"
-    print(f"{s[0]:6d} {s[1]:6d} {s[2]:6d} {s[3]:3d} {s[4]:2d} {s[5]:2d} {s[6]:2d} {s[7]:2d} {s[8]:2d} {s[9]:2d} | {n:3d} | {ca:3d} {sa} {ska:2d} {ta:7.1f} | {f(-1)} | {f(1)} | {f(2)} | {f(3)} | {bc:2d}{flag}")
-    rows.append(dict(sig=list(s), launches=n, auto=dict(cfg=ca, splitk=sa, skinny=ska, us=ta), us={str(c): cands[c] for c in cands}, splitk={str(c): res[c][2] for c in cands}))
+    tot_best += res[bk] * n
+    olds = [v for (c_, _), v in res.items() if c_ == -1]
+    tot_old += (min(olds) if olds else ta) * n
+
+    def f(c_):
+        cand = {k_: v for k_, v in res.items() if k_[0] == c_}
+        if not cand:
+            return "       -   "
+        k_ = min(cand, key=cand.get)
+        return f"{cand[k_]:8.1f}({k_[1]})"
+
+    flag = "" if ta <= res[bk] * 1.06 else "  <-- model picks worse"
+    print(f"{s[0]:6d} {s[1]:6d} {s[2]:6d} {s[3]:3d} {s[4]:2d} {s[5]:2d} {s[6]:2d} {s[7]:2d} {s[8]:2d} {s[9]:2d} | {n:3d} | {ca:3d} {sa} {ska:2d} {ta:7.1f} | {f(-1)} | {f(1)} | {f(2)} | {f(3)} | {bk}{flag}")
+    rows.append(dict(sig=list(s), launches=n, auto=dict(cfg=ca, splitk=sa, skinny=ska, us=ta), us={f"{c_},{S_}": v for (c_, S_), v in res.items()}))
 print(f"sum over the step: auto {tot_auto/1e3:.2f} ms, best-per-shape {tot_best/1e3:.2f} ms, 128x64 family {tot_old/1e3:.2f} ms")
-if len(sys.argv) > 3:
-    json.dump(dict(batch=B, precision=prec, rows=rows), open(sys.argv[3], "w"), indent=0)
+out = [a for a in sys.argv[3:] if not a.startswith("--")]
+if out:
+    json.dump(dict(batch=B, precision=prec, rows=rows), open(out[0], "w"), indent=0)

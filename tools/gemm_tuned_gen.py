@@ -17,7 +17,9 @@ for f in sys.argv[1:]:
         e["auto"] += r["auto"]["us"] * r["launches"]
         e["auto_cfg"][r["auto"]["cfg"]] = e["auto_cfg"].get(r["auto"]["cfg"], 0) + r["launches"]
         for c, t in r["us"].items():
-            e["us"][int(c)] = e["us"].get(int(c), 0.0) + t * r["launches"]
+            ck = tuple(int(v) for v in c.split(","))  # (tile_cfg, splitk)
+            e["us"][ck] = e["us"].get(ck, 0.0) + t * r["launches"]
+        e["auto_s"] = r["auto"]["splitk"]
         e["ncfg"] = min(e.get("ncfg", 9), len(r["us"]))
 lines, gain = [], 0.0
 for key, e in sorted(agg.items()):
@@ -26,15 +28,15 @@ for key, e in sorted(agg.items()):
         continue
     best = min(full, key=full.get)
     auto_cfg = max(e["auto_cfg"], key=e["auto_cfg"].get)
-    if best == auto_cfg:
+    if best == (auto_cfg, e["auto_s"]):
         continue
-    margin = 0.04 if key[8] else (0.25 if best > 0 else 0.04)
+    margin = 0.05 if key[8] else (0.25 if best[0] > 0 else 0.05)
     if full[best] > e["auto"] * (1.0 - margin):
         continue
     gain += e["auto"] - full[best]
-    lines.append("    {%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d},  // %.1f -> %.1f us per step (%s)" % (*key, best, e["auto"], full[best], e["src"]))
+    lines.append("    {%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d},  // %.1f -> %.1f us per step (%s)" % (*key, best[0], best[1], e["auto"], full[best], e["src"]))
 hdr = open(os.path.join(ROOT, "siu3r_amd", "csrc", "gemm_tuned.h")).read()
 head = hdr[:hdr.index("static const siu3r_tuned_entry kTuned[] = {")]
-out = head + "static const siu3r_tuned_entry kTuned[] = {\n" + "\n".join(lines) + ("\n" if lines else "") + "    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},  // (terminator)\n};\n"
+out = head + "static const siu3r_tuned_entry kTuned[] = {\n" + "\n".join(lines) + ("\n" if lines else "") + "    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},  // (terminator)\n};\n"
 open(os.path.join(ROOT, "siu3r_amd", "csrc", "gemm_tuned.h"), "w").write(out)
 print(f"{len(lines)} entries, {gain / 1e3:.2f} ms of summed launch time over the replayed steps")
