@@ -965,12 +965,30 @@ class SIU3RModel:
         key = (B, V, H, W, images.dtype, K.dtype)
         eager = (not self.use_graph) or return_intermediates or ops.kernel_timer_active() or torch.cuda.is_current_stream_capturing()
         ent = None if eager else self._graphs.get(key)
+        main = torch.cuda.current_stream()
+        pp_state = {}
+
+        def make_after_seg(st_, copy_out):
+            # runs on the segmentation stream right behind Mask2Former: the panoptic device stage and the asynchronous read-back of its
+            # tables overlap the heads; the host picks the tables up (an event) after everything is enqueued
+            def after_seg():
+                seg_o = VideoMask2FormerForVideoSegmentationOutput(st_.seg) if copy_out else st_.seg
+                if copy_out:  # the logits leave the graphs' private memory, which the next replay overwrites
+                    for k_ in ("class_queries_logits", "masks_queries_logits"):
+                        seg_o[k_] = seg_o[k_].clone()
+                        seg_o[k_].record_stream(main)
+                pend = self.processor.begin_panoptic(seg_o, threshold=self.seg_threshold, target_sizes=[(H, W)] * B, label_ids_to_fuse=self.label_ids_to_fuse)
+                for k_ in ("tab", "probs", "kept_idx", "acc_list", "p256", "seg", "sem", "ins"):
+                    pend[k_].record_stream(main)  # allocated on the segmentation stream, read on the caller's
+                pp_state["seg_out"], pp_state["pend"] = seg_o, pend
+            return after_seg
+
         if eager or ent is None:
             if not eager:
                 self._graphs[key] = {"graphs": None}  # first call of this shape: eager (packs weights, fills caches)
             st = _Run(images, K)
-            self._run_stages(st, lambda name, fn: fn())
-            gaussians, seg_out = st.gaussians, st.seg
+            self._run_stages(st, lambda name, fn: fn(), make_after_seg(st, False))
+            gaussians = st.gaussians
         else:
             if ent["graphs"] is None:
                 st = ent["st"] = _Run(images.clone(), K.clone())
@@ -1009,15 +1027,11 @@ class SIU3RModel:
                     e1.record()
                     tl.append((name, e0, e1))
 
-            self._run_stages(st, replay)
-            # the Gaussians come from the eager tail (fresh memory); the logits leave the graphs' private memory, which the
-            # next replay overwrites
+            self._run_stages(st, replay, make_after_seg(st, True))
+            # the Gaussians come from the eager tail (fresh memory)
             gaussians = st.gaussians
-            seg_out = VideoMask2FormerForVideoSegmentationOutput(st.seg)
-            for k_ in ("class_queries_logits", "masks_queries_logits"):
-                seg_out[k_] = seg_out[k_].clone()
-        results = self.processor.post_process_panoptic_segmentation(
-            seg_out, threshold=self.seg_threshold, target_sizes=[(H, W)] * B, label_ids_to_fuse=self.label_ids_to_fuse)
+        seg_out = pp_state["seg_out"]
+        results = self.processor.finish_panoptic(pp_state["pend"])
         if not eager:
             # the channel-last logits / mask features / memory levels live in the graphs' private memory, which the next replay
             # overwrites: they served the post-process above and do not leave with the result
@@ -1078,8 +1092,9 @@ class SIU3RModel:
     def _merged_decoder(self, st) -> bool:
         return self._ctx.fold and st.images.shape[1] == 2
 
-    def _run_stages(self, st, run):
-        """Enqueue the stages with their fork/join edges.  run(name, fn) either calls fn (eager) or replays its graph."""
+    def _run_stages(self, st, run, after_seg=None):
+        """Enqueue the stages with their fork/join edges.  run(name, fn) either calls fn (eager) or replays its graph.  after_seg(): enqueued
+        on the segmentation stream right behind Mask2Former (the device half of the panoptic post-process)."""
         ctx = self._ctx
         stages = dict(self._stages(st))
         main = torch.cuda.current_stream()
@@ -1101,6 +1116,8 @@ class SIU3RModel:
                 run(f"int{k}", stages[f"int{k}"])
         with torch.cuda.stream(seg_stream):
             run("seg", stages["seg"])
+            if after_seg is not None:
+                after_seg()
         # decoder: per layer, view 0 and the other views are independent chains (joined after every layer)
         run("dec_pre", stages["dec_pre"])
         dside = ctx.side_stream(0) if par else main

@@ -26,6 +26,14 @@ class VideoMask2FormerImageProcessor:
                                            label_ids_to_fuse: Optional[Set[int]] = None,
                                            target_sizes: Optional[List[Tuple[int, int]]] = None,
                                            word_embeddings=None, with_query_class_logits: bool = True):
+        pend = self.begin_panoptic(outputs, threshold, mask_threshold, overlap_mask_area_threshold, label_ids_to_fuse, target_sizes, word_embeddings)
+        return self.finish_panoptic(pend, with_query_class_logits)
+
+    def begin_panoptic(self, outputs, threshold: float = 0.5, mask_threshold: float = 0.5, overlap_mask_area_threshold: float = 0.8,
+                       label_ids_to_fuse: Optional[Set[int]] = None, target_sizes: Optional[List[Tuple[int, int]]] = None, word_embeddings=None):
+        """First half: the device stage (probabilities, 256^2 masks, argmax maps, segment table) and an asynchronous copy of the small
+        tables into pinned host memory, all on the CURRENT stream; returns the pending state.  SIU3RModel enqueues this right behind
+        Mask2Former on the segmentation stream, so that it runs beside the heads instead of after them."""
         assert word_embeddings is None, "the refer head has no executable reference behaviour (SURVEY.md A.17)"
         if label_ids_to_fuse is None:
             label_ids_to_fuse = set()
@@ -45,21 +53,42 @@ class VideoMask2FormerImageProcessor:
         probs, scores, labels, kept_idx, n_keep = f32(B, Q, Cc), f32(B, Q), i32(B, Q), i32(B, Q), i32(B)
         p256 = f32(B, T, MASK_SIZE, MASK_SIZE, Q)
         lab_map, area, orig = i32(B, T, H, W), i32(B, Q), i32(B, Q)
-        seg_id, seg_label, seg_fused, seg_score = i32(B, Q), i32(B, Q), i32(B, Q), f32(B, Q)
-        acc_list, n_acc = i32(B, Q), i32(B)
+        # the tables the host reads, in ONE buffer: [seg_id | seg_label | seg_fused | acc_list | seg_score bits] x [B, Q], then n_keep, n_acc
+        tab = i32(5 * B * Q + 2 * B)
+        seg_id, seg_label, seg_fused, acc_list = (tab[i * B * Q:(i + 1) * B * Q].view(B, Q) for i in range(4))
+        seg_score = tab[4 * B * Q:5 * B * Q].view(torch.float32).view(B, Q)
+        n_keep_t, n_acc = tab[5 * B * Q:5 * B * Q + B], tab[5 * B * Q + B:]
         seg, sem, ins = i32(B, T, H, W), i32(B, T, H, W), i32(B, T, H, W)
         fuse_mask = 0
         for c in label_ids_to_fuse:
             assert 0 <= c < 32
             fuse_mask |= 1 << c
         check(_lib.lib().siu3r_panoptic_stage1(
-            _p(class_logits), _p(mcl), _p(probs), _p(scores), _p(labels), _p(kept_idx), _p(n_keep), _p(p256), _p(lab_map),
+            _p(class_logits), _p(mcl), _p(probs), _p(scores), _p(labels), _p(kept_idx), _p(n_keep_t), _p(p256), _p(lab_map),
             _p(area), _p(orig), _p(seg_id), _p(seg_label), _p(seg_fused), _p(seg_score), _p(acc_list), _p(n_acc), _p(seg),
             _p(sem), _p(ins), B, T, Q, Cc, IH, IW, H, W, MASK_SIZE, threshold, mask_threshold, overlap_mask_area_threshold,
             fuse_mask, _stream()))
-        # one device->host read of the small tables (the reference does a .item() per query instead)
-        table = torch.stack([seg_id, seg_label, seg_fused, acc_list]).cpu()
-        sc_h, nk_h, na_h = seg_score.cpu(), n_keep.cpu().tolist(), n_acc.cpu().tolist()
+        # one device->host read of the small tables (the reference does a .item() per query instead), asynchronous into pinned memory
+        host = getattr(self, "_host_tab", None)
+        if host is None or host.numel() != tab.numel():
+            host = self._host_tab = torch.empty(tab.numel(), dtype=torch.int32, pin_memory=True)
+        host.copy_(tab, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return dict(ev=ev, host=host, tab=tab, dims=(B, T, Q, Cc, IH, IW, H, W), probs=probs, kept_idx=kept_idx, acc_list=acc_list, p256=p256, seg=seg,
+                    sem=sem, ins=ins, keep=(class_logits, mcl, scores, labels, lab_map, area, orig))
+
+    def finish_panoptic(self, pend, with_query_class_logits: bool = True):
+        """Second half: wait for the tables (an event, not a device sync), build the reference's `segments_info` lists and enqueue the
+        query x class volume of every item on the current stream."""
+        B, T, Q, Cc, IH, IW, H, W = pend["dims"]
+        pend["ev"].synchronize()
+        h = pend["host"]
+        table = h[:4 * B * Q].view(4, B, Q)
+        sc_h = h[4 * B * Q:5 * B * Q].view(torch.float32).view(B, Q)
+        nk_h, na_h = h[5 * B * Q:5 * B * Q + B].tolist(), h[5 * B * Q + B:].tolist()
+        probs, kept_idx, acc_list, p256, seg, sem, ins = (pend[k] for k in ("probs", "kept_idx", "acc_list", "p256", "seg", "sem", "ins"))
+        dev = seg.device
         results = []
         height, width = IH, IW  # the reference's stale (height, width) of the mask logits (quirk, :1297/:1355/:1470)
         for b in range(B):
