@@ -903,6 +903,7 @@ class VideoMask2FormerForVideoSegmentation:
 # whole model (model.py:31-389)
 # ==================================================================================================
 _PTS0_MAIN = os.environ.get("SIU3R_PTS0_MAIN", "0") == "1"
+_DEC_PER_LAYER = os.environ.get("SIU3R_DEC_PER_LAYER", "0") == "1"
 
 
 class _Run:
@@ -1061,9 +1062,14 @@ class SIU3RModel:
             st.dec = bb.decode_end(st.dstate)
 
         dec = [("dec_pre", dec_pre)]
+        if self._merged_decoder(st) and not _DEC_PER_LAYER:
+            # all merged layers as ONE chain graph (a graph boundary costs ~10 us on the critical path; SIU3R_DEC_PER_LAYER=1 keeps one
+            # graph per layer for tools/timeline.py)
+            dec += [("dec_all", lambda: [bb.decode_layer_merged(st.dstate, i) for i in range(bb.dec_depth)])]
         for i in range(bb.dec_depth):
             if self._merged_decoder(st):
-                dec += [(f"dec{i}", lambda i=i: bb.decode_layer_merged(st.dstate, i))]
+                if _DEC_PER_LAYER:
+                    dec += [(f"dec{i}", lambda i=i: bb.decode_layer_merged(st.dstate, i))]
             else:
                 dec += [(f"decA{i}", lambda i=i: bb.decode_side(st.dstate, i, 0)), (f"decB{i}", lambda i=i: bb.decode_side(st.dstate, i, 1))]
         dec += [("dec_post", dec_post)]
@@ -1121,9 +1127,12 @@ class SIU3RModel:
         # decoder: per layer, view 0 and the other views are independent chains (joined after every layer)
         run("dec_pre", stages["dec_pre"])
         dside = ctx.side_stream(0) if par else main
+        if "dec_all" in stages:
+            run("dec_all", stages["dec_all"])
         for i in range(self.backbone.dec_depth):
             if self._merged_decoder(st):  # both sides of the pair in grouped launches on the main stream
-                run(f"dec{i}", stages[f"dec{i}"])
+                if "dec_all" not in stages:
+                    run(f"dec{i}", stages[f"dec{i}"])
                 continue
             if par:
                 dside.wait_stream(main)

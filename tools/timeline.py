@@ -1,6 +1,7 @@
 """Stage timeline of one graph-replayed forward as it really overlaps on the streams: start / end of every stage graph relative to the
 step's first event.  python tools/timeline.py [bf16|bf16x3] [B]"""
 import os, sys, time
+os.environ.setdefault("SIU3R_DEC_PER_LAYER", "1")  # one graph per decoder layer, so that the layers show up separately
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from siu3r_amd.model import SIU3RModel
