@@ -121,3 +121,63 @@ def test_ping_pong_and_pipelined_kernels_fit_one_workgroup_per_cu():
     assert len(res) == 2
     for name, r in res.items():
         assert r["VGPRs"] + r.get("AGPRs", 0) <= 256 and r["ScratchSize [bytes/lane]"] == 0 and r["LDS Size [bytes/block]"] <= 160 * 1024, (name, r)
+
+
+def _plan(**kw):
+    """siu3r_gemm_plan is a host function: it can be asked about a problem without a GPU (pointers are only tested for null)"""
+    from siu3r_amd import _lib
+
+    p = _lib.GemmParams()
+    p.a, p.w_hi, p.c = 64, 64, 64  # non-null, never dereferenced by the plan
+    p.a_dtype, p.c_dtype = _lib.F32, _lib.F32
+    p.w_x3 = 64
+    p.sk_ws, p.sk_cnt, p.sk_ws_floats, p.sk_cnt_n = 64, 64, 1 << 24, 8192
+    for k, v in kw.items():
+        setattr(p, k, v)
+    p.kpad = (p.k + 63) // 64 * 64
+    p.lda = p.k
+    pl = _lib.GemmPlan()
+    _lib.check(_lib.lib().siu3r_gemm_plan(C.byref(p), C.byref(pl)))
+    return pl
+
+
+def test_gemm_plan_consults_the_measured_table_then_the_model():
+    """Decision order of the dispatch (ABI 4): caller's tile_cfg > process default > csrc/gemm_tuned.h (exact problem)
+    > cost model.  The encoder's fc2 (2050 x 1024 x 4096, bf16x3) is in the table with the 256 x 128 tile; with the table ignored the
+    model prices it differently; a neighbouring problem that is not listed is always the model's."""
+    from siu3r_amd import _lib
+
+    lib = _lib.lib()
+    listed = dict(m=2050, n=1024, k=4096)
+    try:
+        tuned = _plan(**listed)
+        assert (tuned.tile_cfg, tuned.bm, tuned.bn) == (2, 256, 128) and "gemm_pp_kernel<true, 2, 2" in tuned.kernel.decode()
+        _lib.check(lib.siu3r_gemm_tune(3, 1))
+        model = _plan(**listed)
+        assert model.tile_cfg != tuned.tile_cfg, "the cost model is expected to pick another tile here (that is why the entry exists)"
+        _lib.check(lib.siu3r_gemm_tune(3, 0))
+        forced = _plan(tile_cfg=3, **listed)
+        assert forced.tile_cfg == 3 and forced.bm == forced.bn == 128
+        a, b = _plan(m=2050, n=1024, k=4032), None
+        _lib.check(lib.siu3r_gemm_tune(3, 1))
+        b = _plan(m=2050, n=1024, k=4032)
+        assert (a.tile_cfg, a.splitk, a.skinny_rows) == (b.tile_cfg, b.splitk, b.skinny_rows)
+        # split-K is planned only with a workspace, and never beyond it
+        none = _plan(sk_ws=0, sk_cnt=0, **listed)
+        assert none.splitk == 1
+        small = _plan(sk_ws_floats=1024, **listed)
+        assert small.splitk == 1 or small.ws_floats <= 1024
+    finally:
+        _lib.check(lib.siu3r_gemm_tune(3, 0))
+
+
+def test_batch_strided_views_host_logic():
+    from siu3r_amd.ops import _batch_strided
+
+    seq = torch.zeros(2, 50, 8)
+    lvl = seq[:, 10:42].view(2, 4, 8, 8)  # a level cut out of the middle of each item's sequence
+    assert not lvl.is_contiguous() and _batch_strided(lvl, 4 * 8 * 8) == 50 * 8
+    assert _batch_strided(torch.zeros(2, 4, 8, 8), 256) == 256
+    assert _batch_strided(seq[:1, :32].view(1, 4, 8, 8), 256) == 256  # one item: its stride does not matter
+    with pytest.raises(AssertionError):
+        _batch_strided(torch.zeros(2, 4, 8, 16)[..., :8], 256)  # rows that are not dense
