@@ -13,6 +13,10 @@
 
 namespace siu3r_epi_pp {
 
+#ifndef SIU3R_EPI_GENERAL
+#define SIU3R_EPI_GENERAL 0  // A/B builds: 1 = every launch takes the general row pass
+#endif
+constexpr bool g_force_general = SIU3R_EPI_GENERAL != 0;
 constexpr int NT = 512;
 constexpr int LDW = 68;                           // floats per staged row (64 + 4: 16-byte aligned rows, spreads banks)
 constexpr int WAVE_STAGE_BYTES = 32 * LDW * 4 + 64 * 2 * 4;  // 32 x 64 block pair + (mean, rstd) of the wave's 64 rows
@@ -76,6 +80,252 @@ __device__ __forceinline__ bool splitk_reduce(const siu3r_gemm_params& p, f32x16
 }
 
 
+// Fast row pass for the common output form -- row-major fp32 C with N % 64 == 0 and 16-byte aligned rows, optional fp32 residual of the
+// same kind, no pixel shuffle / upsample-add / bf16 copy -- which is every GEMM of the encoder, the decoder and most of the heads in the
+// bf16x3 mode.  The general pass below decides all of that per element chunk (64-bit index arithmetic, alignment tests, dtype switches:
+// ~2000 executed instructions per wave and tile, as long as the stores themselves take); here
+//   * rows are addressed through buffer resources over the wave's own rows with 32-bit offsets, an out-of-range offset standing in for
+//     "row beyond M" (stores dropped, loads return 0: no branches in the row loop);
+//   * a lane holds columns [4c, 4c+4) and [32+4c, 32+4c+4) of the 64-column group instead of [8c, 8c+8): each store instruction then
+//     writes one FULL 128-byte line per row (two half-filled lines before: 15-25 % slower on a launch-sized burst, tools/probes/store_probe.hip);
+//   * the feature tests (RoPE, statistics, activation, residual) are wave-uniform and sit outside the element loops.
+template <int MI, int NJ, bool LNF, bool BF>
+__device__ __forceinline__ void wave_rows_fast(const siu3r_gemm_params& p, f32x16 (&acc)[MI][NJ], float* ws, int row_w0, int col_w0, int m_end, int z,
+                                               int lane, const siu3r_zoff& zof) {
+#if __HIP_DEVICE_COMPILE__
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+  typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int prow = lane >> 3, c = lane & 7;
+  const float* addp = LNF ? p.ln_c2 + zof.bias : (p.bias ? p.bias + zof.bias : nullptr);
+  const float* c1p = LNF ? p.ln_c1 + zof.bias : nullptr;
+  float* w_ln = ws + 32 * LDW;
+  const int M = m_end, N = p.n;
+  if (LNF) {
+    if (lane < 32 * MI) {
+      const int m = row_w0 + lane;
+      float mu = 0.f, rstd = 0.f;
+      if (m < M) {
+        const float2* sp = (const float2*)p.ln_stats + ((int64_t)zof.zo * p.ln_sz + (int64_t)zof.zi * p.ln_sz_i + (int64_t)m * p.ln_ldm) * p.ln_tiles;
+        const int Cn = p.k, last = Cn - 64 * (p.ln_tiles - 1);
+        float2 part[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[i] = i < p.ln_tiles ? sp[i] : make_float2(0.f, 0.f);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (i < p.ln_tiles) sum += part[i].x * (float)(i == p.ln_tiles - 1 ? last : 64);
+        mu = sum / (float)Cn;
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (i < p.ln_tiles) {
+            const float d = part[i].x - mu;
+            m2 += part[i].y + d * d * (float)(i == p.ln_tiles - 1 ? last : 64);
+          }
+        rstd = rsqrtf(m2 / (float)Cn + p.ln_eps);
+      }
+      w_ln[2 * lane] = mu;
+      w_ln[2 * lane + 1] = rstd;
+    }
+  }
+  constexpr unsigned OOB = 0x80000000u;  // beyond num_records: the store is dropped, the load returns 0
+  const bool res_bf = p.r_dtype == SIU3R_BF16;
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned char*)p.c + (zof.c + (int64_t)row_w0 * p.ldc) * (BF ? 2 : 4)), (short)0, 0x7fffffff, 0x00020000);
+  const bool has_res = p.residual != nullptr;
+  const int r_esz = res_bf ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(has_res ? (const unsigned char*)p.residual + (zof.r + (int64_t)row_w0 * p.ldr) * r_esz : (const unsigned char*)p.c), (short)0, has_res ? 0x7fffffff : 0, 0x00020000);
+  // 8 residual values of a row group: fp32 as two 16-byte loads at the lane's two column runs, bf16 (BF layout only) as one
+  auto load_res = [&](unsigned roff, f32x4_t& lo, f32x4_t& hi) {
+    if (BF && res_bf) {
+      const u32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(rr, roff, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        lo[2 * e] = __builtin_bit_cast(float, w[e] << 16);
+        lo[2 * e + 1] = __builtin_bit_cast(float, w[e] & 0xffff0000u);
+        hi[2 * e] = __builtin_bit_cast(float, w[2 + e] << 16);
+        hi[2 * e + 1] = __builtin_bit_cast(float, w[2 + e] & 0xffff0000u);
+      }
+    } else {
+      lo = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rr, roff, 0, 0));
+      hi = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rr, roff, BF ? 16 : 128, 0));
+    }
+  };
+  const int act = p.act;
+  const bool stats = p.stats_out != nullptr;
+  const bool upper = c >= 4;  // this lane's columns are the second member of their RoPE pairs (d & 16)
+  const int pc4 = 4 * (c ^ 4);
+  // BF (bf16 C): a lane keeps the 8 consecutive columns [8c, 8c+8) -- 16 bytes, so that 8 lanes already fill a 128-byte line -- and
+  // RoPE / statistics are not offered (fp32 outputs only: the general pass takes those)
+  const int o_lo = BF ? 8 * c : 4 * c, o_hi = BF ? 8 * c + 4 : 32 + 4 * c;
+
+#pragma unroll
+  for (int jp = 0; jp < NJ / 2; ++jp) {
+    const int g0 = col_w0 + jp * 64;  // the 64-column group (one RoPE head, one statistics group)
+    if (g0 < N) {                     // (wave-uniform; N % 64 == 0: a group is whole or absent)
+      const int n_lo = g0 + o_lo, n_hi = g0 + o_hi;
+      const bool rope = !BF && p.rope_cos != nullptr && g0 < p.rope_ncols;
+      f32x4_t b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = b_lo, c1_lo = b_lo, c1_hi = b_lo;
+      if (addp) {
+        b_lo = *(const f32x4_t*)(addp + n_lo);
+        b_hi = *(const f32x4_t*)(addp + n_hi);
+      }
+      if (LNF) {
+        c1_lo = *(const f32x4_t*)(c1p + n_lo);
+        c1_hi = *(const f32x4_t*)(c1p + n_hi);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int mblk = row_w0 + i * 32;
+        if (mblk < M) {  // (wave-uniform)
+          // ---- global reads of the block pair's four row groups go out first (residual, RoPE positions) where the registers allow it:
+          // the 256 x 256 tile holds 128 accumulators and reads them per row group instead
+          constexpr bool HOIST = MI * NJ <= 4;
+          f32x4_t r_lo[HOIST ? 4 : 1], r_hi[HOIST ? 4 : 1];
+          int pos0[4], pos1[4];
+          unsigned coff[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int lr = i * 32 + k * 8 + prow;
+            const bool ok = row_w0 + lr < M;
+            coff[k] = ok ? (unsigned)((lr * (int)p.ldc + n_lo) * (BF ? 2 : 4)) : OOB;
+            if constexpr (HOIST) {
+              const unsigned roff = ok ? (unsigned)((lr * (int)p.ldr + n_lo) * r_esz) : OOB;
+              load_res(roff, r_lo[k], r_hi[k]);
+            }
+            pos0[k] = pos1[k] = 0;
+            if (rope && ok) {
+              const int64_t* pp = p.rope_pos + ((int64_t)z * p.m + row_w0 + lr) * 2;
+              pos0[k] = (int)pp[0];
+              pos1[k] = (int)pp[1];
+            }
+          }
+          // ---- transpose the pair through the wave's LDS (same wave: LDS operations complete in order, a counted wait is the only
+          // synchronisation; the previous pair's reads were waited for before its last use)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ws[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDW + jj * 32 + l31] = acc[i][2 * jp + jj][r];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int lr = i * 32 + k * 8 + prow;
+            const float* rowp = ws + (k * 8 + prow) * LDW;
+            f32x4_t v_lo = *(const f32x4_t*)(rowp + o_lo), v_hi = *(const f32x4_t*)(rowp + o_hi);
+            f32x4_t q_lo = v_lo, q_hi = v_hi;
+            if (rope) {
+              q_lo = *(const f32x4_t*)(rowp + pc4);
+              q_hi = *(const f32x4_t*)(rowp + 32 + pc4);
+            }
+            if (k == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging area may be rewritten
+            float ln_mu = 0.f, ln_rs = 1.f;
+            if (LNF) {
+              ln_mu = w_ln[2 * lr];
+              ln_rs = w_ln[2 * lr + 1];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v_lo[e] = ln_rs * (v_lo[e] - ln_mu * c1_lo[e]) + b_lo[e];
+                v_hi[e] = ln_rs * (v_hi[e] - ln_mu * c1_hi[e]) + b_hi[e];
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v_lo[e] += b_lo[e];
+                v_hi[e] += b_hi[e];
+              }
+            }
+            if (rope) {
+              // the partner columns' bias / LayerNorm terms (cache hits; kept out of the registers that live across the row loop)
+              f32x4_t pb_lo = {0.f, 0.f, 0.f, 0.f}, pb_hi = pb_lo, pc1_lo = pb_lo, pc1_hi = pb_lo;
+              if (addp) {
+                pb_lo = *(const f32x4_t*)(addp + g0 + pc4);
+                pb_hi = *(const f32x4_t*)(addp + g0 + 32 + pc4);
+              }
+              if (LNF) {
+                pc1_lo = *(const f32x4_t*)(c1p + g0 + pc4);
+                pc1_hi = *(const f32x4_t*)(c1p + g0 + 32 + pc4);
+              }
+              // columns d = 4c + e (axis 0, positions pos0) and 32 + 4c + e (axis 1, pos1); table entry d & 15, partner d ^ 16
+              const f32x4_t cs0 = *(const f32x4_t*)(p.rope_cos + (int64_t)pos0[k] * 16 + 4 * (c & 3)), sn0 = *(const f32x4_t*)(p.rope_sin + (int64_t)pos0[k] * 16 + 4 * (c & 3));
+              const f32x4_t cs1 = *(const f32x4_t*)(p.rope_cos + (int64_t)pos1[k] * 16 + 4 * (c & 3)), sn1 = *(const f32x4_t*)(p.rope_sin + (int64_t)pos1[k] * 16 + 4 * (c & 3));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float o0 = LNF ? ln_rs * (q_lo[e] - ln_mu * pc1_lo[e]) + pb_lo[e] : q_lo[e] + pb_lo[e];
+                const float o1 = LNF ? ln_rs * (q_hi[e] - ln_mu * pc1_hi[e]) + pb_hi[e] : q_hi[e] + pb_hi[e];
+                v_lo[e] = upper ? (v_lo[e] * cs0[e] + o0 * sn0[e]) : (v_lo[e] * cs0[e] - o0 * sn0[e]);
+                v_hi[e] = upper ? (v_hi[e] * cs1[e] + o1 * sn1[e]) : (v_hi[e] * cs1[e] - o1 * sn1[e]);
+              }
+            }
+            if (act == 1) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v_lo[e] = siu3r_epi::gelu_fast(v_lo[e]);
+                v_hi[e] = siu3r_epi::gelu_fast(v_hi[e]);
+              }
+            } else if (act == 2) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v_lo[e] = fmaxf(v_lo[e], 0.f);
+                v_hi[e] = fmaxf(v_hi[e], 0.f);
+              }
+            }
+            if constexpr (HOIST) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {  // (zeros without a residual: num_records 0)
+                v_lo[e] += r_lo[k][e];
+                v_hi[e] += r_hi[k][e];
+              }
+            } else if (has_res) {
+              const unsigned roff = coff[k] != OOB ? (unsigned)((lr * (int)p.ldr + n_lo) * r_esz) : OOB;
+              f32x4_t a_, b_;
+              load_res(roff, a_, b_);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v_lo[e] += a_[e];
+                v_hi[e] += b_[e];
+              }
+            }
+            if (!BF && stats) {
+              // (mean, centred sum of squares) of this row's 64-column group, reduced over the group's 8 lanes
+              float s1 = ((v_lo[0] + v_lo[1]) + (v_lo[2] + v_lo[3])) + ((v_hi[0] + v_hi[1]) + (v_hi[2] + v_hi[3]));
+              s1 += __shfl_xor(s1, 1);
+              s1 += __shfl_xor(s1, 2);
+              s1 += __shfl_xor(s1, 4);
+              const float mean = s1 * (1.f / 64.f);
+              float s2 = 0.f;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float d0 = v_lo[e] - mean, d1 = v_hi[e] - mean;
+                s2 += d0 * d0 + d1 * d1;
+              }
+              s2 += __shfl_xor(s2, 1);
+              s2 += __shfl_xor(s2, 2);
+              s2 += __shfl_xor(s2, 4);
+              if (c == 0 && coff[k] != OOB) {
+                const int64_t row = (int64_t)zof.zo * p.st_sz + (int64_t)zof.zi * p.st_sz_i + (int64_t)(row_w0 + lr) * p.st_ldm;
+                ((float2*)p.stats_out)[row * (N >> 6) + (g0 >> 6)] = make_float2(mean, s2);
+              }
+            }
+            if constexpr (BF) {
+              u32x4_t w;
+              w[0] = pack_bf16x2(v_lo[0], v_lo[1]);
+              w[1] = pack_bf16x2(v_lo[2], v_lo[3]);
+              w[2] = pack_bf16x2(v_hi[0], v_hi[1]);
+              w[3] = pack_bf16x2(v_hi[2], v_hi[3]);
+              __builtin_amdgcn_raw_buffer_store_b128(w, rc, coff[k], 0, 0);
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v_lo), rc, coff[k], 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v_hi), rc, coff[k], 128, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+#endif
+}
+
 // Row pass of ONE wave: its 32 MI x 32 NJ accumulator blocks start at (row_w0, col_w0) of the output; rows >= m_end are not stored
 // (they belong to another launch or lie beyond M).  ws: the wave's WAVE_STAGE_BYTES of LDS.
 template <int MI, int NJ, bool LNF>
@@ -87,6 +337,22 @@ __device__ __forceinline__ void wave_rows(const siu3r_gemm_params& p, f32x16 (&a
   const unsigned char* Rb = (const unsigned char*)p.residual;
   const siu3r_zoff zof = siu3r_batch_offsets(p, z);
   const int64_t c_boff = zof.c, r_boff = zof.r;
+  {
+    // (wave-uniform) the common output forms take the fast pass: row-major C, N % 64 == 0, 16-byte aligned rows, no pixel shuffle /
+    // upsample-add / bf16 copy; fp32 C with everything else, bf16 C without RoPE
+    const int64_t res_b = p.r_dtype == SIU3R_F32 ? 4 : 2;
+    const bool res_ok = !p.residual || ((((int64_t)p.ldr * res_b) & 15) == 0 && ((r_boff * res_b + (int64_t)(uintptr_t)p.residual) & 15) == 0 &&
+                                         (int64_t)(32 * MI) * p.ldr < (1 << 28) && (p.r_dtype == SIU3R_F32 || p.c_dtype == SIU3R_BF16));
+    const bool common = p.out_mode == 0 && !p.up_src && !p.c_aux && (p.n & 63) == 0 && (int64_t)(32 * MI) * p.ldc < (1 << 28) && res_ok && !g_force_general;
+    if (common && p.c_dtype == SIU3R_F32 && (p.ldc & 3) == 0 && ((c_boff * 4 + (int64_t)(uintptr_t)p.c) & 15) == 0) {
+      wave_rows_fast<MI, NJ, LNF, false>(p, acc, ws, row_w0, col_w0, m_end, z, lane, zof);
+      return;
+    }
+    if (common && p.c_dtype == SIU3R_BF16 && (p.ldc & 7) == 0 && ((c_boff * 2 + (int64_t)(uintptr_t)p.c) & 15) == 0 && !p.rope_cos && !p.stats_out) {
+      wave_rows_fast<MI, NJ, LNF, true>(p, acc, ws, row_w0, col_w0, m_end, z, lane, zof);
+      return;
+    }
+  }
   const float* biasp = p.bias ? p.bias + zof.bias : nullptr;
   constexpr bool ln = LNF;
   const float* c1p = ln ? p.ln_c1 + zof.bias : nullptr;
