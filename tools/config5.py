@@ -68,7 +68,8 @@ tan = (0.5 * cs.get_fov(Kn[None])).tan()[0]
 ext, Kt = pick_camera(means_c, float(tan[0]), float(tan[1]), 0.2)[None, None], Kn[None, None]
 def fresh():
     return Gaussians(means=G_.means.clone(), covariances=G_.covariances.clone(), harmonics=G_.harmonics, opacities=G_.opacities)
-rend.forward(fresh(), ext, Kt, (H, W), render_color=True)
+for _ in range(3):  # (the first frames size the allocator's blocks: one warm-up left a device malloc inside the timed loop on some runs)
+    rend.forward(fresh(), ext, Kt, (H, W), render_color=True)
 gs = [fresh() for _ in range(n)]
 torch.cuda.synchronize()
 t0 = time.perf_counter()
