@@ -85,6 +85,67 @@ def test_gemm_rope_epilogue(mode):
     check(f"gemm_rope_epilogue[{name}]", out, ref, tol)
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3], ids=["pp256x256", "pp256x128", "pp128x128"])
+@pytest.mark.parametrize("split", [True, False], ids=["bf16x3", "bf16"])
+def test_gemm_ping_pong_row_passes(tile, split):
+    """The ping-pong tiles' two row passes on forced tiles and a ragged M: the fast pass (fp32 / bf16 C, N % 64 == 0) with RoPE on the
+    q | k columns, folded LayerNorm + GELU, residual + row statistics, bf16 C with a bf16 residual; and the general pass on the same
+    problems made ineligible (N % 64 != 0)."""
+    from oracle import siu3r_oracle as O
+
+    ops = _ops()
+    adt, tol = (torch.float32, TOL_F32) if split else (torch.bfloat16, TOL_BF16)
+    M, K, H, D = 300, 256, 2, 64
+    x = gen(M, K, seed=110)
+    xa = x.cuda().to(adt)
+    log = []
+    ops.gemm_tune(0, tile)
+    ops.set_plan_log(log)
+    try:
+        # RoPE on the first 2 H D columns of a 3 H D wide projection (fp32 C)
+        w, b = gen(3 * H * D, K, seed=111, scale=0.3), gen(3 * H * D, seed=112)
+        pos = torch.randint(0, 20, (1, M, 2), generator=torch.Generator().manual_seed(6))
+        cos, sin = O.rope2d_table(20, D)
+        qkv = (xa.float().cpu() @ w.t() + b).view(1, M, 3, H, D)
+        q = O.rope2d(qkv[:, :, 0].permute(0, 2, 1, 3), pos).permute(0, 2, 1, 3)
+        k = O.rope2d(qkv[:, :, 1].permute(0, 2, 1, 3), pos).permute(0, 2, 1, 3)
+        ref = torch.stack((q, k, qkv[:, :, 2]), dim=2).reshape(M, 3 * H * D)
+        out = ops.linear(xa, ops.pack_linear(w.cuda(), b.cuda(), split), out_dtype=torch.float32, rope=(cos.cuda(), sin.cuda(), pos.cuda(), 2 * H * D))
+        assert log[-1].tile_cfg == tile
+        check(f"pp row pass rope [{tile}]", out, ref, tol)
+        # residual + statistics out (fp32 C), then the folded LayerNorm + GELU that consumes them
+        w1, b1 = gen(K, K, seed=113, scale=0.2), gen(K, seed=114)
+        r = gen(M, K, seed=115)
+        y = torch.empty(M, K, device="cuda")
+        st = ops.RowStats(y)
+        yb = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+        ops.linear(xa, ops.pack_linear(w1.cuda(), b1.cuda(), split), residual=r.cuda(), out=y, stats_out=st, aux_out=None if split else yb)
+        yref = xa.float().cpu() @ w1.t() + b1 + r
+        check(f"pp row pass residual [{tile}]", y, yref, tol)
+        part = st.buf.cpu()
+        assert float((part[:, :, 0].mean(1) - y.cpu().mean(1)).abs().max()) <= 1e-5
+        gm, bt = 1 + 0.2 * gen(K, seed=116), gen(K, seed=117)
+        w2, b2 = gen(320, K, seed=118, scale=0.2), gen(320, seed=119)
+        pw2 = ops.pack_linear_ln(w2.cuda(), b2.cuda(), gm.cuda(), bt.cuda(), split)
+        o2 = ops.linear(y if split else yb, pw2, out_dtype=torch.float32, act=ops.ACT_GELU, ln=st)
+        ref2 = F.gelu(F.layer_norm(y.cpu(), (K,), gm, bt, 1e-6) @ w2.t() + b2)
+        check(f"pp row pass ln+gelu [{tile}]", o2, ref2, max(tol, 2e-2 if not split else 0))
+        # bf16 C with a bf16 residual (fast pass, BF layout) -- and ReLU
+        if not split:
+            rb = gen(M, K, seed=120).to(torch.bfloat16)
+            o3 = ops.linear(xa, ops.pack_linear(w1.cuda(), b1.cuda(), False), out_dtype=torch.bfloat16, act=ops.ACT_RELU, residual=rb.cuda())
+            check(f"pp row pass bf16 C [{tile}]", o3, torch.relu(xa.float().cpu() @ w1.t() + b1) + rb.float(), TOL_BF16)
+        # the general pass: N = 200 is not a multiple of 64
+        w4, b4 = gen(200, K, seed=121, scale=0.2), gen(200, seed=122)
+        r4 = gen(M, 200, seed=123)
+        o4 = ops.linear(xa, ops.pack_linear(w4.cuda(), b4.cuda(), split), out_dtype=torch.float32, act=ops.ACT_GELU, residual=r4.cuda())
+        assert log[-1].tile_cfg == tile
+        check(f"pp general pass [{tile}]", o4, F.gelu(xa.float().cpu() @ w4.t() + b4) + r4, tol)
+    finally:
+        ops.set_plan_log(None)
+        ops.gemm_tune(0, 0)
+
+
 @pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
 def test_gemm_batched_strided(mode):
     """tokens[:, :-1] view (strip the intrinsics token) feeding a 1x1 conv / linear."""
