@@ -152,6 +152,9 @@ __device__ __forceinline__ void wave_rows_fast(const siu3r_gemm_params& p, f32x1
       hi = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rr, roff, BF ? 16 : 128, 0));
     }
   };
+  // x2 bilinear upsample-add (align_corners; the DPT stems, dpt_block.py:230-235): fp32 source map [b, oh/2, ow/2, N] behind a buffer resource
+  const bool up = !BF && p.up_src != nullptr;
+  const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(up ? p.up_src : p.c), (short)0, up ? 0x7fffffff : 0, 0x00020000);
   const int act = p.act;
   const bool stats = p.stats_out != nullptr;
   const bool upper = c >= 4;  // this lane's columns are the second member of their RoPE pairs (d & 16)
@@ -270,6 +273,33 @@ __device__ __forceinline__ void wave_rows_fast(const siu3r_gemm_params& p, f32x1
                 v_hi[e] = fmaxf(v_hi[e], 0.f);
               }
             }
+            if (up) {
+              const int m = min(row_w0 + lr, M - 1);
+              const int ohw = p.oh * p.ow, bi = m / ohw, rr_ = m - bi * ohw;
+              const int oy = rr_ / p.ow, ox = rr_ - oy * p.ow;
+              const int sh = p.oh >> 1, sw = p.ow >> 1;
+              const float fy = (p.oh > 1) ? (float)(sh - 1) / (float)(p.oh - 1) * oy : 0.f;
+              const float fx = (p.ow > 1) ? (float)(sw - 1) / (float)(p.ow - 1) * ox : 0.f;
+              const int y0 = (int)fy, x0 = (int)fx;
+              const int y1 = y0 + (y0 < sh - 1 ? 1 : 0), x1 = x0 + (x0 < sw - 1 ? 1 : 0);
+              const float ly = fy - y0, lx = fx - x0;
+              const int sb = bi * sh * sw;
+              const unsigned u00 = (unsigned)(((sb + y0 * sw + x0) * N + n_lo) * 4), u01 = (unsigned)(((sb + y0 * sw + x1) * N + n_lo) * 4);
+              const unsigned u10 = (unsigned)(((sb + y1 * sw + x0) * N + n_lo) * 4), u11 = (unsigned)(((sb + y1 * sw + x1) * N + n_lo) * 4);
+#pragma unroll
+              for (int hh = 0; hh < 2; ++hh) {
+                const f32x4_t a_ = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ru, u00, hh * 128, 0));
+                const f32x4_t b_ = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ru, u01, hh * 128, 0));
+                const f32x4_t c_ = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ru, u10, hh * 128, 0));
+                const f32x4_t d_ = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ru, u11, hh * 128, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float add = (1.f - ly) * ((1.f - lx) * a_[e] + lx * b_[e]) + ly * ((1.f - lx) * c_[e] + lx * d_[e]);
+                  if (hh == 0) v_lo[e] += add;
+                  else v_hi[e] += add;
+                }
+              }
+            }
             if constexpr (HOIST) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {  // (zeros without a residual: num_records 0)
@@ -343,12 +373,14 @@ __device__ __forceinline__ void wave_rows(const siu3r_gemm_params& p, f32x16 (&a
     const int64_t res_b = p.r_dtype == SIU3R_F32 ? 4 : 2;
     const bool res_ok = !p.residual || ((((int64_t)p.ldr * res_b) & 15) == 0 && ((r_boff * res_b + (int64_t)(uintptr_t)p.residual) & 15) == 0 &&
                                          (int64_t)(32 * MI) * p.ldr < (1 << 28) && (p.r_dtype == SIU3R_F32 || p.c_dtype == SIU3R_BF16));
-    const bool common = p.out_mode == 0 && !p.up_src && !p.c_aux && (p.n & 63) == 0 && (int64_t)(32 * MI) * p.ldc < (1 << 28) && res_ok && !g_force_general;
+    const bool up_ok = !p.up_src || (p.up_dtype == SIU3R_F32 && p.c_dtype == SIU3R_F32 && (((int64_t)(uintptr_t)p.up_src) & 15) == 0 &&
+                                     (int64_t)p.m * p.n < (1 << 29) /* the half-resolution source is a quarter of the output: 4 B offsets < 2^31 */);
+    const bool common = p.out_mode == 0 && up_ok && !p.c_aux && (p.n & 63) == 0 && (int64_t)(32 * MI) * p.ldc < (1 << 28) && res_ok && !g_force_general;
     if (common && p.c_dtype == SIU3R_F32 && (p.ldc & 3) == 0 && ((c_boff * 4 + (int64_t)(uintptr_t)p.c) & 15) == 0) {
       wave_rows_fast<MI, NJ, LNF, false>(p, acc, ws, row_w0, col_w0, m_end, z, lane, zof);
       return;
     }
-    if (common && p.c_dtype == SIU3R_BF16 && (p.ldc & 7) == 0 && ((c_boff * 2 + (int64_t)(uintptr_t)p.c) & 15) == 0 && !p.rope_cos && !p.stats_out) {
+    if (common && !p.up_src && p.c_dtype == SIU3R_BF16 && (p.ldc & 7) == 0 && ((c_boff * 2 + (int64_t)(uintptr_t)p.c) & 15) == 0 && !p.rope_cos && !p.stats_out) {
       wave_rows_fast<MI, NJ, LNF, true>(p, acc, ws, row_w0, col_w0, m_end, z, lane, zof);
       return;
     }

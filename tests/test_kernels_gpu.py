@@ -86,6 +86,31 @@ def test_gemm_rope_epilogue(mode):
 
 
 @pytest.mark.parametrize("tile", [1, 2, 3], ids=["pp256x256", "pp256x128", "pp128x128"])
+def test_conv2d_upsample_add_on_ping_pong_tiles(tile):
+    """The same fused stem on forced ping-pong tiles with 64 output channels and two images (the fast row pass carries the upsample-add:
+    fp32 source map, batch index and pixel coordinates recovered from the row number) and with 40 channels (the general pass)."""
+    ops = _ops()
+    B, H, W = 2, 24, 40
+    img = gen(B, 3, H, W, seed=15).abs()
+    ops.gemm_tune(0, tile)
+    log = []
+    ops.set_plan_log(log)
+    try:
+        for C_ in (64, 40):
+            low = gen(B, C_, H // 2, W // 2, seed=16)
+            w, b = gen(C_, 3, 7, 7, seed=17, scale=0.2), gen(C_, seed=18)
+            ref = (F.relu(F.conv2d(img, w, b, padding=3)) + F.interpolate(low, scale_factor=2, mode="bilinear", align_corners=True)).permute(0, 2, 3, 1)
+            pw = ops.pack_conv(w.cuda(), b.cuda(), True, cin_pad=4)
+            out = ops.conv2d(ops.pack_image_nhwc(img.cuda(), torch.float32, 4), pw, stride=1, pad=3, act=ops.ACT_RELU, out_dtype=torch.float32,
+                             up_src=low.permute(0, 2, 3, 1).contiguous().cuda())
+            assert log[-1].tile_cfg == tile
+            check(f"conv7x7+up_add on tile {tile}, {C_} channels", out, ref, TOL_F32)
+    finally:
+        ops.set_plan_log(None)
+        ops.gemm_tune(0, 0)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3], ids=["pp256x256", "pp256x128", "pp128x128"])
 @pytest.mark.parametrize("split", [True, False], ids=["bf16x3", "bf16"])
 def test_gemm_ping_pong_row_passes(tile, split):
     """The ping-pong tiles' two row passes on forced tiles and a ragged M: the fast pass (fp32 / bf16 C, N % 64 == 0) with RoPE on the
