@@ -16,9 +16,10 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsiu3r_hip.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
-# per-file extras.  gemm_pp.hip: its epilogue walks the accumulator blocks in fully unrolled loops whose bodies are large; above the default
+# per-file extras.  gemm_pp*.hip (the ping-pong GEMM: host side + one unit per tile shape and operand mode): its epilogue walks the accumulator blocks in fully unrolled loops whose bodies are large; above the default
 # pragma-unroll size limit the loops stay rolled, the block index becomes a run-time value and the accumulators move to scratch memory
-EXTRA_FLAGS = {"gemm_pp.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
+_PP = ["-mllvm", "-pragma-unroll-threshold=1000000"]
+EXTRA_FLAGS = {"gemm_pp.hip": _PP, **{f"gemm_pp_t{n}{m}.hip": _PP for n in (1, 2, 3) for m in "xb"}}
 
 
 def _sources():

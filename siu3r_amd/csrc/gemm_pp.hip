@@ -1,444 +1,8 @@
-// 8-wave "ping-pong" MFMA GEMM / implicit-GEMM convolution for gfx950 -- the large-tile kernels of siu3r_gemm().
-//
-// Why: the 128 x 64 LDS-DMA kernels (gemm_dma.hip) issue 6 MFMAs per wave between two workgroup barriers; every K tile costs them the same
-// ~0.9 us hand-shake (counted wait -> barrier -> fragment reads -> MFMA chain) whatever it holds, so they top out near 13 % of the
-// matrix peak.  Here a workgroup is 8 waves = two groups of four (one wave of each group per SIMD) that run the SAME instruction
-// stream one barrier apart: while group 0 multiplies step s (16-24 back-to-back MFMAs on 8 independent 32 x 32 accumulators), group 1
-// reads its fragments of step s from LDS, issues its LDS-DMA pieces of step s+3 and (bf16x3) splits its fp32 A fragments into hi / lo
-// bf16; at the next barrier the roles swap.  The matrix pipe of a SIMD therefore always has one wave feeding it and the LDS / DMA /
-// VALU work of the other wave is hidden behind it (cdna_hip_programming.md 5.5 T3-T5, MI355X_MICROARCH.md "Two waves per SIMD").
-//
-// Tiles: 128 MI x 64 NJ (256 x 256, 256 x 128, 128 x 128), waves 4 (M) x 2 (N), wave tile 32 MI x 32 NJ, v_mfma_f32_32x32x16_bf16.
-// Steps: the K loop advances in HALF K tiles -- 64 bytes of every operand row: 32 bf16 (bf16 mode) or 16 fp32 of A and 16 hi + 16 lo
-// bf16 of W (bf16x3; W is stored [n][k/32][hi 32 | lo 32], the lane's SOURCE address picks its halves) -- so that both modes run the
-// same loop: 12 (MI=2,NJ=4) ds_read_b128 per wave and step, MI + NJ/2 LDS-DMA pieces per wave and step.
-// LDS: ring of 4 stages x (BM + BN) rows x 64 B, XOR-swizzled 16-byte chunks (chunk ^ (row >> 2 & 3): conflict-free for the
-// ds_read_b128 lane groups); LDS-DMA pieces are 16 rows x 64 B, the swizzle is applied to the per-lane SOURCE address (the DMA
-// destination is lane-linear).  Prefetch distance 3 steps, counted vmcnt, raw s_barrier; the only vmcnt(0) is at the loop's end.
-// Ordering (I_n = interval between barriers n and n+1; group 0: MEM(s) in I_2s, MFMA(s) in I_2s+1; group 1 one interval later):
-//   RAW  step s+1 is first read in I_2s+2: every wave waits for its pieces of step s+1 before barrier 2s+2 (group 0 at the end of its
-//        MFMA phase, group 1 at the end of its MEM phase; the (D-1) younger steps' pieces stay in flight);
-//   WAR  step s+3 lands in the stage of step s-1, last read by group 1 in I_2s-1 with lgkmcnt(0) before barrier 2s; it is issued in I_2s
-//        (group 0) / I_2s+1 (group 1).
-// Same A addressing modes (dense, conv tap cursor, small-cin conv), buffer addressing and fused epilogue as gemm_dma.hip.
-#include <stdlib.h>
-
-#include "common.h"
-#include "gemm_epilogue_pp.h"
+// Host side of the 8-wave ping-pong GEMM (kernel template: gemm_pp_kernel.h; one tile shape and operand mode per translation unit: gemm_pp_t{1,2,3}{x,b}.hip)
+// and the skinny remainder-row kernel.
+#include "gemm_pp_kernel.h"
 
 namespace siu3r_gemm_pp {
-
-constexpr unsigned OOB = 0xffffff00u;
-constexpr int RSRC_FLAGS = 0x00020000;
-// ring stages (one step each) and steps per phase of a tile configuration: 24 MFMAs (bf16x3; 16 in bf16) per wave between two barriers
-constexpr int nstage(int MI, int NJ) { return (MI == 2 && NJ == 4) ? 4 : (MI == 2 ? 6 : 8); }
-constexpr int spp(int MI, int NJ) { return (MI == 2 && NJ == 4) ? 1 : 2; }
-
-typedef __attribute__((address_space(3))) void* lds_ptr;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-typedef __attribute__((ext_vector_type(2))) short i16x2;
-
-template <int MI, int NJ>
-constexpr int smem_bytes() {
-  constexpr int ring = nstage(MI, NJ) * (128 * MI + 64 * NJ) * 64, st = siu3r_epi_pp::staging_bytes();
-  return ring > st ? ring : st;
-}
-
-#define SIU3R_DS_READ(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory")
-
-template <bool X3, int MI, int NJ, int MODE, bool RELU, bool LNF>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params p) {
-#if __HIP_DEVICE_COMPILE__
-  constexpr int BM = 128 * MI, BN = 64 * NJ;
-  constexpr int NSTAGE = nstage(MI, NJ), SPP = spp(MI, NJ), PD = NSTAGE - SPP;  // prefetch distance in steps
-  static_assert(NSTAGE % SPP == 0, "a phase uses whole stages");
-  constexpr int STAGE_BYTES = (BM + BN) * 64;
-  constexpr int A_PCS = MI, W_PCS = NJ / 2, PPW = A_PCS + W_PCS;  // LDS-DMA pieces (16 rows x 64 B) per wave and step
-  constexpr int ESZ = X3 ? 4 : 2;                                 // bytes per A element
-  constexpr int KSTEP = X3 ? 16 : 32;                             // K elements per step
-  constexpr int CK = 16 / ESZ;                                    // A elements per 16-byte chunk
-  static_assert(NJ % 2 == 0, "W pieces are dealt to whole waves");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[smem_bytes<MI, NJ>()];
-
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int grp = wave >> 2;        // ping-pong group
-  const int wm = wave & 3, wn = grp;
-  const int l31 = lane & 31, lh = lane >> 5;
-
-  const int M = p.m_main > 0 ? p.m_main : p.m;  // (the last rows may belong to a skinny launch)
-  const int N = p.n, K = p.k, kpad = p.kpad;
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const int xcd = (blockIdx.x + blockIdx.z) & 7, li = blockIdx.x >> 3;  // (regions rotate with the batch item: few tiles per item x many items still load all XCDs)
-  const int map_gx = p.map_gx;
-  const int ry = xcd / map_gx, rx = xcd - ry * map_gx;
-  const int lm = li / p.map_rn, ln = li - lm * p.map_rn;
-  const int tile_m = ry * p.map_rm + lm, tile_n = rx * p.map_rn + ln;
-  if (lm >= p.map_rm || tile_m >= tiles_m || tile_n >= tiles_n) return;
-  const int z = blockIdx.z;
-  const int np_all = kpad / (KSTEP * SPP);  // phases (kpad % 64 == 0: whole phases)
-  const int pbase = p.splitk > 1 ? (int)((int64_t)blockIdx.y * np_all / p.splitk) : 0;
-  const int np = p.splitk > 1 ? (int)((int64_t)(blockIdx.y + 1) * np_all / p.splitk) - pbase : np_all;
-  const int sbase = pbase * SPP, ns = np * SPP;
-
-  const siu3r_zoff zof = siu3r_batch_offsets(p, z);
-  const unsigned char* Ab = (const unsigned char*)p.a + zof.a * ESZ;
-  const unsigned char* Wb = X3 ? (const unsigned char*)p.w_x3 + zof.w * 4 : (const unsigned char*)p.w_hi + zof.w * 2;
-  const int WROW = X3 ? kpad * 4 : kpad * 2;  // bytes per W row
-
-  // ---- LDS-DMA geometry: piece = 16 rows x 64 B; lane -> (row = 16 piece + lane / 4, physical chunk = lane % 4); the lane fetches the
-  // LOGICAL chunk q that the swizzle stores there.  (row >> 2) & 3 == (lane >> 4) & 3 for every piece: one q per lane.
-  const int prow = lane >> 2;
-  const int q = (lane & 3) ^ ((lane >> 4) & 3);
-  const int cin = p.cin, iw = p.iw, ih = p.ih, kw = p.kw, kh = p.kh;
-  const int pad_bias = (MODE != 0) ? (p.pad * iw + p.pad) * cin * ESZ : 0;
-  __amdgpu_buffer_rsrc_t rA, rW;
-  if (MODE == 0)
-    rA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, (short)0, (int)(((int64_t)(p.m - 1) * p.lda + K) * ESZ), RSRC_FLAGS);
-  else
-    rA = __builtin_amdgcn_make_buffer_rsrc((void*)(Ab - pad_bias), (short)0, (int)OOB, RSRC_FLAGS);
-  rW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, (short)0, (int)((int64_t)N * WROW), RSRC_FLAGS);
-
-  unsigned a_voff[A_PCS], a_mask[A_PCS];
-  int a_iy0[A_PCS], a_ix0[A_PCS];
-#pragma unroll
-  for (int i = 0; i < A_PCS; ++i) {
-    const int r = (wave * A_PCS + i) * 16 + prow;
-    int m = tile_m * BM + r;
-    const bool row_ok = m < M;  // rows beyond M fetch row M - 1 again (never stored); out-of-range pieces land late
-    if (!row_ok) m = M - 1;
-    a_voff[i] = a_mask[i] = 0;
-    a_iy0[i] = a_ix0[i] = 0;
-    if (MODE == 0) {
-      a_voff[i] = (unsigned)((int64_t)m * p.lda * ESZ + q * 16);
-    } else {
-      const int ohw = p.oh * p.ow;
-      const int b = m / ohw, rr = m - b * ohw;
-      const int oy = rr / p.ow, ox = rr - oy * p.ow;
-      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-      if (MODE == 1) {
-        a_voff[i] = (unsigned)((((b * ih + iy0) * iw + ix0) * cin) * ESZ + q * 16 + pad_bias);
-        unsigned mk = 0;  // (a zero-padded K tail lands on tap kh*kw, whose bit is never set)
-        for (int ky = 0; ky < kh; ++ky)
-          for (int kx = 0; kx < kw; ++kx)
-            if (iy0 + ky >= 0 && iy0 + ky < ih && ix0 + kx >= 0 && ix0 + kx < iw) mk |= 1u << (ky * kw + kx);
-        a_mask[i] = row_ok ? mk : 0u;
-      } else {
-        a_voff[i] = (unsigned)((((b * ih + iy0) * iw + ix0) * cin) * ESZ + pad_bias);
-        a_iy0[i] = row_ok ? iy0 : -(1 << 20);
-        a_ix0[i] = ix0;
-      }
-    }
-  }
-  unsigned w_voff[W_PCS];
-#pragma unroll
-  for (int i = 0; i < W_PCS; ++i) {
-    const int r = (wave * W_PCS + i) * 16 + prow;
-    int n = tile_n * BN + r;
-    if (n > N - 1) n = N - 1;
-    // bf16x3: logical chunks 0,1 = the step's 16 hi values, 2,3 = its 16 lo values, 64 bytes further in the [hi 32 | lo 32] segment
-    w_voff[i] = (unsigned)((int64_t)n * WROW + q * 16 + ((X3 && q >= 2) ? 32 : 0));
-  }
-  const bool ktail = kpad > K;     // (K % 8 == 0: a 16-byte chunk is entirely inside or outside K)
-  const int ks_tail0 = K / KSTEP;  // first step that touches k >= K
-
-  // MODE 1: tap cursor of the next step to issue (steps are issued strictly in order): wave-uniform scalars
-  int cur_c0 = 0, cur_kx = 0, cur_toff = 0, cur_row = 0;
-  unsigned cur_bit = 1u;
-  auto cursor_advance = [&]() {
-    cur_c0 += KSTEP;
-    cur_toff += KSTEP * ESZ;
-    if (cur_c0 == cin) {
-      cur_c0 = 0;
-      cur_bit <<= 1;
-      if (++cur_kx == kw) {
-        cur_kx = 0;
-        cur_row += iw * cin * ESZ;
-      }
-      cur_toff = cur_row + cur_kx * cin * ESZ;
-    }
-  };
-  // MODE 2 (small cin): the lane tracks (channel offset, kx, ky) of its chunk for the next step to issue, advanced by KSTEP elements
-  int s_c0 = 0, s_kx = 0, s_ky = 0;
-  int qs_r = 0, qs_qx = 0, qs_qy = 0;
-  if (MODE == 2) {
-    const int qq = KSTEP / cin;
-    qs_r = KSTEP - qq * cin;
-    qs_qy = qq / kw;
-    qs_qx = qq - qs_qy * kw;
-    const int k0 = q * CK;
-    const int tap = k0 / cin;
-    s_c0 = k0 - tap * cin;
-    s_ky = tap / kw;
-    s_kx = tap - s_ky * kw;
-  }
-  auto state_advance = [&]() {
-    s_c0 += qs_r;
-    const int carry = s_c0 >= cin ? 1 : 0;
-    s_c0 -= carry * cin;
-    s_kx += qs_qx + carry;
-    const int wrap = s_kx >= kw ? 1 : 0;
-    s_kx -= wrap * kw;
-    s_ky += qs_qy + wrap;
-  };
-
-  // all pieces of step s (relative to sbase) into ring stage `stage`.  Steps beyond the slice's last one re-fetch the last step into a
-  // stage that is free by then: the loop body stays branch-free and the vmcnt counts constant.  (A burst of pieces blocks the issuing
-  // wave for ~150 cycles per piece -- the CU takes one 1-KiB piece per ~35 cycles from all of its waves, whatever the piece's shape:
-  // tools/probes/dma_probe.hip -- which is why the MEM phase carries nothing else that is slow.)
-  auto issue = [&](int s, int stage) {
-    const int sg = sbase + (s < ns ? s : ns - 1);
-    unsigned char* dstA = smem + stage * STAGE_BYTES + wave * (A_PCS * 1024);
-    unsigned char* dstW = smem + stage * STAGE_BYTES + BM * 64 + wave * (W_PCS * 1024);
-#pragma unroll
-    for (int i = 0; i < A_PCS; ++i) {
-      if (MODE == 0) {
-        unsigned voff = a_voff[i];
-        if (ktail && sg >= ks_tail0) voff = (sg * KSTEP + q * CK < K) ? voff : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(dstA + i * 1024), 16, voff, sg * 64, 0, 0);
-      } else if (MODE == 1) {
-        const unsigned voff = (a_mask[i] & cur_bit) ? a_voff[i] : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(dstA + i * 1024), 16, voff, cur_toff, 0, 0);
-      } else {
-        const int iy = a_iy0[i] + s_ky, ix = a_ix0[i] + s_kx;
-        const bool ok = s_ky < kh && (unsigned)iy < (unsigned)ih && (unsigned)ix < (unsigned)iw;  // ky >= kh: zero-padded K tail
-        const unsigned voff = ok ? a_voff[i] + (unsigned)(((s_ky * iw + s_kx) * cin + s_c0) * ESZ) : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(dstA + i * 1024), 16, voff, 0, 0, 0);
-      }
-    }
-    const int soffW = X3 ? (sg >> 1) * 128 + (sg & 1) * 32 : sg * 64;
-#pragma unroll
-    for (int i = 0; i < W_PCS; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr)(dstW + i * 1024), 16, w_voff[i], soffW, 0, 0);
-    if (MODE == 1 && s + 1 < ns) cursor_advance();
-    if (MODE == 2 && s + 1 < ns) state_advance();
-  };
-
-  f32x16 acc[MI][NJ];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // ---- fragment addresses.  Row r of a region, logical chunk c: r * 64 + ((c ^ (r >> 2 & 3)) << 4); rows of further 32-row blocks are
-  // immediate offsets (+2048 per block: the swizzle term depends on r % 16 only).
-  const unsigned int lds_base = (unsigned int)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const int fsw = (l31 >> 2) & 3;
-  const unsigned int rowA = (wm * (32 * MI) + l31) * 64, rowB = BM * 64 + (wn * (32 * NJ) + l31) * 64;
-  // x3: A chunks (2 lh, 2 lh + 1) = the lane half's 8 fp32; W chunks lh (hi) and 2 + lh (lo).  bf16: chunks lh (k-substep 0), 2 + lh (1)
-  const unsigned int offA0 = rowA + (((X3 ? 2 * lh : lh) ^ fsw) << 4), offA1 = rowA + (((X3 ? 2 * lh + 1 : 2 + lh) ^ fsw) << 4);
-  const unsigned int offB0 = rowB + ((lh ^ fsw) << 4), offB1 = rowB + (((2 + lh) ^ fsw) << 4);
-
-  u32x4 fa[SPP][MI][2], fb[SPP][NJ][2];  // [step of the phase][block][x3: fp32 halves / hi,lo planes; bf16: k-substep]
-  auto read_frags = [&](int u, int stage) {
-    const unsigned int sb = lds_base + stage * STAGE_BYTES;
-    const unsigned int a0 = sb + offA0, a1 = sb + offA1, b0 = sb + offB0, b1 = sb + offB1;
-#define SIU3R_RD_A(I) if constexpr (I < MI) { SIU3R_DS_READ(fa[u][I][0], a0, I * 2048); SIU3R_DS_READ(fa[u][I][1], a1, I * 2048); }
-#define SIU3R_RD_B(J) if constexpr (J < NJ) { SIU3R_DS_READ(fb[u][J][0], b0, J * 2048); SIU3R_DS_READ(fb[u][J][1], b1, J * 2048); }
-    SIU3R_RD_A(0) SIU3R_RD_A(1)
-    SIU3R_RD_B(0) SIU3R_RD_B(1) SIU3R_RD_B(2) SIU3R_RD_B(3)
-#undef SIU3R_RD_A
-#undef SIU3R_RD_B
-  };
-  auto wait_frags = [&]() {
-    // the wait, then every fragment named "+v" in an (empty) volatile statement behind it: nothing that consumes one can be scheduled
-    // above the wait (cdna_hip_programming.md 5.7 (ii); volatile statements keep their order)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int u = 0; u < SPP; ++u) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(fa[u][i][0]), "+v"(fa[u][i][1]));
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(fb[u][j][0]), "+v"(fb[u][j][1]));
-    }
-  };
-  auto as_frag = [&](u32x4 v) {
-    if (!X3 && RELU) {  // fused input ReLU: a negative bf16 is a negative int16
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        union { unsigned int u; i16x2 h; } x;
-        x.u = v[e];
-        x.h = __builtin_elementwise_max(x.h, (i16x2){0, 0});
-        v[e] = x.u;
-      }
-    }
-    union { u32x4 u; bf16x8 h; } cv;
-    cv.u = v;
-    return cv.h;
-  };
-
-#ifndef SIU3R_PP_DBG
-#define SIU3R_PP_DBG 0  // tuning builds only: 1 no in-loop DMA, 2 no MFMA, 4 no fragment reads, 8 no hi / lo split, 16 no barriers, 32 no epilogue, 64 stamps
-#endif
-  constexpr int dbg = SIU3R_PP_DBG;
-  constexpr bool dma = !(dbg & 1);
-  // dbg & 64: per-segment shader-cycle sums (s_memtime: an SMEM op on lgkmcnt, so every stamp also waits for the LDS reads in
-  // flight) of waves 0 and 4 -> p.trace[wg][grp][8]
-  unsigned tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
-  auto tick = [&](int seg) {
-    if constexpr ((dbg & 64) != 0) {
-      const unsigned now = (unsigned)__builtin_readcyclecounter();
-      tsum[seg] += now - tlast;
-      tlast = now;
-    }
-  };
-
-  // ---- prologue: steps 0 .. PD-1 in flight, the first phase's steps landed
-  for (int s_ = 0; s_ < sbase; ++s_) {
-    if (MODE == 1) cursor_advance();
-    if (MODE == 2) state_advance();
-  }
-  constexpr int YOUNG = (PD - SPP) * PPW;  // pieces younger than the next phase's at the wait points (issue is unconditional: constant)
-  auto wait_young = [&]() {
-    static_assert(YOUNG == 8 || YOUNG == 6, "vmcnt immediate");
-    if constexpr (YOUNG == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  };
-#pragma unroll
-  for (int s_ = 0; s_ < PD; ++s_) issue(s_, s_);
-  wait_young();
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one interval behind group 0
-  if constexpr ((dbg & 64) != 0) tlast = (unsigned)__builtin_readcyclecounter();
-
-  int st_rd = 0, st_is = PD % NSTAGE;
-  for (int s = 0; s < ns; s += SPP) {
-    // ---- MEM: fragments of this phase's steps, LDS-DMA pieces of the steps PD ahead.  (The hi / lo split is NOT done here: the partner
-    // wave multiplies at s_setprio 1 meanwhile and this wave's VALU would get the left-over issue slots only -- 40 VALU took ~600 cycles.)
-    tick(7);
-#pragma unroll
-    for (int u = 0; u < SPP; ++u)
-      if (!(dbg & 4)) read_frags(u, st_rd + u);
-    if (dma) {
-#pragma unroll
-      for (int u = 0; u < SPP; ++u) issue(s + PD + u, st_is + u);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    tick(1);
-    wait_frags();
-    tick(2);
-    if (grp == 1 && dma) wait_young();  // the next phase's steps have landed (this wave's share); group 0 waits after its MFMA phase
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(dbg & 16)) __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    tick(4);
-    // ---- MFMA: per step 3 (bf16x3) or 2 (bf16) rounds of MI NJ MFMAs on independent accumulators
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int u = 0; u < SPP; ++u) {
-      bf16x8 bh[NJ][2];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        union { u32x4 u; bf16x8 h; } c0, c1;
-        c0.u = fb[u][j][0];
-        c1.u = fb[u][j][1];
-        bh[j][0] = c0.h;
-        bh[j][1] = c1.h;
-      }
-      if constexpr ((dbg & 2) != 0) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(fa[u][i][0]), "v"(fa[u][i][1]));
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(bh[j][0]), "v"(bh[j][1]));
-      } else if constexpr (X3) {
-        // hi = upper 16 bits (one v_perm per pair of values), lo = bf16_rne(a - hi) (2 and, 2 sub, 1 cvt per pair).  Chunks pinned by
-        // sched_barrier: [hi perms], then rounds hi x hi, hi x lo, lo x hi; the lo conversion of a pair sits behind the MFMAs of the first
-        // two rounds (the matrix pipe runs 32 cycles per MFMA: a few VALU per MFMA are free)
-        union U8 { u32x4 u; bf16x8 h; };
-        U8 ah[MI], al[MI];
-        auto raw = [&](int i, int e) { return e < 4 ? fa[u][i][0][e] : fa[u][i][1][e - 4]; };
-        auto relu = [&](unsigned int x) { return (RELU && (x & 0x80000000u)) ? 0u : x; };
-        auto hi_pair = [&](int i, int e) { ah[i].u[e] = __builtin_amdgcn_perm(relu(raw(i, 2 * e + 1)), relu(raw(i, 2 * e)), 0x07060302u); };
-        auto lo_pair = [&](int i, int e) {
-          const unsigned int x0 = relu(raw(i, 2 * e)), x1 = relu(raw(i, 2 * e + 1));
-          al[i].u[e] = pack_bf16x2(__uint_as_float(x0) - __uint_as_float(x0 & 0xffff0000u), __uint_as_float(x1) - __uint_as_float(x1 & 0xffff0000u));
-        };
-        if constexpr ((dbg & 8) != 0) {
-#pragma unroll
-          for (int i = 0; i < MI; ++i) {
-            ah[i].u = fa[u][i][0];
-            al[i].u = fa[u][i][1];
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hi_pair(i, e);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int NM = MI * NJ;  // MFMAs per round
-        constexpr int NP = 4 * MI;   // lo pairs to convert under the first 2 NM MFMAs
-#pragma unroll
-        for (int g = 0; g < 2 * NM; ++g) {
-          const int r = g / NM, ij = g % NM, i = ij / NJ, j = ij % NJ;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].h, bh[j][r], acc[i][j], 0, 0, 0);
-          if constexpr (!(dbg & 8)) {
-            const int p0 = g * NP / (2 * NM), p1 = (g + 1) * NP / (2 * NM);  // pairs dealt evenly over the 2 NM MFMAs
-#pragma unroll
-            for (int pp = p0; pp < p1; ++pp) lo_pair(pp / 4, pp % 4);
-          }
-          if ((g & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].h, bh[j][0], acc[i][j], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fa[u][i][ks]), bh[j][ks], acc[i][j], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    tick(5);
-    if (grp == 0 && dma) wait_young();
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(dbg & 16)) __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    tick(6);
-    st_rd = (st_rd + SPP == NSTAGE) ? 0 : st_rd + SPP;
-    st_is = (st_is + SPP == NSTAGE) ? 0 : st_is + SPP;
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();
-  // every wave's LDS-DMA (the tail steps' re-fetches) has landed before any wave reuses the ring as epilogue staging
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if constexpr ((dbg & 64) != 0) {
-    if (p.trace && (t & 255) == 0) {
-      uint64_t* tr = p.trace + ((size_t)blockIdx.x * 2 + grp) * 8;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) tr[e] = tsum[e];
-    }
-  }
-  if (dbg & 32) {
-    float keep = 0.f;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
-    if (keep == 123.456f) ((float*)p.c)[0] = 1.f;
-    return;
-  }
-  if (p.splitk > 1) {
-    const int64_t tile_id = ((int64_t)z * tiles_m + tile_m) * tiles_n + tile_n;
-    if (!siu3r_epi_pp::splitk_reduce<MI, NJ>(p, acc, smem, tile_id, t)) return;
-  }
-  siu3r_epi_pp::wave_rows<MI, NJ, LNF>(p, acc, (float*)(smem + wave * siu3r_epi_pp::WAVE_STAGE_BYTES), tile_m * BM + wm * (32 * MI),
-                                       tile_n * BN + wn * (32 * NJ), M, z, lane);
-#endif
-}
-
-
 // ---- the last <= 32 rows of a dense problem (M = 2 x 1025 tokens = 8 x 256 + 2: a ninth row of tiles that holds two rows would cost a
 // second round of workgroups).  A workgroup multiplies those rows by 64 columns over the whole K: its 8 waves take K slices, load
 // their MFMA fragments straight from global memory (no LDS ring: the W panel is streamed once, 16 bytes per lane, everything of a
@@ -563,6 +127,10 @@ __global__ __launch_bounds__(512, 2) void gemm_skinny_kernel(const siu3r_gemm_pa
 
 }  // namespace siu3r_gemm_pp
 
+#define SIU3R_PP_DECL(T) void siu3r_gemm_pp_go_##T(const siu3r_gemm_params& p, int mode, bool lnf, dim3 grid, hipStream_t s)
+SIU3R_PP_DECL(t1x); SIU3R_PP_DECL(t1b); SIU3R_PP_DECL(t2x); SIU3R_PP_DECL(t2b); SIU3R_PP_DECL(t3x); SIU3R_PP_DECL(t3b);
+#undef SIU3R_PP_DECL
+
 // ---- host side: applicability, names, launches.  The decision (family, tile, split-K, skinny rows) is siu3r_gemm_plan's (gemm.hip).
 // A-mode the ping-pong kernels run this problem in (0 dense, 1 conv tap cursor, 2 small-cin conv), or -1: outside their range
 int siu3r_gemm_pp_mode(const siu3r_gemm_params& p) {
@@ -621,30 +189,14 @@ int siu3r_gemm_pp_launch(const siu3r_gemm_params& pin, int cfg, void* stream) {
   dim3 grid(8 * p.map_rm * p.map_rn, p.splitk > 1 ? p.splitk : 1, p.batch > 0 ? p.batch : 1), block(512);
   hipStream_t s = (hipStream_t)stream;
   const bool lnf = p.ln_stats != nullptr;
-#define SIU3R_PP_GO(X3_, MI__, NJ__, MODE_, RELU_, LNF_) hipLaunchKernelGGL((gemm_pp_kernel<X3_, MI__, NJ__, MODE_, RELU_, LNF_>), grid, block, 0, s, p)
-#define SIU3R_PP_MODES(X3_, MI__, NJ__)                                         \
-  do {                                                                          \
-    if (mode == 0 && lnf) SIU3R_PP_GO(X3_, MI__, NJ__, 0, false, true);         \
-    else if (mode == 0) SIU3R_PP_GO(X3_, MI__, NJ__, 0, false, false);          \
-    else if (mode == 1 && p.relu_in) SIU3R_PP_GO(X3_, MI__, NJ__, 1, true, false); \
-    else if (mode == 1) SIU3R_PP_GO(X3_, MI__, NJ__, 1, false, false);          \
-    else SIU3R_PP_GO(X3_, MI__, NJ__, 2, false, false);                         \
-  } while (0)
-#define SIU3R_PP_TILES(X3_)                       \
-  do {                                            \
-    if (cfg == 1) SIU3R_PP_MODES(X3_, 2, 4);      \
-    else if (cfg == 2) SIU3R_PP_MODES(X3_, 2, 2); \
-    else SIU3R_PP_MODES(X3_, 1, 2);               \
-  } while (0)
-#ifdef SIU3R_PP_MINI  // tuning builds: one instantiation
+#ifdef SIU3R_PP_MINI  // tuning builds (tools/ab_pp.sh): one instantiation, compiled here
   hipLaunchKernelGGL((gemm_pp_kernel<SIU3R_PP_MINI, false, false>), grid, block, 0, s, p);
 #else
-  if (x3) SIU3R_PP_TILES(true);
-  else SIU3R_PP_TILES(false);
+  // one translation unit per tile shape and operand mode (they compile in parallel): gemm_pp_t1{x,b}.hip 256 x 256, _t2 256 x 128, _t3 128 x 128
+  if (cfg == 1) (x3 ? siu3r_gemm_pp_go_t1x : siu3r_gemm_pp_go_t1b)(p, mode, lnf, grid, s);
+  else if (cfg == 2) (x3 ? siu3r_gemm_pp_go_t2x : siu3r_gemm_pp_go_t2b)(p, mode, lnf, grid, s);
+  else (x3 ? siu3r_gemm_pp_go_t3x : siu3r_gemm_pp_go_t3b)(p, mode, lnf, grid, s);
 #endif
-#undef SIU3R_PP_TILES
-#undef SIU3R_PP_MODES
-#undef SIU3R_PP_GO
   SIU3R_LAUNCH_CHECK("siu3r_gemm(pp)");
   return 0;
 }

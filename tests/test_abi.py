@@ -108,7 +108,10 @@ def test_ping_pong_and_pipelined_kernels_fit_one_workgroup_per_cu():
 
     B.build()
     checked = 0
-    for name, r in B.kernel_resources("gemm_pp.hip").items():
+    pp = {}
+    for unit in ("gemm_pp_t1x.hip", "gemm_pp_t1b.hip", "gemm_pp_t2x.hip", "gemm_pp_t2b.hip", "gemm_pp_t3x.hip", "gemm_pp_t3b.hip"):
+        pp.update(B.kernel_resources(unit))
+    for name, r in pp.items():
         m = re.search(r"gemm_pp_kernelILb(\d)ELi(\d)ELi(\d)", name)
         if not m:
             continue

@@ -1,4 +1,4 @@
-"""Ping-pong GEMM kernels (gemm_pp.hip) vs the 128 x 64 kernels: correctness against torch fp32 and graph-timed TF/s per tile
+"""Ping-pong GEMM kernels (gemm_pp_kernel.h) vs the 128 x 64 kernels: correctness against torch fp32 and graph-timed TF/s per tile
 configuration.  python tools/mb_pp.py [check] [bench] [big]"""
 import json
 import os
