@@ -16,6 +16,7 @@ precision "bf16x3" = fp32 activations, bf16 MFMA with the hi/lo operand split (3
         bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import collections
 import json
 import math
 import os
@@ -87,15 +88,14 @@ def pmc_frame_bytes(section, views_per_call):
     return tot / frames, f"{PMC_NAME}[{section}] (all kernels of the command / {frames} frames)"
 
 
-def timed_steps(step, steps, D, dev):
-    """the contract's timed region: barrier + synchronize on both sides, max over ranks"""
+def timed_steps(run, steps, D, dev):
+    """the contract's timed region: barrier + synchronize on both sides, max over ranks.  run(steps) does exactly `steps` steps and
+    returns the last one's result."""
     torch.cuda.synchronize()
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = None
-    for _ in range(steps):
-        out = step()
+    out = run(steps)
     torch.cuda.synchronize()
     D.barrier()
     torch.cuda.synchronize()
@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="image pairs per step per GPU (configs[1] = 1)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--precision", default="bf16x3", choices=["bf16", "bf16x3"], help="the timed mode (default: the 1e-3 parity mode)")
+    ap.add_argument("--depth", type=int, default=1, help="steps in flight: 1 = one synchronous forward() per step (default); 2 = SIU3RModel.forward_async, "
+                    "step n+1 is enqueued before step n's segment table is picked up on the host (measured: no gain, profiles/r04_pipeline_probe.txt)")
     ap.add_argument("--no-second-mode", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -150,15 +152,35 @@ def main():
     def run_mode(precision):
         model = SIU3RModel(sd, image_size=(H, W), precision=precision, device=dev)
 
+        model.pipeline_depth = depth = max(1, args.depth)
+
         def step():
             with torch.no_grad():
                 return model(images, K, enable_query_class_logit_lift=True)
 
-        # untimed warm-up: at least 3 passes whatever W is (1st packs the weights eagerly, 2nd captures the HIP graphs, 3rd replays)
-        for _ in range(max(3, args.warmup)):
-            step()
+        def run(n):
+            """n steps, every one complete (network body, panoptic post-process, host-side segment lists); with depth > 1 step i+1
+            is enqueued before step i's result is picked up, so that consecutive steps overlap on the GPU"""
+            if depth == 1:
+                out = None
+                for _ in range(n):
+                    out = step()
+                return out
+            pend, out = collections.deque(), None
+            with torch.no_grad():
+                for _ in range(n):
+                    pend.append(model.forward_async(images, K, enable_query_class_logit_lift=True))
+                    if len(pend) >= depth:
+                        out = pend.popleft().result()
+                while pend:
+                    out = pend.popleft().result()
+            return out
+
+        # untimed warm-up: at least 3 passes whatever W is (1st packs the weights eagerly, 2nd captures the HIP graphs, 3rd replays);
+        # one more round per extra pipeline slot (each slot captures its own graphs on first use)
+        run(max(3, args.warmup) + 2 * (depth - 1))
         model.release_source_weights()
-        dt, out = timed_steps(step, args.steps, D, dev)
+        dt, out = timed_steps(run, args.steps, D, dev)
         return model, step, dt, out
 
     model, step, dt, out = run_mode(args.precision)
@@ -193,6 +215,9 @@ def main():
                    "pairs_per_step_per_gpu": B, "image_size": [H, W], "precision": args.precision, "parity": PARITY[args.precision],
                    "parallelism": f"dp{world} (independent pairs, one all-gather of metric statistics)",
                    "launch": "per-chain HIP graphs on 4 streams (encoder+decoder+pts3d heads | ViT-Adapter+Mask2Former | Gaussian head 1 | Gaussian head 2)" if (model.use_graph and model._ctx.concurrent) else "eager",
+                   "steps_in_flight": max(1, args.depth),
+                   "pipelining": ("forward_async: step n+1 is enqueued (own buffers, graphs and streams) before step n's segment table is read on the host; "
+                                  "every step is complete and inside the timed region; results bit-identical to forward()") if args.depth > 1 else "none (synchronous forward per step)",
                    "n_segments_per_step": total["n_segments"] / max(1, world), "n_gaussians_per_step": total["n_gaussians"] / max(1, world)},
         "network_tflops_algorithmic": value * FLOPS_PER_PAIR_512 * (H * W / (512 * 512)) / 1e12,
     }

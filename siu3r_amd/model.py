@@ -118,7 +118,7 @@ class _Ctx:
         self.act = torch.float32 if self.split else torch.bfloat16
         self.dev = w.dev
         self.cache: Dict = {}
-        self._streams: List = []
+        self._streams: Dict = {}
         self.concurrent = os.environ.get("SIU3R_NO_STREAMS", "0") != "1"
         # LayerNorms of the CroCo blocks folded into the GEMM that consumes them (statistics from the producing GEMM's epilogue), and
         # the two decoder sides of a pair merged into grouped launches.  SIU3R_NO_LNFOLD=1 restores the kernel-per-op path (A/B runs)
@@ -128,11 +128,12 @@ class _Ctx:
         """i-th auxiliary HIP stream: the independent chains of the network (two decoder sides, the four DPT heads,
         the ViT-Adapter/Mask2Former branch) are enqueued on separate streams so that at batch 1, where most launches
         are far smaller than the 256 CUs, they fill the chip together.  Forks and joins are wait_stream() edges."""
-        while len(self._streams) <= i:
+        k = i
+        if k not in self._streams:
             # default priority on purpose: a high-priority stream for the (critical) segmentation chain was measured to
             # nearly double the step on this runtime (14.5 -> 27.3 ms)
-            self._streams.append(torch.cuda.Stream(device=self.dev))
-        return self._streams[i]
+            self._streams[k] = torch.cuda.Stream(device=self.dev)
+        return self._streams[k]
 
     def ln(self, name, x, eps, out_dtype=None):
         return ops.layernorm(x, self.w.v(name + ".weight"), self.w.v(name + ".bias"), eps, out_dtype or self.act)
@@ -904,6 +905,19 @@ class VideoMask2FormerForVideoSegmentation:
 # ==================================================================================================
 _PTS0_MAIN = os.environ.get("SIU3R_PTS0_MAIN", "0") == "1"
 _DEC_PER_LAYER = os.environ.get("SIU3R_DEC_PER_LAYER", "0") == "1"
+_PIPE_PTSR = int(os.environ.get("SIU3R_PIPE_PTSR", "0"))  # forward_async: the head stream (0 / 1) the pts3d head of views 1.. queues on
+
+
+class _PendingForward:
+    """Handle of SIU3RModel.forward_async(): the device side of the step is enqueued; result() does the host half (once)."""
+
+    def __init__(self, finish):
+        self._finish, self._out, self.done = finish, None, False
+
+    def result(self):
+        if not self.done:
+            self._out, self.done, self._finish = self._finish(), True, None
+        return self._out
 
 
 class _Run:
@@ -938,6 +952,9 @@ class SIU3RModel:
         self.raw_gs_dim = (sh_degree + 1) ** 2 * 3 + 3 + 4 + 1
         self.use_graph = os.environ.get("SIU3R_NO_GRAPH", "0") != "1"
         self._graphs: Dict = {}
+        self.pipeline_depth = max(1, int(os.environ.get("SIU3R_PIPELINE_DEPTH", "2")))  # forward_async: steps that may be pending at once
+        self._next_slot = 0
+        self._inflight: Dict = {}
         self._timeline = None  # a list collects (stage, start event, end event) of the next graph-replayed forward
 
     def eval(self):
@@ -957,7 +974,37 @@ class SIU3RModel:
         (captured at the second call; the first packs the weights), the graphs launched on those same streams: at
         batch 1 the ~1100 launches of a pass otherwise cost more host time than GPU time, and ONE graph for the
         whole body serialises its branches on this runtime.  The panoptic post-process (host-visible segment table)
-        always runs eagerly afterwards.  SIU3R_NO_GRAPH=1 / SIU3R_NO_STREAMS=1 disable the two mechanisms."""
+        always runs eagerly afterwards.  SIU3R_NO_GRAPH=1 / SIU3R_NO_STREAMS=1 disable the two mechanisms.
+
+        forward() = forward_async(...).result() on the caller's stream."""
+        if self._inflight.get(0) is not None and not self._inflight[0].done:
+            raise RuntimeError("SIU3RModel.forward: a forward_async() of slot 0 is still pending; call its result() first")
+        return self._submit(context_views_images, context_views_intrinsics, mask_labels, class_labels, enable_query_class_logit_lift,
+                            return_intermediates, slot=None).result()
+
+    def forward_async(self, context_views_images, context_views_intrinsics, mask_labels=None, class_labels=None,
+                      enable_query_class_logit_lift=False):
+        """forward() split at its one host synchronisation: enqueues the whole device side of the step (network body + the device
+        stage of the panoptic post-process + the asynchronous read-back of the segment table) and returns a handle; handle.result()
+        waits for the table (an event), builds the reference's `segments_info` lists and returns what forward() returns.
+
+        Up to `pipeline_depth` (default 2) steps may be pending.  Each pending step owns a SLOT: its own static activation buffers,
+        chain graphs, split-K workspaces and HIP streams, so that step n+1's encoder / decoder (latency-bound: 136-288 workgroups per
+        launch on 256 CUs) runs beside step n's heads and Mask2Former branch (throughput-bound) instead of behind them.  Steps are
+        independent -- the same arithmetic, the same launch sequence per step, bit-identical results to forward() (tests/
+        test_model_gpu.py::test_forward_async_interleaved) -- only their position in time changes.  The inputs are copied into the
+        slot's buffers on entry: the caller may overwrite them as soon as this returns (stream-ordered)."""
+        slot = self._next_slot
+        prev = self._inflight.get(slot)
+        if prev is not None and not prev.done:
+            raise RuntimeError(f"SIU3RModel.forward_async: {self.pipeline_depth} steps are already pending; call result() on the oldest first")
+        self._next_slot = (slot + 1) % self.pipeline_depth
+        h = self._submit(context_views_images, context_views_intrinsics, mask_labels, class_labels, enable_query_class_logit_lift, False, slot=slot)
+        self._inflight[slot] = h
+        return h
+
+    def _submit(self, context_views_images, context_views_intrinsics, mask_labels, class_labels, enable_query_class_logit_lift,
+                return_intermediates, slot):
         assert mask_labels is None and class_labels is None, "inference path only (training losses are out of scope)"
         ctx = self._ctx
         images = context_views_images.to(ctx.dev)
@@ -966,8 +1013,16 @@ class SIU3RModel:
         key = (B, V, H, W, images.dtype, K.dtype)
         eager = (not self.use_graph) or return_intermediates or ops.kernel_timer_active() or torch.cuda.is_current_stream_capturing()
         ent = None if eager else self._graphs.get(key)
-        main = torch.cuda.current_stream()
-        pp_state = {}
+        caller = torch.cuda.current_stream()
+        # slot None (forward()): state slot 0, and the chains are joined back into the caller's stream before the tail.  slot s
+        # (forward_async): state slot s, and the caller's stream carries ONLY encoder -> decoder: the heads, the joins and the tail stay
+        # on the side streams, so that the next step's encoder (enqueued on the caller's stream right behind this step's decoder) starts
+        # while this step's heads run; result() joins.  (One set of streams for all slots on purpose: this runtime multiplexes streams
+        # onto 4 hardware queues in order of first use, and a second set of streams ended up sharing queues with the first -- slot 1's
+        # encoder then simply queued behind slot 0's tail; with 8 queues everything overlapped and the step got 10-35 % SLOWER.)
+        sidx = 0 if slot is None else slot
+        pipelined = slot is not None and ctx.concurrent
+        pp_state = {"tail_stream": caller}
 
         def make_after_seg(st_, copy_out):
             # runs on the segmentation stream right behind Mask2Former: the panoptic device stage and the asynchronous read-back of its
@@ -977,44 +1032,38 @@ class SIU3RModel:
                 if copy_out:  # the logits leave the graphs' private memory, which the next replay overwrites
                     for k_ in ("class_queries_logits", "masks_queries_logits"):
                         seg_o[k_] = seg_o[k_].clone()
-                        seg_o[k_].record_stream(main)
-                pend = self.processor.begin_panoptic(seg_o, threshold=self.seg_threshold, target_sizes=[(H, W)] * B, label_ids_to_fuse=self.label_ids_to_fuse)
+                        seg_o[k_].record_stream(caller)
+                pend = self.processor.begin_panoptic(seg_o, threshold=self.seg_threshold, target_sizes=[(H, W)] * B,
+                                                     label_ids_to_fuse=self.label_ids_to_fuse, host_slot=sidx)
                 for k_ in ("tab", "probs", "kept_idx", "acc_list", "p256", "seg", "sem", "ins"):
-                    pend[k_].record_stream(main)  # allocated on the segmentation stream, read on the caller's
+                    pend[k_].record_stream(caller)  # allocated on the segmentation stream, read on the caller's
                 pp_state["seg_out"], pp_state["pend"] = seg_o, pend
             return after_seg
 
         if eager or ent is None:
+            need = {}
             if not eager:
-                self._graphs[key] = {"graphs": None}  # first call of this shape: eager (packs weights, fills caches)
+                # first call of this shape: eager (packs weights, fills caches) -- and measures the split-K workspace every chain asks for
+                ent = self._graphs[key] = {"graphs": None, "st": None, "slots": {}, "need": need}
             st = _Run(images, K)
-            self._run_stages(st, lambda name, fn: fn(), make_after_seg(st, False))
-            gaussians = st.gaussians
+
+            def run_eager(name, fn):
+                if eager:
+                    return fn()
+                with ops.splitk_meter() as m:
+                    fn()
+                need[name] = m
+
+            self._run_stages(st, run_eager, make_after_seg(st, False))
         else:
-            if ent["graphs"] is None:
-                st = ent["st"] = _Run(images.clone(), K.clone())
-                ent["graphs"] = {}
-                torch.cuda.synchronize()
-                conc, ctx.concurrent = ctx.concurrent, False  # a captured chain is serial by construction
-
-                def capture(name, fn):
-                    g = torch.cuda.CUDAGraph()
-                    # thread_local: only this thread's calls belong to the capture (a RCCL watchdog thread of a multi-GPU job
-                    # must not be able to invalidate it).  The chain's split-K workspace is its own (the chain graphs replay
-                    # concurrently) and exists before the capture starts (no fill node in the graph).
-                    with ops.splitk_scope((id(self), key, name), ctx.dev):
-                        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                            fn()
-                    ent["graphs"][name] = g
-
-                try:
-                    for name, fn in self._stages(st):
-                        if name != "tail":  # the tail (2 launches) stays eager: its outputs are then fresh tensors, not graph memory
-                            capture(name, fn)
-                finally:
-                    ctx.concurrent = conc
-                torch.cuda.synchronize()
-            st = ent["st"]
+            sl = ent["slots"].get(sidx)
+            if sl is None:
+                sl = ent["slots"][sidx] = self._capture_slot(ent, key, images, K)
+                if sidx == 0:
+                    ent["graphs"], ent["st"] = sl["graphs"], sl["st"]  # (tools/ read the first slot through these)
+            st = sl["st"]
+            if sl.get("done") is not None:
+                caller.wait_event(sl["done"])  # the slot's previous step (a no-op when its result() ran on this stream, as it normally has)
             st.images.copy_(images, non_blocking=True)
             st.K.copy_(K, non_blocking=True)
             tl = self._timeline
@@ -1023,31 +1072,75 @@ class SIU3RModel:
                 if tl is not None:  # tools/timeline.py: stage start / end events on the stage's own stream
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                fn() if name == "tail" else ent["graphs"][name].replay()
+                fn() if name == "tail" else sl["graphs"][name].replay()
                 if tl is not None:
                     e1.record()
                     tl.append((name, e0, e1))
 
-            self._run_stages(st, replay, make_after_seg(st, True))
-            # the Gaussians come from the eager tail (fresh memory)
-            gaussians = st.gaussians
-        seg_out = pp_state["seg_out"]
-        results = self.processor.finish_panoptic(pp_state["pend"])
-        if not eager:
-            # the channel-last logits / mask features / memory levels live in the graphs' private memory, which the next replay
-            # overwrites: they served the post-process above and do not leave with the result
-            for k_ in ("_masks_channel_last", "_mask_features", "_ms"):
-                seg_out.pop(k_, None)
-        gaussians, masks, infos, qcl, qscores = pp.post_process_gaussians(gaussians, results, B, V, H, W, enable_query_class_logit_lift)
-        if return_intermediates:
-            _, _, decs = self.backbone._assemble(st.enc, st.dec)
-            all1 = [t[:, 0, :-1] for t in st.enc["av"]]
-            all2 = [t[:, 1, :-1] for t in st.enc["av"]]
-            self._last = dict(dec1=decs[0], dec2=decs[1], decs=decs, all_feat1=all1, all_feat2=all2, ms=st.ms, pts1=st.pts[0],
-                              pts2=st.pts[1], gs_raw1=st.gs[0].reshape(B, H, W, -1), gs_raw2=st.gs[1].reshape(-1, H, W, st.gs[1].shape[-1]), seg_out=st.seg)
-        if enable_query_class_logit_lift:
-            return gaussians, seg_out, masks, infos, qscores
-        return gaussians, seg_out, masks, infos
+            pp_state["tail_stream"] = self._run_stages(st, replay, make_after_seg(st, True), pipelined=pipelined)
+            if pipelined:
+                sl["done"] = torch.cuda.Event()
+                sl["done"].record(pp_state["tail_stream"])
+        # the Gaussians come from the eager tail (fresh memory)
+        gaussians = st.gaussians
+        tail_stream = pp_state["tail_stream"]
+
+        def finish():
+            cur = torch.cuda.current_stream()
+            if tail_stream is not cur:
+                cur.wait_stream(tail_stream)  # the Gaussian fields (pipelined: the tail ran on a head stream, every chain joined into it)
+                for _, v_ in gaussians.items():
+                    if isinstance(v_, torch.Tensor):
+                        v_.record_stream(cur)
+            seg_out = pp_state["seg_out"]
+            if cur is not caller:
+                for k_ in ("tab", "probs", "kept_idx", "acc_list", "p256", "seg", "sem", "ins"):
+                    pp_state["pend"][k_].record_stream(cur)
+            results = self.processor.finish_panoptic(pp_state["pend"])
+            if not eager:
+                # the channel-last logits / mask features / memory levels live in the graphs' private memory, which the next replay
+                # overwrites: they served the post-process above and do not leave with the result
+                for k_ in ("_masks_channel_last", "_mask_features", "_ms"):
+                    seg_out.pop(k_, None)
+            g_, masks, infos, qcl, qscores = pp.post_process_gaussians(gaussians, results, B, V, H, W, enable_query_class_logit_lift)
+            if return_intermediates:
+                _, _, decs = self.backbone._assemble(st.enc, st.dec)
+                all1 = [t[:, 0, :-1] for t in st.enc["av"]]
+                all2 = [t[:, 1, :-1] for t in st.enc["av"]]
+                self._last = dict(dec1=decs[0], dec2=decs[1], decs=decs, all_feat1=all1, all_feat2=all2, ms=st.ms, pts1=st.pts[0],
+                                  pts2=st.pts[1], gs_raw1=st.gs[0].reshape(B, H, W, -1), gs_raw2=st.gs[1].reshape(-1, H, W, st.gs[1].shape[-1]), seg_out=st.seg)
+            if enable_query_class_logit_lift:
+                return g_, seg_out, masks, infos, qscores
+            return g_, seg_out, masks, infos
+
+        return _PendingForward(finish)
+
+    def _capture_slot(self, ent, key, images, K):
+        """Static buffers + one HIP graph per chain for one slot of this shape.  The chain's split-K workspace is its own (the chain
+        graphs replay concurrently), has exactly the size the chain's GEMMs asked for in the eager pass (none if none splits), exists
+        before the capture starts (no fill node in the graph) and is kept next to the graph."""
+        ctx = self._ctx
+        sl = {"st": _Run(images.clone(), K.clone()), "graphs": {}, "ws": {}}
+        st = sl["st"]
+        torch.cuda.synchronize()
+        conc, ctx.concurrent = ctx.concurrent, False  # a captured chain is serial by construction
+        try:
+            for name, fn in self._stages(st):
+                if name == "tail":  # the tail (2 launches) stays eager: its outputs are then fresh tensors, not graph memory
+                    continue
+                m = ent["need"].get(name)
+                ws = sl["ws"][name] = m.workspace(ctx.dev) if m is not None else None
+                g = torch.cuda.CUDAGraph()
+                # thread_local: only this thread's calls belong to the capture (a RCCL watchdog thread of a multi-GPU job must not
+                # be able to invalidate it)
+                with ops.splitk_scope(ws):
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        fn()
+                sl["graphs"][name] = g
+        finally:
+            ctx.concurrent = conc
+        torch.cuda.synchronize()
+        return sl
 
     # ---- the chains of the network body.  Each stage only reads what earlier stages left in the _Run
     def _stages(self, st):
@@ -1098,9 +1191,12 @@ class SIU3RModel:
     def _merged_decoder(self, st) -> bool:
         return self._ctx.fold and st.images.shape[1] == 2
 
-    def _run_stages(self, st, run, after_seg=None):
+    def _run_stages(self, st, run, after_seg=None, pipelined=False):
         """Enqueue the stages with their fork/join edges.  run(name, fn) either calls fn (eager) or replays its graph.  after_seg(): enqueued
-        on the segmentation stream right behind Mask2Former (the device half of the panoptic post-process)."""
+        on the segmentation stream right behind Mask2Former (the device half of the panoptic post-process).  Returns the stream the
+        tail ran on (every chain is joined into it).  pipelined (forward_async): the current stream carries only encoder -> decoder;
+        the pts3d head of the other views, the joins and the tail go to the head streams, so that whatever the caller enqueues next on
+        the current stream (the next step's encoder) is not ordered behind this step's heads."""
         ctx = self._ctx
         stages = dict(self._stages(st))
         main = torch.cuda.current_stream()
@@ -1156,13 +1252,18 @@ class SIU3RModel:
         pts0_stream = seg_stream if (par and not _PTS0_MAIN) else main
         if pts0_stream is not main:
             pts0_stream.wait_stream(main)  # the decoder's outputs
-        for name, s_ in zip(("gs0", "gsr", "ptsr", "pts0"), hs + [main, pts0_stream]):
+        pipelined = pipelined and par
+        ptsr_stream = hs[_PIPE_PTSR] if pipelined else main  # pipelined: behind one of the Gaussian heads instead of on the encoder's stream
+        for name, s_ in zip(("gs0", "gsr", "ptsr", "pts0"), hs + [ptsr_stream, pts0_stream]):
             with torch.cuda.stream(s_):
                 run(name, stages[name])
+        tail_stream = hs[1] if pipelined else main
         for s_ in hs + [seg_stream]:
-            if s_ is not main:
-                main.wait_stream(s_)
-        run("tail", stages["tail"])
+            if s_ is not tail_stream:
+                tail_stream.wait_stream(s_)
+        with torch.cuda.stream(tail_stream):
+            run("tail", stages["tail"])
+        return tail_stream
 
     def _s_encode_begin(self, st):
         ctx = self._ctx

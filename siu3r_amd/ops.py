@@ -192,29 +192,51 @@ def kernel_timer_active() -> bool:
     return _timer is not None
 
 
-# ---- split-K workspace.  The library decides tile and K split (siu3r_gemm_plan); the caller lends it one workspace per STREAM: fp32
-# slabs plus int32 tickets that are zero at allocation and that every split launch leaves zero again (the tile's last arriver resets its
-# ticket), so launches on one stream reuse them back to back without a fill kernel; launches on different streams may overlap and get
-# different workspaces.
-# A HIP-graph capture is its own scope (splitk_scope): torch captures every graph on the same internal stream, and the chain graphs of a
-# forward replay concurrently.
-SPLITK_WS_FLOATS = 16 * 1024 * 1024   # 64 MiB of slabs per stream / scope
+# ---- split-K workspace.  The library decides tile and K split (siu3r_gemm_plan); the caller lends it a workspace: fp32 slabs plus int32
+# tickets that are zero at allocation and that every split launch leaves zero again (the tile's last arriver resets its ticket), so
+# launches that are ordered behind each other reuse them back to back without a fill kernel.  Eager launches use one workspace per
+# STREAM (launches on different streams may overlap).  A HIP-graph capture is its own scope (splitk_scope): torch captures every graph
+# on the same internal stream, and the chain graphs of a forward replay concurrently -- the owner of the graph (model.py) measures
+# what the chain's GEMMs ask for in an eager pass (splitk_meter), allocates exactly that, keeps it next to the graph (it dies with it)
+# and lends it for the capture; a chain without a split GEMM gets none.
+SPLITK_WS_FLOATS = 16 * 1024 * 1024   # 64 MiB of slabs per eager stream
 SPLITK_COUNTERS = 8192
 _sk_pool: dict = {}
-_sk_scope = None
+_sk_scope = None    # None: per-stream pool; ("scope", (slabs, tickets) | None): what the enclosing splitk_scope lends
+_sk_meter = None
+
+
+class splitk_meter:
+    """with splitk_meter() as m: ...  -> m.floats / m.counters = the largest split-K workspace (siu3r_gemm_plan's ws_floats / counters)
+    any GEMM launched inside asked for; both 0 when none of them splits."""
+
+    def __enter__(self):
+        global _sk_meter
+        self.prev, _sk_meter = _sk_meter, self
+        self.floats = self.counters = 0
+        return self
+
+    def __exit__(self, *exc):
+        global _sk_meter
+        _sk_meter = self.prev
+
+    def workspace(self, dev):
+        """a workspace of exactly the measured size (None if nothing splits); the tickets start at zero"""
+        if self.floats == 0:
+            return None
+        return (torch.empty((self.floats,), dtype=torch.float32, device=dev), torch.zeros((max(1, self.counters),), dtype=torch.int32, device=dev))
 
 
 class splitk_scope:
-    """with splitk_scope(tag): GEMMs launched inside use the split-K workspace of `tag` (allocated and zeroed on entry, i.e. BEFORE a
-    graph capture that the caller opens inside the block) instead of the current stream's."""
+    """with splitk_scope(ws): GEMMs launched inside split K through `ws` = (slabs, tickets) -- allocated and zeroed by the caller, i.e.
+    BEFORE a graph capture that the caller opens inside the block -- instead of the current stream's workspace; ws None = no split."""
 
-    def __init__(self, tag, dev):
-        self.tag, self.dev = ("scope", tag), dev
+    def __init__(self, ws):
+        self.ws = ws
 
     def __enter__(self):
         global _sk_scope
-        self.prev, _sk_scope = _sk_scope, self.tag
-        _splitk_workspace(self.dev)
+        self.prev, _sk_scope = _sk_scope, ("scope", self.ws)
         return self
 
     def __exit__(self, *exc):
@@ -223,7 +245,9 @@ class splitk_scope:
 
 
 def _splitk_workspace(dev):
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _sk_scope or torch.cuda.current_stream().cuda_stream)
+    if _sk_scope is not None:
+        return _sk_scope[1]
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     ws = _sk_pool.get(key)
     if ws is None:
         ws = (torch.empty((SPLITK_WS_FLOATS,), dtype=torch.float32, device=dev), torch.zeros((SPLITK_COUNTERS,), dtype=torch.int32, device=dev))
@@ -252,8 +276,14 @@ def gemm_tune(key: int, value: int):
 
 def _gemm_launch(p: GemmParams, dev=None):
     if p.splitk != 1:
-        ws, cnt = _splitk_workspace(dev if dev is not None else torch.device("cuda", torch.cuda.current_device()))
-        p.sk_ws, p.sk_cnt, p.sk_ws_floats, p.sk_cnt_n = ws.data_ptr(), cnt.data_ptr(), ws.numel(), cnt.numel()
+        wsp = _splitk_workspace(dev if dev is not None else torch.device("cuda", torch.cuda.current_device()))
+        if wsp is not None:
+            ws, cnt = wsp
+            p.sk_ws, p.sk_cnt, p.sk_ws_floats, p.sk_cnt_n = ws.data_ptr(), cnt.data_ptr(), ws.numel(), cnt.numel()
+        if _sk_meter is not None:
+            pl = gemm_plan(p)
+            if pl.splitk > 1:
+                _sk_meter.floats, _sk_meter.counters = max(_sk_meter.floats, pl.ws_floats), max(_sk_meter.counters, pl.counters)
     if _plan_log is not None:
         _plan_log.append(gemm_plan(p))
     if _timer is None:

@@ -30,10 +30,12 @@ class VideoMask2FormerImageProcessor:
         return self.finish_panoptic(pend, with_query_class_logits)
 
     def begin_panoptic(self, outputs, threshold: float = 0.5, mask_threshold: float = 0.5, overlap_mask_area_threshold: float = 0.8,
-                       label_ids_to_fuse: Optional[Set[int]] = None, target_sizes: Optional[List[Tuple[int, int]]] = None, word_embeddings=None):
+                       label_ids_to_fuse: Optional[Set[int]] = None, target_sizes: Optional[List[Tuple[int, int]]] = None, word_embeddings=None,
+                       host_slot: int = 0):
         """First half: the device stage (probabilities, 256^2 masks, argmax maps, segment table) and an asynchronous copy of the small
         tables into pinned host memory, all on the CURRENT stream; returns the pending state.  SIU3RModel enqueues this right behind
-        Mask2Former on the segmentation stream, so that it runs beside the heads instead of after them."""
+        Mask2Former on the segmentation stream, so that it runs beside the heads instead of after them.  The host copy of the tables
+        is valid until the next begin_panoptic() with the same host_slot."""
         assert word_embeddings is None, "the refer head has no executable reference behaviour (SURVEY.md A.17)"
         if label_ids_to_fuse is None:
             label_ids_to_fuse = set()
@@ -69,9 +71,11 @@ class VideoMask2FormerImageProcessor:
             _p(sem), _p(ins), B, T, Q, Cc, IH, IW, H, W, MASK_SIZE, threshold, mask_threshold, overlap_mask_area_threshold,
             fuse_mask, _stream()))
         # one device->host read of the small tables (the reference does a .item() per query instead), asynchronous into pinned memory
-        host = getattr(self, "_host_tab", None)
+        # (pinned staging buffer per host_slot: results that are pending at the same time -- SIU3RModel.forward_async -- must not share one)
+        tabs = self.__dict__.setdefault("_host_tabs", {})
+        host = tabs.get(host_slot)
         if host is None or host.numel() != tab.numel():
-            host = self._host_tab = torch.empty(tab.numel(), dtype=torch.int32, pin_memory=True)
+            host = tabs[host_slot] = torch.empty(tab.numel(), dtype=torch.int32, pin_memory=True)
         host.copy_(tab, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()

@@ -316,6 +316,55 @@ def test_graph_replay_with_new_inputs_equals_eager():
     torch.cuda.empty_cache()
 
 
+def test_forward_async_interleaved():
+    """forward_async(): three steps pending at once over three slots, results picked up out of phase with the submissions, every slot
+    used for its eager / capture / replay rounds -- each step's result must be bit for bit what a graph-free synchronous forward()
+    computes on that step's input (the slots share nothing but the weights)."""
+    from oracle import weights as OW
+    from siu3r_amd.model import SIU3RModel
+
+    if "sd" not in _STATE:
+        _STATE["sd"] = OW.make_weights(0)
+    g = torch.Generator().manual_seed(22)
+    n_in = 9
+    imgs = torch.rand(n_in, 1, 2, 3, 256, 256, generator=g).cuda()
+    K = torch.tensor([[318 / 256, 0, 0.5], [0, 318 / 256, 0.5], [0, 0, 1]])[None, None].repeat(1, 2, 1, 1).cuda()
+    model = SIU3RModel(_STATE["sd"], image_size=(256, 256), precision="bf16x3")
+    model.pipeline_depth = 3
+    plain = SIU3RModel(_STATE["sd"], image_size=(256, 256), precision="bf16x3")
+    plain.use_graph = False
+    import collections
+    pend, got = collections.deque(), []
+    with torch.no_grad():
+        for n in range(n_in):
+            buf = imgs[n].clone()
+            pend.append(model.forward_async(buf, K, enable_query_class_logit_lift=True))
+            buf.fill_(0.5)  # the input was copied into the slot on entry (stream-ordered): the caller may overwrite it
+            if len(pend) == 3:
+                got.append(pend.popleft().result())
+        while pend:
+            got.append(pend.popleft().result())
+        with pytest.raises(RuntimeError):  # a fourth pending step has no slot
+            hs = [model.forward_async(imgs[0], K) for _ in range(4)]
+        for h in model._inflight.values():
+            h.result()
+        torch.cuda.synchronize()
+        for n in range(n_in):
+            a, b = got[n], plain(imgs[n], K, enable_query_class_logit_lift=True)
+            torch.cuda.synchronize()
+            for f in ("means", "covariances", "harmonics", "opacities", "semantic_labels", "instance_labels"):
+                assert torch.equal(getattr(a[0], f), getattr(b[0], f)), (n, f)
+            assert torch.equal(a[1].class_queries_logits, b[1].class_queries_logits), n
+            assert torch.equal(a[1].masks_queries_logits, b[1].masks_queries_logits), n
+            assert a[3] == b[3] and a[4] == b[4], n
+            assert all(torch.equal(x, y) for x, y in zip(a[0].seg_query_class_logits, b[0].seg_query_class_logits)), n
+        # a synchronous forward() after the pipeline drained uses slot 0 again
+        a, b = model(imgs[3], K), got[3]
+        assert torch.equal(a[0].means, b[0].means) and torch.equal(a[1].masks_queries_logits, b[1].masks_queries_logits)
+    del model, plain
+    torch.cuda.empty_cache()
+
+
 def test_batch_of_pairs_matches_single_pairs():
     """B = 2 pairs in one forward (graph-captured on the third call) == each pair alone, up to the fp32 rounding of sums whose slicing
     depends on the launch geometry (split-K at few tiles), and the id maps up to border pixels."""
