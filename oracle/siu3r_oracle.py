@@ -590,7 +590,7 @@ def m2f_decoder(w: W, ms: Sequence[T], mask_features: T, B: int, Tn: int, heads:
     dp = tm + ".decoder"
     hs = qf
     inter = _ln(w, dp + ".layernorm", hs, 1e-5)
-    inters, masks = [inter], []
+    inters, masks, used_masks = [inter], [], []
     m, am = _mask_predictor(w, dp + ".mask_predictor", inter, pix, sizes[0], heads)
     masks.append(m)
     n_layers = len({k.split(".")[5] for k in w if k.startswith(dp + ".layers.")})
@@ -599,6 +599,7 @@ def m2f_decoder(w: W, ms: Sequence[T], mask_features: T, B: int, Tn: int, heads:
         lvl = idx % 3
         am = am.clone()
         am[torch.where(am.sum(-1) == am.shape[-1])] = False  # fully blocked rows re-opened (:1306-1308)
+        used_masks.append(am[::heads].to(torch.uint8))  # [B, Q, T*h*w] (identical over the heads): what layer idx attends through
         a = _mha(hs + qe, feats[lvl] + poss[lvl], feats[lvl], w[p + ".cross_attn.in_proj_weight"],
                  w[p + ".cross_attn.in_proj_bias"], w[p + ".cross_attn.out_proj.weight"],
                  w[p + ".cross_attn.out_proj.bias"], heads, am)
@@ -622,7 +623,7 @@ def m2f_decoder(w: W, ms: Sequence[T], mask_features: T, B: int, Tn: int, heads:
         inters.append(inter)
         masks.append(m)
     class_logits = _lin(w, "mask2former.class_predictor", inters[-1].transpose(0, 1))
-    return class_logits, masks[-1], dict(all_masks=masks, all_inter=inters)
+    return class_logits, masks[-1], dict(all_masks=masks, all_inter=inters, attn_masks=used_masks)
 
 
 # ----------------------------------------------------------------------------------------
@@ -757,6 +758,7 @@ def model_forward(w: W, images: T, intrinsics: T, keep_intermediates: bool = Tru
         seg_masks=[r["segmentation"] for r in results], seg_infos=[r["segments_info"] for r in results],
         query_class_logits=[r["query_class_logits"] for r in results],
         query_scores=[r["query_scores"] for r in results],
+        attn_masks=extra["attn_masks"],
     )
     if keep_intermediates:
         out.update(bb=bb, ms1=ms1, ms2=ms2, pts1=pts1, pts2=pts2, gs_raw1=gs1, gs_raw2=gs2,
@@ -789,6 +791,7 @@ def model_forward_multi(w: W, images: T, intrinsics: T, keep_intermediates: bool
         seg_masks=[r["segmentation"] for r in results], seg_infos=[r["segments_info"] for r in results],
         query_class_logits=[r["query_class_logits"] for r in results],
         query_scores=[r["query_scores"] for r in results],
+        attn_masks=extra["attn_masks"],
     )
     if keep_intermediates:
         out.update(bb=bb, ms_v=ms_v, pts=pts, gs_raw=gs, mask_features=mask_features, ms=ms)

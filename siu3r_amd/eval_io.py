@@ -7,11 +7,14 @@ reads back (src/evaluator.py:108-150, 240-404):
         depth/<scene>_<tid>.png, depth_gt/...   int32 millimetres (`(depth * 1000).astype(int32)`, :309-310, mode "I")
         {context,target}_seg_pred/<scene>_pred<vid>.png + pred.json    segment id = 1000 * semantic + instance as R + 256 G + 65536 B
         {context,target}_seg_gt/<scene>_gt<vid>.png                    same encoding, instance = 1 + index in the sorted instance list
-    <save_dir>/results.json                     keys psnr, {context,target}_{pq,pqs_per_class,miou,ious_per_class} (evaluator.py:368-399)
+    <save_dir>/results.json                     keys psnr, ssim, absrel, rmse, {context,target}_{pq,pqs_per_class,miou,ious_per_class}
+                                                (evaluator.py:368-399); per scene render_scores.json / depth_scores.json
 
 so that the reference's tooling can score this build's outputs and vice versa.  The numbers come from siu3r_amd.metrics (additive
-statistics; PQ / PSNR definitions are third-party in the reference: parity unpinned, see that module).  SSIM / LPIPS / mAP are not part
-of the BASELINE metric and are not computed.  Host-side IO (numpy + PIL); nothing here runs on the GPU."""
+statistics).  Pinned to the reference: depth errors and mIoU -- tests/golden/evaluator_tree.npz holds what the reference's own
+Evaluator.evaluate returns for a synthetic tree (tests/golden/make_golden_eval.py).  PQ / PSNR / SSIM are torchmetrics classes in the
+reference: restated, parity unpinned (see that module).  LPIPS / mAP are not computed.  Host-side IO (numpy + PIL); nothing here
+runs on the GPU."""
 from __future__ import annotations
 
 import json
@@ -131,6 +134,8 @@ def load_segmentation_dir(pred_dir: Path, gt_dir: Path):
 
 def accumulate_dir(path, acc: Optional[M.MetricAccumulator] = None, scenes: Optional[Sequence[str]] = None, write_scene_scores: bool = True) -> M.MetricAccumulator:
     """Fold the scene directories under `path` (all, or the named subset: a rank's shard) into additive statistics."""
+    from PIL import Image
+
     acc = acc or M.MetricAccumulator()
     root = Path(path)
     dirs = sorted(d for d in root.iterdir() if d.is_dir() and "_context" in d.name)
@@ -142,12 +147,17 @@ def accumulate_dir(path, acc: Optional[M.MetricAccumulator] = None, scenes: Opti
             scores = []
             for item in sorted((d / "rgb").glob("*.png")):
                 pred, gt = load_image01(item), load_image01(d / "rgb_gt" / item.name)
-                p = M.psnr(pred, gt)  # the files already hold the truncated uint8 values
-                acc.sum_psnr += p
-                acc.n_images += 1
-                scores.append({"item": item.name, "psnr": p})
+                scores.append({"item": item.name, **acc.add_render_u8(pred, gt)})  # the files already hold the truncated uint8 values
             if write_scene_scores:
                 with open(d / "render_scores.json", "w") as fh:
+                    json.dump(scores, fh, indent=4)
+        if (d / "depth").is_dir() and (d / "depth_gt").is_dir():
+            scores = []
+            for item in sorted((d / "depth").glob("*.png")):  # int32 millimetres -> metres (evaluator.py:340-345)
+                dm, gm = (np.array(Image.open(f)).astype(np.float32) / 1000.0 for f in (item, d / "depth_gt" / item.name))
+                scores.append({"item": item.name, **acc.add_depth(dm, gm)})
+            if write_scene_scores:
+                with open(d / "depth_scores.json", "w") as fh:
                     json.dump(scores, fh, indent=4)
         for mode in ("context", "target"):
             if (d / f"{mode}_seg_pred").is_dir() and (d / f"{mode}_seg_gt").is_dir() and any((d / f"{mode}_seg_pred").glob("*.png")):

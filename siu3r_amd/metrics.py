@@ -5,9 +5,14 @@ renders, evaluator.py:257-268, visualizer.py:291/358: `(img * 255).astype(uint8)
 `(semantic, instance)` maps decoded from `1000 * sem + ins` (evaluator.py:126-150, 282-329) with things = [3..20],
 stuffs = [1, 2] (1-based, :32-37), mean IoU from an intersection/union histogram.  Everything the BASELINE metric needs is
 additive over images, so here each rank accumulates a fixed-length fp64 vector and ONE all-gather (siu3r_amd/distributed.py)
-reproduces the single-process result.  torchmetrics is not in this image: PSNR / PQ follow the published definitions
-(PQ: Kirillov et al. 2019, as implemented by torchmetrics.detection.PanopticQuality with allow_unknown_preds_category=True)
-and are PARITY-UNPINNED against the library; the tests check them against hand-computed cases.  Host-side code (numpy)."""
+reproduces the single-process result.  Image quality adds SSIM (torchmetrics StructuralSimilarityIndexMeasure defaults, :231-233)
+and depth quality adds AbsRel / RMSE after a least-squares scale + shift fit over the valid ground-truth pixels (:229-236,
+:346-366); all three are per-image values the evaluator averages, i.e. additive too.  Not computed: LPIPS (needs the VGG weights,
+absent offline) and mAP (`context_map` / `target_map`: COCO matching over the whole set, not additive).
+torchmetrics (pinned 1.7.3, uv.lock:3373) is not in this image: PSNR / SSIM / PQ restate its algorithms -- PQ: Kirillov et al. 2019
+as torchmetrics.detection.PanopticQuality(allow_unknown_preds_category=True, return_per_class=True) implements it, per-class order
+= sorted things then sorted stuffs -- and are PARITY-UNPINNED against the library; the tests check them against hand-computed
+cases (void / unknown categories, absent classes, mostly-void segments).  Host-side code (numpy)."""
 from __future__ import annotations
 
 from typing import Dict, Iterable, Sequence
@@ -32,6 +37,64 @@ def psnr(pred: np.ndarray, target: np.ndarray, data_range: float | None = None) 
     return float("inf") if mse == 0 else 10.0 * np.log10(dr * dr / mse)
 
 
+def _gauss1d(size: int = 11, sigma: float = 1.5) -> np.ndarray:
+    d = np.arange((1 - size) / 2.0, (1 + size) / 2.0, 1.0)
+    g = np.exp(-((d / sigma) ** 2) / 2.0)
+    return g / g.sum()
+
+
+def ssim(pred: np.ndarray, target: np.ndarray, data_range: float | None = None, kernel_size: int = 11, sigma: float = 1.5,
+         k1: float = 0.01, k2: float = 0.03) -> float:
+    """StructuralSimilarityIndexMeasure() of torchmetrics on ONE image [H, W, C] (or [H, W]): separable 11-tap Gaussian window
+    (sigma 1.5) per channel over the reflect-padded image, the local variances clamped at 0, the SSIM map cropped by the pad again
+    and averaged; data_range None = max(pred.max - pred.min, target.max - target.min)."""
+    p, t = np.asarray(pred, np.float64), np.asarray(target, np.float64)
+    if p.ndim == 2:
+        p, t = p[..., None], t[..., None]
+    dr = max(float(p.max() - p.min()), float(t.max() - t.min())) if data_range is None else float(data_range)
+    c1, c2 = (k1 * dr) ** 2, (k2 * dr) ** 2
+    pad = (kernel_size - 1) // 2
+    if min(p.shape[0], p.shape[1]) <= 2 * pad:  # reflect padding needs pad < size, the crop a non-empty interior (torchmetrics raises)
+        raise ValueError(f"ssim: image {p.shape[:2]} too small for an {kernel_size}-tap window")
+    g = _gauss1d(kernel_size, sigma)
+
+    def blur(x):  # [H + 2 pad, W + 2 pad, C] -> valid separable convolution [H, W, C]
+        H = x.shape[0] - 2 * pad
+        y = sum(g[i] * x[i:i + H] for i in range(kernel_size))
+        W = x.shape[1] - 2 * pad
+        return sum(g[i] * y[:, i:i + W] for i in range(kernel_size))
+
+    rp = lambda x: np.pad(x, ((pad, pad), (pad, pad), (0, 0)), mode="reflect")
+    pp, tp = rp(p), rp(t)
+    mu_p, mu_t = blur(pp), blur(tp)
+    s_pp = np.maximum(blur(pp * pp) - mu_p * mu_p, 0.0)
+    s_tt = np.maximum(blur(tp * tp) - mu_t * mu_t, 0.0)
+    s_pt = blur(pp * tp) - mu_p * mu_t
+    full = ((2 * mu_p * mu_t + c1) * (2 * s_pt + c2)) / ((mu_p * mu_p + mu_t * mu_t + c1) * (s_pp + s_tt + c2))
+    return float(full[pad:-pad, pad:-pad].mean())
+
+
+def fit_scale_and_shift(pred: np.ndarray, gt: np.ndarray):
+    """least-squares (scale, shift) with scale * pred + shift ~ gt over gt > 0 (evaluator.py:229-236)"""
+    m = gt > 0
+    x, y = np.asarray(pred, np.float64)[m], np.asarray(gt, np.float64)[m]
+    A = np.stack((x, np.ones_like(x)), 1)
+    sol, *_ = np.linalg.lstsq(A, y, rcond=None)
+    return float(sol[0]), float(sol[1])
+
+
+def depth_errors(depth: np.ndarray, depth_gt: np.ndarray):
+    """(absrel, rmse) of a depth map in metres against ground truth after the scale + shift alignment, over the pixels with
+    ground truth (evaluator.py:346-366); (nan, nan) when no pixel has ground truth."""
+    gt = np.asarray(depth_gt, np.float64)
+    m = gt > 0
+    if not m.any():
+        return float("nan"), float("nan")
+    sc, sh = fit_scale_and_shift(depth, gt)
+    d = np.asarray(depth, np.float64)[m] * sc + sh
+    return float(np.mean(np.abs(d - gt[m]) / gt[m])), float(np.sqrt(np.mean((d - gt[m]) ** 2)))
+
+
 def decode_segment_ids(rgb_u8: np.ndarray):
     """RGB PNG -> (semantic, instance) via segment_id = R + 256 G + 65536 B = 1000 * sem + ins (evaluator.py:126-144)."""
     sid = rgb_u8[..., 0].astype(np.int64) + rgb_u8[..., 1].astype(np.int64) * 256 + rgb_u8[..., 2].astype(np.int64) * 65536
@@ -54,7 +117,9 @@ def panoptic_stats(pred_sem, pred_ins, gt_sem, gt_ins, things: Sequence[int] = T
                    num_classes: int = NUM_CLASSES) -> np.ndarray:
     """One update of PanopticQuality: returns [num_classes, 4] = (sum IoU of TPs, TP, FP, FN) per category.
     A predicted and a ground-truth segment of the same category match iff IoU > 0.5 (unique by construction), where the union
-    excludes the part of the prediction that lies on void ground truth; unmatched predictions mostly (> 50 %) on void are not FPs."""
+    excludes the part of the prediction that lies on void ground truth; unmatched predictions mostly (> 50 %) on void ground truth
+    are not FPs and, symmetrically, unmatched ground-truth segments mostly covered by void PREDICTION (unknown categories become
+    void under allow_unknown_preds_category) are not FNs (torchmetrics _panoptic_quality_update_sample, after COCO panopticapi)."""
     p_col, p_cat = _segments(np.asarray(pred_sem), np.asarray(pred_ins), things, stuffs, True)
     g_col, g_cat = _segments(np.asarray(gt_sem), np.asarray(gt_ins), things, stuffs, True)
     p_col, g_col = p_col.reshape(-1), g_col.reshape(-1)
@@ -76,8 +141,8 @@ def panoptic_stats(pred_sem, pred_ins, gt_sem, gt_ins, things: Sequence[int] = T
             out[c, 1] += 1
             matched_p.add(pc)
             matched_g.add(gc)
-    for gc in g_area:
-        if gc // 100000 != 0 and gc not in matched_g:
+    for gc, a in g_area.items():
+        if gc // 100000 != 0 and gc not in matched_g and inter.get((0, gc), 0) / a <= 0.5:
             out[gc // 100000, 3] += 1
     for pc, a in p_area.items():
         if pc // 100000 != 0 and pc not in matched_p and inter.get((pc, 0), 0) / a <= 0.5:
@@ -86,9 +151,11 @@ def panoptic_stats(pred_sem, pred_ins, gt_sem, gt_ins, things: Sequence[int] = T
 
 
 def pq_from_stats(stats: np.ndarray, classes: Iterable[int] = THINGS + STUFFS) -> Dict[str, object]:
-    """per-class PQ = sum IoU / (TP + FP/2 + FN/2) (0 where the class never occurs), mean over `classes` (evaluator.py:384-387)."""
+    """per-class PQ = sum IoU / (TP + FP/2 + FN/2) (0 where the class never occurs) in the order `classes` is given (the evaluator's
+    `*_pqs_per_class`: torchmetrics' continuous ids = sorted things, then sorted stuffs), and its mean over ALL of them, absent
+    classes included (np.mean of the per-class list, evaluator.py:384-387)."""
     per = []
-    for c in sorted(classes):
+    for c in classes:
         s, tp, fp, fn = stats[c]
         d = tp + 0.5 * fp + 0.5 * fn
         per.append(float(s / d) if d > 0 else 0.0)
@@ -107,18 +174,41 @@ def miou_stats(pred_sem, gt_sem, num_classes: int = NUM_CLASSES) -> np.ndarray:
 
 
 class MetricAccumulator:
-    """Additive statistics of one rank.  Vector layout (fp64): [n_images, sum_psnr] + context PQ [C,4] + target PQ [C,4] +
-    context mIoU [C,2] + target mIoU [C,2]  ->  2 + 12 C doubles (254 for C = 21: 2 KB per rank in the all-gather)."""
+    """Additive statistics of one rank.  Vector layout (fp64): [n_images, sum_psnr, n_ssim, sum_ssim, n_depth, sum_absrel, sum_rmse] +
+    context PQ [C,4] + target PQ [C,4] + context mIoU [C,2] + target mIoU [C,2]  ->  7 + 12 C doubles (259 for C = 21: 2 KB per
+    rank in the all-gather)."""
+    HEAD = 7
 
     def __init__(self, num_classes: int = NUM_CLASSES, things=THINGS, stuffs=STUFFS):
         self.C, self.things, self.stuffs = num_classes, tuple(things), tuple(stuffs)
-        self.n_images, self.sum_psnr = 0.0, 0.0
+        self.n_images, self.sum_psnr, self.n_ssim, self.sum_ssim = 0.0, 0.0, 0.0, 0.0
+        self.n_depth, self.sum_absrel, self.sum_rmse = 0.0, 0.0, 0.0
         self.pq = {k: np.zeros((num_classes, 4)) for k in ("context", "target")}
         self.iou = {k: np.zeros((num_classes, 2)) for k in ("context", "target")}
 
     def add_render(self, pred01: np.ndarray, gt01: np.ndarray):
-        self.sum_psnr += psnr(png_roundtrip(pred01), png_roundtrip(gt01))
+        return self.add_render_u8(png_roundtrip(pred01), png_roundtrip(gt01))
+
+    def add_render_u8(self, pred: np.ndarray, gt: np.ndarray):
+        """images as read back from the PNGs (uint8 / 255); returns the item's scores (render_scores.json)"""
+        sc = {"psnr": psnr(pred, gt)}
+        self.sum_psnr += sc["psnr"]
         self.n_images += 1
+        if min(np.shape(pred)[:2]) > 10:  # (images smaller than the 11-tap window have no SSIM)
+            sc["ssim"] = ssim(pred, gt)
+            self.sum_ssim += sc["ssim"]
+            self.n_ssim += 1
+        return sc
+
+    def add_depth(self, depth_m: np.ndarray, depth_gt_m: np.ndarray):
+        """one target view's rendered and ground-truth depth in metres (as read back from the millimetre PNGs); views without any
+        ground-truth pixel are skipped (the reference would average a NaN)"""
+        a, r = depth_errors(depth_m, depth_gt_m)
+        if a == a:
+            self.sum_absrel += a
+            self.sum_rmse += r
+            self.n_depth += 1
+        return {"absrel": a, "rmse": r}
 
     def add_segmentation(self, which: str, pred_sem, pred_ins, gt_sem, gt_ins):
         """one scene: all its views concatenated along H, as the evaluator does (evaluator.py:146-150)."""
@@ -126,15 +216,15 @@ class MetricAccumulator:
         self.iou[which] += miou_stats(pred_sem, gt_sem, self.C)
 
     def to_vector(self) -> np.ndarray:
-        return np.concatenate(([self.n_images, self.sum_psnr], self.pq["context"].ravel(), self.pq["target"].ravel(),
+        return np.concatenate(([self.n_images, self.sum_psnr, self.n_ssim, self.sum_ssim, self.n_depth, self.sum_absrel, self.sum_rmse], self.pq["context"].ravel(), self.pq["target"].ravel(),
                                self.iou["context"].ravel(), self.iou["target"].ravel())).astype(np.float64)
 
     @classmethod
     def from_vectors(cls, vecs: np.ndarray, num_classes: int = NUM_CLASSES, things=THINGS, stuffs=STUFFS) -> "MetricAccumulator":
-        v = np.asarray(vecs, np.float64).reshape(-1, 2 + 12 * num_classes).sum(0)
+        v = np.asarray(vecs, np.float64).reshape(-1, cls.HEAD + 12 * num_classes).sum(0)
         m = cls(num_classes, things, stuffs)
-        m.n_images, m.sum_psnr = v[0], v[1]
-        o, C = 2, num_classes
+        m.n_images, m.sum_psnr, m.n_ssim, m.sum_ssim, m.n_depth, m.sum_absrel, m.sum_rmse = v[:cls.HEAD]
+        o, C = cls.HEAD, num_classes
         m.pq["context"] = v[o:o + 4 * C].reshape(C, 4); o += 4 * C
         m.pq["target"] = v[o:o + 4 * C].reshape(C, 4); o += 4 * C
         m.iou["context"] = v[o:o + 2 * C].reshape(C, 2); o += 2 * C
@@ -142,16 +232,22 @@ class MetricAccumulator:
         return m
 
     def compute(self) -> Dict[str, object]:
-        """the keys of the reference's results.json (evaluator.py:370-399) that the BASELINE metric uses."""
+        """the keys of the reference's results.json (evaluator.py:368-399) except `lpips` and `*_map` (module docstring)."""
         res: Dict[str, object] = {}
         if self.n_images:
             res["psnr"] = self.sum_psnr / self.n_images
+        if self.n_ssim:
+            res["ssim"] = self.sum_ssim / self.n_ssim
+        if self.n_depth:
+            res["absrel"] = self.sum_absrel / self.n_depth
+            res["rmse"] = self.sum_rmse / self.n_depth
         for k in ("context", "target"):
             if self.pq[k].sum() > 0:
                 r = pq_from_stats(self.pq[k], self.things + self.stuffs)
                 res[f"{k}_pqs_per_class"], res[f"{k}_pq"] = r["per_class"], r["pq"]
-            if self.iou[k][:, 1].sum() > 0:
-                inter, union = self.iou[k][:, 0], self.iou[k][:, 1]
+            if self.iou[k][1:, 1].sum() > 0:
+                # include_background=False (evaluator.py:60-66): class 0 is dropped, the list has C - 1 entries (utils/miou.py:64-77)
+                inter, union = self.iou[k][1:, 0], self.iou[k][1:, 1]
                 iou = np.where(union > 0, inter / np.maximum(union, 1), 0.0)
                 res[f"{k}_ious_per_class"], res[f"{k}_miou"] = iou.tolist(), float(np.mean(iou))
         return res

@@ -700,6 +700,10 @@ class VideoMask2FormerForVideoSegmentationOutput(dict):
 class VideoMask2FormerForVideoSegmentation:
     def __init__(self, ctx: _Ctx, num_queries=100):
         self.ctx, self.num_queries = ctx, num_queries
+        # None, or nine uint8 [B, Q, T*h*w] masks (1 = blocked) that the masked cross-attention layers use INSTEAD of thresholding their
+        # own mask logits (sigmoid < 0.5, video_seg_decoder.py:1461-1478): tests feed the oracle's masks to show that a logit difference
+        # above 1e-3 is a flipped borderline mask pixel and nothing else.  Eager mode only.
+        self.forced_attn_masks = None
         self.heads = 8
 
     # ---- pixel decoder (video_seg_decoder.py:2072-2196), feats NHWC [N2, h_l, w_l, 1024], strides 4,8,16,32
@@ -859,6 +863,10 @@ class VideoMask2FormerForVideoSegmentation:
             q = ops.linear(hsb, ctx.w.lin[p + ".cross_attn.q"], out_dtype=ctx.act, residual=bres(ctx.cache[p + ".cross_attn.qres"])).view(B, Q, 8, d)
             j = idx // 3
             k, v = kvs[lvl][:, :, j], kvs[lvl][:, :, 3 + j]
+            if self.forced_attn_masks is not None:  # parity diagnostics (tests): attend through given masks instead of the thresholded ones
+                fm = self.forced_attn_masks[idx].to(ctx.dev, torch.uint8)
+                am = torch.zeros((B, Q, ((fm.shape[-1] + 63) // 64) * 64), dtype=torch.uint8, device=ctx.dev)
+                am[..., :fm.shape[-1]] = fm
             a = ops.attention(q, k, v, heads=8, head_dim=d, scale=d ** -0.5, mask=am, split3=ctx.split)
             a = ops.linear(a, ctx.w.linear(p + ".cross_attn.out_proj"), out_dtype=torch.float32, residual=hs)
             hs, hsb = ctx.ln2(p + ".cross_attn_layer_norm", a, 1e-5)

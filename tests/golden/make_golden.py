@@ -29,12 +29,20 @@ from oracle import weights as OW  # noqa: E402
 
 STRIDE = 4093  # prime stride for the sampled tensors
 ISTRIDE = 97    # stride for the integer id maps
+WINDOW = 65536  # one contiguous window per tensor, compared densely (offset: a third into the tensor, 64-aligned)
+
+
+def window_of(numel):
+    if numel <= WINDOW:
+        return 0, numel
+    return (numel // 3) // 64 * 64, WINDOW
 
 
 def summarize(t: torch.Tensor):
     f = t.detach().float().reshape(-1)
+    o, n = window_of(f.numel())
     return dict(shape=list(t.shape), l2=float(f.double().norm()), mean=float(f.double().mean()), absmax=float(f.abs().max()),
-                sample=f[::STRIDE].numpy().astype(np.float32))
+                sample=f[::STRIDE].numpy().astype(np.float32), window=f[o:o + n].numpy().astype(np.float32))
 
 
 def load_pair(size):
@@ -192,9 +200,10 @@ if __name__ == "__main__":
     assert R.reference_available(), "/root/reference is required to (re)generate the fixtures"
     R.install_stubs()
     torch.manual_seed(0)
-    small_op_fixtures()
-    panoptic_fixture()
-    lifting_fixture()
+    if "models" not in sys.argv[1:]:  # `make_golden.py models`: only the forward fixtures
+        small_op_fixtures()
+        panoptic_fixture()
+        lifting_fixture()
     sd = OW.make_weights(0)
     multi_fixture(sd)
     for size in (256, 512):

@@ -7,6 +7,14 @@ import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STRIDE = 4093
+WINDOW = 65536
+
+
+def window_of(numel):
+    """the contiguous window tests/golden/make_golden.py stores of every tensor (dense comparison)"""
+    if numel <= WINDOW:
+        return 0, numel
+    return (numel // 3) // 64 * 64, WINDOW
 
 
 def load_model_fixture(size):
@@ -49,6 +57,16 @@ def compare_summary(name, t: torch.Tensor, z, tol):
     l2 = abs(float(f.double().norm()) - float(z[f"{name}.l2"])) / (float(z[f"{name}.l2"]) + 1e-30)
     print(f"[golden] {name:24s} sample max-normalised err {err:.3e}  |l2 rel diff| {l2:.3e}")
     assert err <= tol and l2 <= tol, (name, err, l2)
+    if f"{name}.window" in z.files:
+        # one contiguous window (64 Ki elements) compared densely: max-normalised error and the relative L2 norm OF THE DIFFERENCE
+        o, n = window_of(f.numel())
+        w_want, w_got = torch.from_numpy(z[f"{name}.window"]).double(), f[o:o + n].double()
+        assert w_want.numel() == n, (name, w_want.numel(), n)
+        werr = float((w_got - w_want).abs().max()) / scale
+        wl2 = float((w_got - w_want).norm() / (w_want.norm() + 1e-30))
+        print(f"[golden] {name:24s} dense window [{o}:{o + n}] max-normalised err {werr:.3e}  rel l2 of the difference {wl2:.3e}")
+        assert werr <= tol and wl2 <= tol, (name, werr, wl2)
+        err = max(err, werr)
     return err
 
 

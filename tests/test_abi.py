@@ -127,6 +127,64 @@ def test_ping_pong_and_pipelined_kernels_fit_one_workgroup_per_cu():
         assert r["VGPRs"] + r.get("AGPRs", 0) <= 256 and r["ScratchSize [bytes/lane]"] == 0 and r["LDS Size [bytes/block]"] <= 160 * 1024, (name, r)
 
 
+def _device_disassembly(unit):
+    """gfx950 disassembly of one translation unit's device code: .hip_fatbin of the object file -> unbundle -> llvm-objdump"""
+    import subprocess
+    import tempfile
+
+    from siu3r_amd import build as B
+
+    B.build()
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(B.OBJ, unit.replace(".hip", ".o"))
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        subprocess.run([f"{llvm}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj, os.path.join(tmp, "unused.o")], check=True)
+        subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        return subprocess.run([f"{llvm}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="needs the ROCm LLVM tools")
+def test_ping_pong_main_loops_are_spill_free():
+    """The 256-row ping-pong variants report scratch (264-316 B per lane for 256 x 256, test above).  That is only acceptable behind the
+    main loop: in the compiled code object of every variant, no scratch access may lie inside a loop that holds MFMAs (the prologue
+    may park a value, the row passes of the epilogue may spill next to the live accumulators; a K loop that spills would cost every
+    step).  Checked on the shipped objects: every backward branch spanning MFMAs is a loop, all MFMAs must be inside one."""
+    checked = spilling = 0
+    for unit in ("gemm_pp_t1x.hip", "gemm_pp_t1b.hip", "gemm_pp_t2x.hip", "gemm_pp_t2b.hip", "gemm_pp_t3x.hip", "gemm_pp_t3b.hip"):
+        asm = _device_disassembly(unit)
+        funcs = re.split(r"\n([0-9a-f]+) <([^>]+)>:\n", asm)
+        for base, name, body in zip(funcs[1::3], funcs[2::3], funcs[3::3]):
+            if "gemm_pp_kernel" not in name:
+                continue
+            base = int(base, 16)
+            ins = []  # (address, text)
+            for l in body.split("\n"):
+                m = re.search(r"//\s*([0-9A-Fa-f]+):", l)
+                if m:
+                    ins.append((int(m.group(1), 16), l))
+            mfma = [a for a, l in ins if "v_mfma" in l]
+            scratch = [a for a, l in ins if re.search(r"\bscratch_(load|store)", l)]
+            assert mfma, name
+            # loops that hold MFMAs: backward branches (target <= branch address) spanning at least one MFMA
+            loops = []
+            for a, l in ins:
+                m = re.search(r"s_c?branch\w*\s.*<[^>]*\+0x([0-9a-f]+)>", l)
+                if m and base + int(m.group(1), 16) <= a and any(base + int(m.group(1), 16) <= x <= a for x in mfma):
+                    loops.append((base + int(m.group(1), 16), a))
+            assert loops, f"{name}: no MFMA loop found in the disassembly"
+            # innermost ones only (an outer loop over tiles / slices holds the epilogue too); back-edges of one header are one loop
+            heads = {lo: max(h for l_, h in loops if l_ == lo) for lo, _ in loops}
+            loops = [(lo, hi) for lo, hi in heads.items() if not any(lo < lo2 and hi2 <= hi or lo <= lo2 and hi2 < hi for lo2, hi2 in heads.items())]
+            assert all(any(lo <= x <= hi for lo, hi in loops) for x in mfma), f"{name}: MFMAs outside the K loop"
+            checked += 1
+            spilling += 1 if scratch else 0
+            bad = [hex(x) for x in scratch if any(lo <= x <= hi for lo, hi in loops)]
+            assert not bad, f"{unit}: {name}: scratch accesses inside the MFMA loop at {bad[:4]} (loops {[(hex(lo), hex(hi)) for lo, hi in loops]})"
+    assert checked >= 12, checked
+    print(f"{checked} ping-pong variants disassembled, {spilling} use scratch -- none of it inside an MFMA loop")
+
+
 def _plan(**kw):
     """siu3r_gemm_plan is a host function: it can be asked about a problem without a GPU (pointers are only tested for null)"""
     from siu3r_amd import _lib

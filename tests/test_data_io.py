@@ -233,3 +233,40 @@ def test_substituted_pairs_are_counted_once_across_ranks():
     seen = set()
     kept = scannet.own_items([2, 2], [{"pair_index": 3}, {"pair_index": 3}], 3, seen)
     assert [k["pair_index"] for k in kept] == [3]
+
+
+def test_evaluator_tree_against_reference(tmp_path):
+    """tests/golden/evaluator_tree.npz: a synthetic result tree and what the REFERENCE's Evaluator.evaluate returns for it (depth
+    quality + mIoU; generated by tests/golden/make_golden_eval.py).  The tree is rebuilt with the product's writers and scored with the
+    product's reader / metrics: absrel, rmse (overall and per item), per-class IoUs and mIoU must agree."""
+    from siu3r_amd import eval_io as E
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "evaluator_tree.npz"))
+    scenes = sorted({k.split(".")[0] for k in z.files if k.startswith("scene")})
+    cids, tids = (10, 30), (12, 20, 28)
+    for name in scenes:
+        dp, dg = z[f"{name}.depth"].astype(np.float64) / 1000.0, z[f"{name}.depth_gt"].astype(np.float64) / 1000.0
+        # +0.5 mm: the writer truncates metres * 1000 to int32 (visualizer.py:309-310); the stored values are whole millimetres
+        blank = np.zeros((1, len(tids), 3) + dp.shape[1:], np.float32)
+        E.save_recon_images(blank, (dp + 0.0005)[None], blank, (dg + 0.0005 * (dg > 0))[None], tmp_path, [name], [cids], [tids])
+        for mode, ids in (("context", cids), ("target", tids)):
+            ps, pi, gs, gi = (z[f"{name}.{mode}.{k}"].astype(np.int64) for k in ("pred_sem", "pred_ins", "gt_sem", "gt_ins"))
+            E.save_seg_ids(mode, ps[None], pi[None], tmp_path, [name], [cids], [tids])
+            base = E.scene_dir(tmp_path, name, cids)
+            os.makedirs(base / f"{mode}_seg_gt", exist_ok=True)
+            from PIL import Image
+            for s_, i_, v in zip(gs, gi, ids):
+                Image.fromarray(E.encode_segment_ids(s_, i_)).save(base / f"{mode}_seg_gt" / f"{name}_gt{v}.png")
+    res = E.evaluate_dir(tmp_path)
+    # the reference computes in fp32 (torch.linalg.lstsq, torch.mean); this build in fp64
+    assert abs(res["absrel"] - float(z["result.absrel"])) <= 2e-6 * float(z["result.absrel"]) + 1e-8, (res["absrel"], z["result.absrel"])
+    assert abs(res["rmse"] - float(z["result.rmse"])) <= 2e-6 * float(z["result.rmse"]) + 1e-8, (res["rmse"], z["result.rmse"])
+    for mode in ("context", "target"):
+        np.testing.assert_allclose(res[f"{mode}_ious_per_class"], z[f"result.{mode}_ious_per_class"], rtol=1e-6, atol=1e-7)
+        assert len(res[f"{mode}_ious_per_class"]) == 20
+        assert abs(res[f"{mode}_miou"] - float(z[f"result.{mode}_miou"])) < 1e-6
+    items = []
+    for d in sorted(p for p in tmp_path.iterdir() if p.is_dir()):
+        items += [[it["absrel"], it["rmse"]] for it in json.load(open(d / "depth_scores.json"))]
+    np.testing.assert_allclose(np.asarray(items), z["result.depth_items"], rtol=5e-5, atol=1e-7)
+    assert os.path.exists(tmp_path / "results.json") and "psnr" in res and "ssim" in res  # (blank renders: psnr inf is a legal value)

@@ -36,8 +36,8 @@ def test_panoptic_quality_hand_case():
     # chair #1: pred 16 px (cols 6-7), gt 32, inter 16 -> IoU 0.5, not > 0.5: FP + FN; chair #2 exact: TP with IoU 1
     assert st[5].tolist() == [1.0, 1, 1, 1]
     assert st[7].tolist() == [0, 0, 0, 0]            # table lies entirely on void
-    r = M.pq_from_stats(st, classes=(1, 5, 7))
-    assert np.allclose(r["per_class"], [2 / 3, 1.0 / 2.0, 0.0])
+    r = M.pq_from_stats(st, classes=(5, 7, 1))  # the evaluator's order: things, then stuffs
+    assert np.allclose(r["per_class"], [1.0 / 2.0, 0.0, 2 / 3]) and abs(r["pq"] - (0.5 + 2 / 3) / 3) < 1e-12
     assert M.miou_stats(ps, gs)[1].tolist() == [32, 48] and M.miou_stats(ps, gs)[5].tolist() == [32, 48]
 
 
@@ -53,6 +53,95 @@ def test_accumulator_is_additive():
         acc.add_segmentation("context", ps2, pi, gs, gi)
         acc.add_segmentation("target", ps, pi, gs, gi)
     merged = M.MetricAccumulator.from_vectors(np.stack((a.to_vector(), b.to_vector())))
-    assert a.to_vector().shape == (2 + 12 * 21,)
+    assert a.to_vector().shape == (7 + 12 * 21,)
     assert merged.compute() == whole.compute()
     assert set(whole.compute()) >= {"psnr", "context_pq", "context_miou", "target_pq", "target_miou"}
+
+
+def test_panoptic_quality_void_and_unknown_categories():
+    """torchmetrics PanopticQuality(allow_unknown_preds_category=True) semantics on the cases the hand case above does not reach:
+    unknown predicted categories become void; a ground-truth segment mostly covered by void prediction is NOT a false negative; one
+    covered by less is; the IoU's union leaves out the part of the prediction on void ground truth; instance 0 of a thing is an
+    instance like any other; absent classes count as PQ 0 in the evaluator's mean."""
+    H, W = 10, 10
+    gs, gi = np.zeros((H, W), int), np.zeros((H, W), int)
+    gs[:5, :], gi[:5, :] = 5, 1                       # chair A: 50 px
+    gs[5:, :5], gi[5:, :5] = 7, 0                     # table, instance id 0: 25 px; the remaining 25 px are void
+    ps, pi = gs.copy(), gi.copy()
+    ps[:3, :] = 99                                    # 30 of chair A's 50 px predicted as an unknown category -> void: 60 % > 50 %
+    pi[:3, :] = 4
+    ps[5:, 5:8], pi[5:, 5:8] = 7, 0                   # the table prediction also covers 15 px of void ground truth
+    st = M.panoptic_stats(ps, pi, gs, gi)
+    # chair: prediction 20 px vs gt 50 px -> IoU 0.4, no match; FP (its void share is 0); the gt segment is 60 % void-predicted: no FN
+    assert st[5].tolist() == [0, 0, 1, 0]
+    # table: pred 40 px (25 on gt, 15 on void) -> union = 40 + 25 - 25 - 15 = 25 -> IoU 1.0
+    assert st[7].tolist() == [1.0, 1, 0, 0]
+    ps2 = ps.copy()
+    ps2[2, :] = 5                                     # now only 20 of 50 px are void-predicted: a false negative again
+    pi2 = pi.copy()
+    pi2[2, :] = 1
+    st2 = M.panoptic_stats(ps2, pi2, gs, gi)
+    assert st2[5].tolist() == [30 / 50, 1, 0, 0]      # ... and with 30 px the IoU is 0.6: matched
+    ps3 = ps.copy()
+    ps3[:3, :] = 5
+    pi3 = pi.copy()
+    pi3[:3, :] = 9                                    # a second chair instance takes the upper 30 px instead: 0.6 IoU -> it is the match
+    st3 = M.panoptic_stats(ps3, pi3, gs, gi)
+    assert st3[5].tolist() == [0.6, 1, 1, 0]
+    r = M.pq_from_stats(st, classes=M.THINGS + M.STUFFS)
+    assert len(r["per_class"]) == 20 and r["per_class"][M.THINGS.index(7)] == 1.0 and abs(r["pq"] - 1.0 / 20) < 1e-12
+    # unknown categories in the GROUND TRUTH are void as well (torchmetrics always allows them there)
+    gs4 = gs.copy()
+    gs4[:5, :] = 42
+    st4 = M.panoptic_stats(gs, gi, gs4, gi)
+    assert st4[5].tolist() == [0, 0, 0, 0] and st4[7].tolist() == [1.0, 1, 0, 0]  # the chair prediction lies on void entirely: no FP
+
+
+def test_ssim_definition():
+    """SSIM restated from torchmetrics' defaults (11-tap sigma-1.5 Gaussian, reflect pad 5, crop 5, k1 = 0.01, k2 = 0.03):
+    identical images -> 1; a constant offset on a flat image -> the closed form of the luminance term; symmetric; additive keys."""
+    rng = np.random.default_rng(0)
+    a = rng.random((32, 40, 3))
+    assert abs(M.ssim(a, a) - 1.0) < 1e-12
+    b = np.clip(a + rng.normal(0, 0.1, a.shape), 0, 1)
+    s_ab = M.ssim(a, b, data_range=1.0)
+    assert 0.0 < s_ab < 1.0 and abs(s_ab - M.ssim(b, a, data_range=1.0)) < 1e-12
+    # flat images x and y: variances 0 -> SSIM = (2xy + c1) / (x^2 + y^2 + c1) (c2 cancels) with data_range fixed
+    x, y = np.full((24, 24, 1), 0.4), np.full((24, 24, 1), 0.6)
+    c1 = (0.01 * 1.0) ** 2
+    assert abs(M.ssim(x, y, data_range=1.0) - (2 * 0.24 + c1) / (0.16 + 0.36 + c1)) < 1e-12
+    # window weights: normalised, symmetric, the published 11-tap values
+    g = M._gauss1d()
+    assert abs(g.sum() - 1) < 1e-15 and np.allclose(g, g[::-1]) and abs(g[5] / g[4] - np.exp(0.5 / 2.25)) < 1e-12
+    # a single bright pixel far from the border: the SSIM map differs from 1 only inside the 11 x 11 window around it
+    z = np.zeros((40, 40, 1))
+    z2 = z.copy()
+    z2[20, 20, 0] = 1.0
+    full = 1.0 - M.ssim(z, z2, data_range=1.0)
+    assert 0 < full < 121 / (30 * 30)
+    acc = M.MetricAccumulator()
+    sc = acc.add_render(a.astype(np.float32), b.astype(np.float32))
+    res = acc.compute()
+    assert set(sc) == {"psnr", "ssim"} and abs(res["ssim"] - sc["ssim"]) < 1e-15 and abs(res["psnr"] - sc["psnr"]) < 1e-12
+
+
+def test_depth_errors_scale_shift():
+    rng = np.random.default_rng(1)
+    gt = rng.uniform(0.5, 4.0, (20, 30))
+    gt[rng.random(gt.shape) < 0.2] = 0.0
+    pred = gt * 0.5 + 0.25                             # an exact affine image of the ground truth: both errors vanish after the fit
+    pred[gt == 0] = 7.0                                # (pixels without ground truth do not enter)
+    a, r = M.depth_errors(pred, gt)
+    assert a < 1e-12 and r < 1e-12
+    sc, sh = M.fit_scale_and_shift(pred, gt)
+    assert abs(sc - 2.0) < 1e-9 and abs(sh + 0.5) < 1e-9
+    noisy = pred + rng.normal(0, 0.02, pred.shape)
+    a2, r2 = M.depth_errors(noisy, gt)
+    assert 0 < a2 < 0.1 and 0 < r2 < 0.1
+    acc = M.MetricAccumulator()
+    acc.add_depth(noisy, gt)
+    acc.add_depth(pred, np.zeros_like(gt))             # no ground truth at all: skipped, not a NaN in the mean
+    res = acc.compute()
+    assert abs(res["absrel"] - a2) < 1e-15 and abs(res["rmse"] - r2) < 1e-15
+    merged = M.MetricAccumulator.from_vectors(np.stack((acc.to_vector(), acc.to_vector())))
+    assert abs(merged.compute()["rmse"] - r2) < 1e-12 and merged.n_depth == 2

@@ -253,6 +253,17 @@ def test_multiview_eight_views_and_batched_views_against_oracle():
         _report(f"multi B={B} V={V} class logits", seg.class_queries_logits, ref["class_queries_logits"], 5e-3, 5e-3, fails)
         _report(f"multi B={B} V={V} mask logits", seg.masks_queries_logits, ref["masks_queries_logits"], 5e-3, 5e-3, fails)
         assert not fails, fails
+        if max(_errs(seg.class_queries_logits, ref["class_queries_logits"])[0], _errs(seg.masks_queries_logits, ref["masks_queries_logits"])[0]) > 1e-3:
+            # above 1e-3 only through flipped attention-mask pixels: with the oracle's masks forced in, within 1e-3 (see test_parity_sweep)
+            model.use_graph = False
+            model.mask2former.forced_attn_masks = ref["attn_masks"]
+            with torch.no_grad():
+                seg_f = model(img.cuda(), K.cuda())[1]
+            model.mask2former.forced_attn_masks = None
+            model.use_graph = True
+            _report(f"multi B={B} V={V} class logits (oracle masks forced)", seg_f.class_queries_logits, ref["class_queries_logits"], 1e-3, 1e-3, fails)
+            _report(f"multi B={B} V={V} mask logits (oracle masks forced)", seg_f.masks_queries_logits, ref["masks_queries_logits"], 1e-3, 1e-3, fails)
+            assert not fails, fails
         assert torch.equal(outs[0][0].means, g.means) and torch.equal(outs[0][1].masks_queries_logits, seg.masks_queries_logits)
         agree = float((g.semantic_labels.cpu() == ref["semantic_labels"]).float().mean())
         print(f"[multi] B={B} V={V}: semantic label agreement {agree:.5f}, segments {[len(i) for i in outs[2][3]]}")
@@ -279,10 +290,10 @@ def test_inference_cli_writes_ply(tmp_path, precision):
     for i in (0, 1):
         Image.fromarray(np.ascontiguousarray(pair[i])).resize((320, 288)).save(tmp_path / f"v{i}.png")
     out = subprocess.run([sys.executable, os.path.join(root, "inference.py"), "--image_path1", str(tmp_path / "v0.png"), "--image_path2", str(tmp_path / "v1.png"),
-                          "--output_path", str(tmp_path / "out"), "--size", "128", "--precision", precision], capture_output=True, text=True, timeout=600, cwd=root)
+                          "--output_path", str(tmp_path / "out"), "--precision", precision], capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stdout + out.stderr
     v = read_ply_vertices(tmp_path / "out" / "output.ply")
-    assert len(v) == 2 * 128 * 128
+    assert len(v) == 2 * 256 * 256 == 131072  # the default --size 256 (reference inference.py:13-38: center crop + resize to 256): configs[0]
     names = v.dtype.names
     assert names[:9] == ("x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2") and "semantic_label" in names and "rot_3" in names
     assert np.isfinite(v["x"]).all() and np.isfinite(v["opacity"]).all() and (v["opacity"] >= 0).all() and (v["opacity"] <= 1).all()
@@ -432,7 +443,8 @@ def test_parity_sweep(case):
       * every Gaussian field <= 1e-3 max-normalised (north_star's bar; measured <= 8e-5);
       * Mask2Former class / mask logits <= 1e-3 on most inputs, and <= 5e-3 when one of the nine THRESHOLDED attention masks
         (sigmoid(mask) < 0.5, reference video_seg_decoder.py:1306-1308, 1461-1478) flips a borderline pixel between two fp32 evaluation
-        orders -- both logit tensors then move together (measured 1-3e-3 in 3 of 7 cases);
+        orders -- both logit tensors then move together (measured 1-3e-3 in 3 of 7 cases); in exactly those cases the test re-runs
+        the forward with the ORACLE's nine boolean masks forced in and demands <= 1e-3: the flipped pixels are the whole difference;
       * graph replay bit-identical to eager; label maps agree >= 0.995 (argmax over fp32 scores at segment borders)."""
     from oracle import siu3r_oracle as O
     from oracle import weights as OW
@@ -460,6 +472,17 @@ def test_parity_sweep(case):
     assert max(fields.values()) <= 1e-3, fields
     assert max(logits.values()) <= 5e-3, logits
     assert agree >= 0.995
+    if max(logits.values()) > 1e-3:
+        # above the north-star bar: then it must be a flipped pixel of a thresholded attention mask and nothing else -- with the
+        # oracle's nine boolean masks forced into the HIP run (eager) the same logits are within 1e-3
+        model.use_graph = False
+        model.mask2former.forced_attn_masks = ref["attn_masks"]
+        with torch.no_grad():
+            _, seg_f = model(img.cuda(), K.cuda())[:2]
+        model.mask2former.forced_attn_masks = None
+        forced = {"class": err(seg_f.class_queries_logits, ref["class_queries_logits"]), "mask": err(seg_f.masks_queries_logits, ref["masks_queries_logits"])}
+        print(f"[parity-sweep]   with the oracle's attention masks forced: class {forced['class']:.2e}, mask {forced['mask']:.2e}")
+        assert max(forced.values()) <= 1e-3, forced
     assert torch.equal(outs[0][0].means, gs.means) and torch.equal(outs[0][1].masks_queries_logits, seg.masks_queries_logits)
     del model
     torch.cuda.empty_cache()
