@@ -275,7 +275,9 @@ int siu3r_raster_sort(int V, int64_t G, uint32_t* keys_a, uint32_t* keys_b, int3
  * stats (the true count is stats[v][2]): size by a bound, enqueue the whole frame, check once afterwards. */
 int siu3r_raster_bin(const siu3r_raster_cam* cams_host, int V, int64_t G, const uint32_t* keys, const int32_t* ids, const int32_t* rect,
                      int32_t* bin_hist, int32_t* bin_tot, int32_t* bin_start, void* entries, int64_t cap_e, uint64_t* stats, void* stream);
-/* stage 4 (mode 0): image [V,3,H,W], depth [V,H,W], accumulated opacity [V,H,W], n_touched [V,G] i32 (NULL = not wanted) */
+/* stage 4 (mode 0): image [V,3,H,W], depth [V,H,W], accumulated opacity [V,H,W], n_touched [V,G] i32 (NULL = not wanted).
+ * A view whose entries overflowed cap_e (bin_start[v][NB] > cap_e) gets NaN in every output pixel: never a subtly wrong image, so the
+ * caller may read stats late (asynchronously) and repeat the call with a larger cap_e. */
 int siu3r_raster_composite_rgb(const siu3r_raster_cam* cams_host, int V, const void* cams_dev, int64_t G, const int32_t* bin_start,
                                const void* entries, int64_t cap_e, const float* rec, float* image, float* out_depth, float* out_alpha,
                                int32_t* n_touched, void* stream);

@@ -758,6 +758,12 @@ __global__ __launch_bounds__(256) void composite_rgb_kernel(const Cam* __restric
     }
     staged = 0;
   }
+  // A view whose coarse-bin entries did not fit cap_e lost its farthest splats: its outputs are POISONED (NaN) instead of being subtly
+  // wrong, so that a caller may defer reading the overflow counters (stats) to a convenient moment (raster.py: check_overflow="deferred")
+  if (inside && (int64_t)bin_start[v * (geo.NB + 1) + geo.NB] > cap_e) {
+    const float qnan = __int_as_float(0x7fc00000);
+    T = qnan, C0 = qnan, C1 = qnan, C2 = qnan, D = qnan, O = qnan;
+  }
   if (inside && K3) {
     const size_t hw = (size_t)c.width * c.height, pix = (size_t)py * c.width + px;
     float* o = image + ((size_t)v * hw + pix) * 3;

@@ -43,10 +43,11 @@ def get_projection_matrix(near, far, fov_x, fov_y) -> torch.Tensor:
 
 def render_cuda(extrinsics, intrinsics, near, far, image_shape, background_color, gaussian_means, gaussian_covariances,
                 gaussian_sh_coefficients, gaussian_opacities, use_sh: bool = True, cam_rot_delta=None, cam_trans_delta=None,
-                sh_band4: bool = False, return_aux: bool = False, entry_capacity=None):
+                sh_band4: bool = False, return_aux: bool = False, entry_capacity=None, check_overflow=True):
     """reference signature cuda_splatting.py:46-60 (batch = views).  Returns (images [b,3,h,w], depths [b,h,w]); return_aux adds the
     per-call outputs (radii, n_touched, opacity, binning state).  entry_capacity: optional size of the coarse-bin entry buffers (an
-    overflow of the default bound is detected and the call repeated with the exact size)."""
+    overflow of the default bound is detected and the call repeated with the exact size).  check_overflow: True (synchronous, as the
+    CUDA original's buffer resize is) / "deferred" / False: see raster._with_retry."""
     assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
     assert cam_rot_delta is None and cam_trans_delta is None, "pose gradients are training-only (out of scope)"
     b = extrinsics.shape[0]
@@ -81,7 +82,8 @@ def render_cuda(extrinsics, intrinsics, near, far, image_shape, background_color
         sh_i = gaussian_sh_coefficients[i0]
         planar = sh_i.shape[-1] == 25
         out = raster.rasterize_views_k2(cams, gaussian_means[i0], gaussian_covariances[i0], sh_i if planar else sh_i.permute(0, 2, 1).contiguous(),
-                                        gaussian_opacities[i0], want_n_touched=return_aux, entry_capacity=entry_capacity, sh_planar=planar)
+                                        gaussian_opacities[i0], want_n_touched=return_aux, entry_capacity=entry_capacity, sh_planar=planar,
+                                        check_overflow=check_overflow)
         images.append(out["image"])
         depths.append(out["depth"])
         aux.append(out)

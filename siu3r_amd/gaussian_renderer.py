@@ -15,11 +15,22 @@ from .ops import _gpu, _p, _stream
 
 
 class SplattingCUDA:
-    def __init__(self) -> None:
+    def __init__(self, deferred_overflow_check: bool = False) -> None:
+        """deferred_overflow_check False (default): the rasterizer's overflow counters are read right after every call (one device
+        synchronisation per call, transparent repeat with the exact buffer size), as the CUDA original's buffer resize does.  True: the
+        colour render does not synchronise; the counters are looked at when the next render starts or at check_pending() (an
+        overflowing view is NaN meanwhile, never subtly wrong; the needed buffer size is remembered and RasterOverflow asks for the call
+        to be repeated): a render loop then keeps the GPU busy while the host prepares the next call (bench.py's render legs)."""
         self.near = 0.1
         self.far = 100.0
         self.scale_factor = 1 / self.near
         self.background_color = torch.tensor([0.0, 0.0, 0.0], dtype=torch.float32)
+        self.deferred_overflow_check = deferred_overflow_check
+
+    @staticmethod
+    def check_pending():
+        """barrier of the deferred overflow checks: raises raster.RasterOverflow if a render since the last check overflowed"""
+        raster.check_pending(block=True)
 
     def forward(self, gaussians: Gaussians, extrinsics, intrinsics, image_shape, render_color: bool = True,
                 render_feature: bool = False, render_id: bool = False, render_qc_logits: bool = False,
@@ -43,7 +54,7 @@ class SplattingCUDA:
                     extrinsics[i], intr[i], torch.full((v,), near), torch.full((v,), far), image_shape,
                     self.background_color[None].repeat(v, 1), gaussians.means[i][None].expand(v, -1, -1),
                     gaussians.covariances[i][None].expand(v, -1, -1, -1), gaussians.harmonics[i][None].expand(v, -1, -1, -1),
-                    gaussians.opacities[i][None].expand(v, -1))
+                    gaussians.opacities[i][None].expand(v, -1), check_overflow="deferred" if self.deferred_overflow_check else True)
                 colors.append(c_i)
                 depths.append(d_i)
             color = torch.stack(colors).clamp_(0.0, 1.0)  # (:73) clamp is pure data conditioning on the output buffer

@@ -912,6 +912,8 @@ class VideoMask2FormerForVideoSegmentation:
 # whole model (model.py:31-389)
 # ==================================================================================================
 _PTS0_MAIN = os.environ.get("SIU3R_PTS0_MAIN", "0") == "1"
+_HEAD_MAP = os.environ.get("SIU3R_HEAD_MAP", "")
+_PTS0_OWN = os.environ.get("SIU3R_PTS0_OWN", "0") == "1"  # A/B: a fifth stream for the pts3d head of view 0 (needs GPU_MAX_HW_QUEUES >= 5 to overlap)
 _DEC_PER_LAYER = os.environ.get("SIU3R_DEC_PER_LAYER", "0") == "1"
 _PIPE_PTSR = int(os.environ.get("SIU3R_PIPE_PTSR", "0"))  # forward_async: the head stream (0 / 1) the pts3d head of views 1.. queues on
 
@@ -1257,16 +1259,23 @@ class SIU3RModel:
         # pts0 rides on the segmentation stream, behind Mask2Former: that chain ends ~2.5 ms after the heads start, and the head of view 0
         # then overlaps the other three instead of running alone after them (21.8 -> 20.9 ms body at B = 1; SIU3R_PTS0_MAIN=1 restores
         # the two pts3d heads back to back on the main stream)
-        pts0_stream = seg_stream if (par and not _PTS0_MAIN) else main
+        pts0_stream = (ctx.side_stream(4) if _PTS0_OWN else seg_stream) if (par and not _PTS0_MAIN) else main
         if pts0_stream is not main:
             pts0_stream.wait_stream(main)  # the decoder's outputs
         pipelined = pipelined and par
         ptsr_stream = hs[_PIPE_PTSR] if pipelined else main  # pipelined: behind one of the Gaussian heads instead of on the encoder's stream
-        for name, s_ in zip(("gs0", "gsr", "ptsr", "pts0"), hs + [ptsr_stream, pts0_stream]):
+        placement = list(zip(("gs0", "gsr", "ptsr", "pts0"), hs + [ptsr_stream, pts0_stream]))
+        if _HEAD_MAP and par:  # A/B: SIU3R_HEAD_MAP="0,1,m,s" = stream of gs0, gsr, ptsr, pts0 (0 / 1 head streams, m main, s segmentation), in launch order
+            pick = {"0": hs[0], "1": hs[1], "m": main, "s": seg_stream}
+            placement = [(n_, pick[k_]) for n_, k_ in zip(("gs0", "gsr", "ptsr", "pts0"), _HEAD_MAP.split(","))]
+            for _, s_ in placement:
+                if s_ is seg_stream:
+                    seg_stream.wait_stream(main)
+        for name, s_ in placement:
             with torch.cuda.stream(s_):
                 run(name, stages[name])
         tail_stream = hs[1] if pipelined else main
-        for s_ in hs + [seg_stream]:
+        for s_ in hs + [seg_stream, pts0_stream]:
             if s_ is not tail_stream:
                 tail_stream.wait_stream(s_)
         with torch.cuda.stream(tail_stream):

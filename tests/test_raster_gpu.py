@@ -196,6 +196,41 @@ def test_capacity_overflow_is_detected_and_retried():
     assert torch.equal(a["image"], b["image"]) and torch.equal(a["n_touched"], b["n_touched"])
 
 
+def test_deferred_overflow_check_poisons_and_reports():
+    """check_overflow="deferred": no synchronisation in the call; an overflowing view comes back as NaN (never subtly wrong), the next
+    deferred call / check_pending() raises RasterOverflow and remembers the needed capacity, and the repeated call equals the
+    synchronous result bit for bit.  SplattingCUDA(deferred_overflow_check=True) is the same mechanism behind the reference API."""
+    from siu3r_amd import raster
+
+    G, H, W = 4000, 96, 128
+    means, cov, opac, sh = random_scene(G, seed=11, scale=(0.05, 0.2))
+    k2 = [_k2_cam(H, W, seed=2), _k2_cam(H, W, seed=3)]
+    shs = sh.permute(0, 2, 1).contiguous().cuda()
+    a = (means.cuda(), raster.cov6_from_cov3x3(cov.cuda()), shs, opac.cuda())
+    raster.check_pending()
+    full = raster.rasterize_views_k2(k2, *a)
+    E = max(full["state"].totals(2))
+    ok = raster.rasterize_views_k2(k2, *a, check_overflow="deferred")
+    raster.check_pending()  # nothing overflowed: silent
+    assert torch.equal(ok["image"], full["image"]) and torch.equal(ok["n_touched"], full["n_touched"])
+    bad = raster.rasterize_views_k2(k2, *a, entry_capacity=E // 3, check_overflow="deferred")
+    assert len(raster._PENDING) == 1
+    torch.cuda.synchronize()
+    assert torch.isnan(bad["image"]).all() and torch.isnan(bad["depth"]).all() and torch.isnan(bad["opacity"]).all()
+    with pytest.raises(raster.RasterOverflow, match="deferred"):
+        raster.check_pending()
+    assert not raster._PENDING
+    again = raster.rasterize_views_k2(k2, *a, check_overflow="deferred")  # the remembered capacity covers the scene now
+    raster.check_pending()
+    assert again["state"]["cap_e"] >= E and torch.equal(again["image"], full["image"]) and torch.equal(again["depth"], full["depth"])
+    # the next deferred call is the implicit check point of the previous one
+    raster.rasterize_views_k2(k2, *a, entry_capacity=E // 3, check_overflow="deferred")
+    torch.cuda.synchronize()
+    with pytest.raises(raster.RasterOverflow):
+        raster.rasterize_views_k2(k2, *a, check_overflow="deferred")
+    raster.check_pending()
+
+
 def test_views_batched_equals_view_by_view():
     """V cameras in one call (blockIdx.y = view) == V single-view calls, bit for bit (K2 and K3)."""
     from siu3r_amd import raster
