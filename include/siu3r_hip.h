@@ -26,7 +26,7 @@ extern "C" {
 #define SIU3R_F64 3
 
 const char* siu3r_last_error(void);
-#define SIU3R_ABI_VERSION 4 /* 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
+#define SIU3R_ABI_VERSION 5 /* 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
 int siu3r_abi_version(void);
 
 /* ---- seam 1: curope.rope_2d(tokens, positions, base, fwd)
@@ -131,7 +131,8 @@ typedef struct {
 int siu3r_gemm_plan(const siu3r_gemm_params* p, siu3r_gemm_plan_t* out);
 /* tuning aid (tools/, tests): key 0 = process-wide default of siu3r_gemm_params.tile_cfg (SIU3R_TILE_*; also env SIU3R_GEMM_PP), key 1 =
  * 1 disables the skinny remainder-row launch, key 2 = 1 disables split-K, key 3 = 1 ignores the table of measured tile choices
- * (csrc/gemm_tuned.h; also env SIU3R_GEMM_NO_TUNED) so that every problem is priced by the cost model.  Not for concurrent use. */
+ * (csrc/gemm_tuned.h; also env SIU3R_GEMM_NO_TUNED) so that every problem is priced by the cost model, key 4 = 1 sends the remainder
+ * rows to the skinny launch whenever it is applicable (tests).  Not for concurrent use. */
 int siu3r_gemm_tune(int key, int value);
 
 /* ---- LayerNorm over the last dim (fp32 in, act-dtype out); reference: nn.LayerNorm call sites
@@ -267,9 +268,11 @@ int siu3r_raster_project(const siu3r_raster_cam* cams_host, int V, void* cams_de
                          int cov_stride, const float* opacities, const float* colors, int channels, int sh_planar, float* rec,
                          int32_t* radii, int32_t* rect, int32_t* tiles_touched, uint32_t* keys, uint64_t* stats, void* stream);
 /* stage 2: per view, stable LSD radix sort (4 x 8 bits) of keys_a [V,G] with the Gaussian index as payload; keys_b / ids_a / ids_b
- * [V,G] ping-pong buffers; rs_hist i32 [V,256,nchunks_sort], rs_tot i32 [V,256].  Result (depth, id)-ordered in keys_a / ids_a. */
+ * [V,G] ping-pong buffers; rs_hist i32 [V,256,nchunks_sort], rs_tot i32 [V,256]; stats: stage 1's counters (device).  Culled Gaussians
+ * (key 0xffffffff) leave the sort in its first pass: the result is the (depth, id)-ordered list of the n = stats[v][0] VISIBLE Gaussians in
+ * keys_a / ids_a [v][0, n); what lies behind is unspecified (stage 3 reads n from stats as well). */
 int siu3r_raster_sort(int V, int64_t G, uint32_t* keys_a, uint32_t* keys_b, int32_t* ids_a, int32_t* ids_b, int32_t* rs_hist,
-                      int32_t* rs_tot, void* stream);
+                      int32_t* rs_tot, const uint64_t* stats, void* stream);
 /* stage 3: depth-ordered coarse bins.  bin_hist i32 [V,NB,nchunks_bin], bin_tot i32 [V,NB], bin_start i32 [V,NB+1] (out),
  * entries: 8-byte records [V,cap_e] (Gaussian id, rect clipped to the bin).  Entries beyond cap_e are dropped and flagged in
  * stats (the true count is stats[v][2]): size by a bound, enqueue the whole frame, check once afterwards. */

@@ -83,7 +83,7 @@ class RasterCam(C.Structure):
 
 # name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/siu3r_hip.h.
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
-ABI_VERSION = 4  # SIU3R_ABI_VERSION of include/siu3r_hip.h these ctypes declarations mirror
+ABI_VERSION = 5  # SIU3R_ABI_VERSION of include/siu3r_hip.h these ctypes declarations mirror
 
 SIGNATURES = {
     "siu3r_last_error": [],
@@ -111,7 +111,7 @@ SIGNATURES = {
     "siu3r_split_bf16": [_P, _P, _P, _P, _L, _I, _I, _L, _P],
     "siu3r_raster_geometry": [_I, _I, _L, C.POINTER(C.c_int32)],
     "siu3r_raster_project": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P],
-    "siu3r_raster_sort": [_I, _L, _P, _P, _P, _P, _P, _P, _P],
+    "siu3r_raster_sort": [_I, _L, _P, _P, _P, _P, _P, _P, _P, _P],
     "siu3r_raster_bin": [C.POINTER(RasterCam), _I, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "siu3r_raster_composite_rgb": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _P],
     "siu3r_raster_tile_lists": [C.POINTER(RasterCam), _I, _P, _P, _L, _P, _P, _P, _L, _P, _P],

@@ -346,12 +346,14 @@ static int g_tile_default = getenv("SIU3R_GEMM_PP") ? atoi(getenv("SIU3R_GEMM_PP
 static int g_no_skinny = getenv("SIU3R_GEMM_NO_SKINNY") ? 1 : 0;
 static int g_no_splitk = getenv("SIU3R_NO_SPLITK") ? atoi(getenv("SIU3R_NO_SPLITK")) : 0;
 static int g_no_tuned = getenv("SIU3R_GEMM_NO_TUNED") ? 1 : 0;
+static int g_force_skinny = getenv("SIU3R_GEMM_FORCE_SKINNY") ? 1 : 0;  // tests: remainder rows go to the skinny launch whenever it is applicable
 static float g_bf16_pp_hurdle = getenv("SIU3R_GEMM_BF16_PP_HURDLE") ? (float)atof(getenv("SIU3R_GEMM_BF16_PP_HURDLE")) : 1.3f;
 extern "C" int siu3r_gemm_tune(int key, int value) {
   if (key == 0) g_tile_default = value;
   else if (key == 1) g_no_skinny = value;
   else if (key == 2) g_no_splitk = value;
   else if (key == 3) g_no_tuned = value;
+  else if (key == 4) g_force_skinny = value;
   else return 1;
   return 0;
 }
@@ -410,7 +412,7 @@ void plan(const siu3r_gemm_params& p, siu3r_gemm_plan_t& pl) {
     // that row of tiles would cost another round of workgroups (both options are priced)
     const int rem = p.m % c.bm;
     const bool skinny_ok = is_pp && !g_no_skinny && p.a_mode == 0 && rem != 0 && rem <= 32 && p.n >= 64;
-    for (int sk = 0; sk <= (skinny_ok ? 1 : 0); ++sk) {
+    for (int sk = (skinny_ok && g_force_skinny) ? 1 : 0; sk <= (skinny_ok ? 1 : 0); ++sk) {
       const int skinny = sk ? rem : 0;
       const int mrows = p.m - skinny;
       const int64_t tiles = (int64_t)((mrows + c.bm - 1) / c.bm) * ((p.n + c.bn - 1) / c.bn) * Z;
@@ -428,7 +430,8 @@ void plan(const siu3r_gemm_params& p, siu3r_gemm_plan_t& pl) {
         float t = rounds * ((x3 ? c.t0_x3 : c.t0_bf) + (float)((ksteps + S - 1) / S) * (x3 ? c.t_step_x3 : c.t_step_bf));
         if (mrows == 0) t = 0.f;
         // skinny launch: a kernel boundary plus its K loop (its fragment-shaped loads are address-bound: ~9 us per 1024 k in bf16x3)
-        if (skinny) t += 3.5f + (x3 ? 9.3f : 5.0f) * (float)p.kpad / 1024.f;
+        // (<= 4 rows and 2048 <= kpad <= 4096: the matrix-vector kernel of gemm_pp.hip, 26 us at K = 4096 in bf16x3)
+        if (skinny) t += (skinny <= 4 && p.kpad >= 2048 && p.kpad <= 4096) ? 5.0f + (x3 ? 5.0f : 3.0f) * (float)p.kpad / 1024.f : 3.5f + (x3 ? 9.3f : 5.0f) * (float)p.kpad / 1024.f;
         if (S > 1) t += 2.5f + (float)(2.0 * S * tiles * c.bm * c.bn * 4.0 / 5.0e6);
         // bf16: the 128 x 64 LDS-DMA kernel is already within a few per cent of the best tile on almost every shape of the network and
         // shares a CU with the other chains' kernels; end to end the ping-pong tiles LOSE 7-11 % there (same-box A/B of bench.py at

@@ -125,6 +125,131 @@ __global__ __launch_bounds__(512, 2) void gemm_skinny_kernel(const siu3r_gemm_pa
 #endif
 }
 
+
+// ---- the same remainder rows when there are at most FOUR of them (M = 2 x 1025 = 8 x 256 + 2; 1025 = 4 x 256 + 1 per decoder side) ------------
+// (used for long K only, 2048 <= kpad <= 4096: see the launcher.)
+// A matrix-vector product has no use for MFMA: the W panel is the only traffic, and the fragment-shaped loads of the kernel above fetch
+// it as 64 scattered 16-byte pieces per instruction (12.8 us at K = 1024, ~40 at K = 4096 -- which kept fc2 on a ninth row of tiles).  Here a wave streams each W row in fully coalesced 1 KiB loads (8 columns' worth of one chunk in flight behind the 8 being
+// consumed), the <= 4 A rows sit in LDS as fp32 and are read once per chunk for all 8 columns, products are plain fp32 FMAs of the
+// exact operands (bf16x3: a * w_hi and a * w_lo accumulate separately -- no rounding of A at all), a lane-level partial sum per
+// (column, row) is reduced across the wave at the end, and wave 0 hands the 64-column block to the common row pass in accumulator layout.
+constexpr int GV_ROWS = 4, GV_KMAX = 4096;
+template <bool X3, bool LNF>
+__global__ __launch_bounds__(512) void gemm_skinny_gemv_kernel(const siu3r_gemm_params p) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int ESZ = X3 ? 4 : 2;
+  __shared__ __attribute__((aligned(16))) float s_a[GV_ROWS * GV_KMAX];
+  __shared__ __attribute__((aligned(16))) float s_res[GV_ROWS][64];
+  __shared__ __attribute__((aligned(16))) unsigned char s_stage[siu3r_epi_pp::WAVE_STAGE_BYTES];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int M = p.m, N = p.n, K = p.k, kpad = p.kpad;
+  const int row0 = p.m_main, R = M - row0, col0 = blockIdx.x * 64, z = blockIdx.z;
+  const siu3r_zoff zof = siu3r_batch_offsets(p, z);
+  const unsigned char* Ab = (const unsigned char*)p.a + zof.a * ESZ;
+  const unsigned char* Wb = X3 ? (const unsigned char*)p.w_x3 + zof.w * 4 : (const unsigned char*)p.w_hi + zof.w * 2;
+  const int WROW = X3 ? kpad * 4 : kpad * 2;
+  // A rows -> LDS (fp32, zero beyond K)
+  for (int i = t; i < R * (kpad / 4); i += 512) {
+    const int r = i / (kpad / 4), k = (i - r * (kpad / 4)) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < K) {  // K % 4 == 0 (launcher)
+      const unsigned char* src = Ab + ((int64_t)(row0 + r) * p.lda + k) * ESZ;
+      if (X3) {
+        v = *(const float4*)src;
+      } else {
+        const uint2 u = *(const uint2*)src;
+        v = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+      }
+    }
+    *(float4*)(s_a + r * kpad + k) = v;
+  }
+  __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, (short)0, (int)((int64_t)N * WROW), RSRC_FLAGS);
+  const int nchunk = (WROW + 1023) / 1024;
+  unsigned voff[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    int n = col0 + wave * 8 + c;
+    if (n > N - 1) n = N - 1;
+    voff[c] = (unsigned)((int64_t)n * WROW + lane * 16);
+  }
+  // a lane's 16 bytes of a chunk: bf16x3 -> 8 values of ONE plane (hi or lo) of k0 .. k0 + 8 in the [hi 32 | lo 32] segment; bf16 -> 8 consecutive k
+  const int k_lane = X3 ? (lane >> 3) * 32 + (lane & 3) * 8 : lane * 8;
+  constexpr int K_PER_CHUNK = X3 ? 256 : 512;
+  float acc[8][GV_ROWS];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < GV_ROWS; ++r) acc[c][r] = 0.f;
+  auto issue = [&](u32x4 (&w)[8], int ch) {
+    const bool in = ch * 1024 + lane * 16 < WROW;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) w[c] = __builtin_amdgcn_raw_buffer_load_b128(rW, in ? voff[c] : OOB, ch * 1024, 0);
+  };
+  __syncthreads();
+  auto consume = [&](const u32x4 (&w)[8], int ch) {
+    int k0 = ch * K_PER_CHUNK + k_lane;
+    if (k0 > kpad - 8) k0 = 0;  // (a lane beyond the row end loaded zeros)
+    float a[GV_ROWS][8];
+#pragma unroll
+    for (int r = 0; r < GV_ROWS; ++r) {
+      if (r < R) {
+        const float4 x = *(const float4*)(s_a + r * kpad + k0), y = *(const float4*)(s_a + r * kpad + k0 + 4);
+        a[r][0] = x.x; a[r][1] = x.y; a[r][2] = x.z; a[r][3] = x.w; a[r][4] = y.x; a[r][5] = y.y; a[r][6] = y.z; a[r][7] = y.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[r][e] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float wv[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        wv[2 * e] = __uint_as_float(w[c][e] << 16);
+        wv[2 * e + 1] = __uint_as_float(w[c][e] & 0xffff0000u);
+      }
+#pragma unroll
+      for (int r = 0; r < GV_ROWS; ++r)
+        if (r < R) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[c][r] = __builtin_fmaf(a[r][e], wv[e], acc[c][r]);
+        }
+    }
+  };
+  u32x4 w0[8], w1[8];
+  issue(w0, 0);
+  for (int ch = 0; ch < nchunk; ch += 2) {
+    if (ch + 1 < nchunk) issue(w1, ch + 1);
+    consume(w0, ch);
+    if (ch + 2 < nchunk) issue(w0, ch + 2);
+    if (ch + 1 < nchunk) consume(w1, ch + 1);
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < GV_ROWS; ++r) {
+      float v = acc[c][r];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) s_res[r][wave * 8 + c] = v;
+    }
+  __syncthreads();
+  if (wave != 0) return;
+  // accumulator layout of a 32 x 32 block: lane -> column lane % 32, register i -> row 8 (i / 4) + 4 (lane / 32) + i % 4
+  f32x16 out[1][2];
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = 8 * (i >> 2) + 4 * lh + (i & 3);
+      out[0][j][i] = row < GV_ROWS ? s_res[row][j * 32 + l31] : 0.f;
+    }
+  siu3r_epi_pp::wave_rows<1, 2, LNF>(p, out, (float*)s_stage, row0, col0, M, z, lane);
+#endif
+}
+
 }  // namespace siu3r_gemm_pp
 
 #define SIU3R_PP_DECL(T) void siu3r_gemm_pp_go_##T(const siu3r_gemm_params& p, int mode, bool lnf, dim3 grid, hipStream_t s)
@@ -209,6 +334,20 @@ int siu3r_gemm_skinny_launch(const siu3r_gemm_params& p, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const bool lnf = p.ln_stats != nullptr;
 #ifndef SIU3R_PP_MINI
+  // at most four rows: the matrix-vector kernel (16-byte aligned A rows, K % 4 == 0, the rows fit its LDS)
+  const int rows = p.m - p.m_main, esz = x3 ? 4 : 2;
+  static const bool no_gemv = getenv("SIU3R_GEMM_NO_GEMV") != nullptr;
+  // (measured, tools/mb_skinny.py: the MFMA kernel above wins at K = 1024 -- 12.7 vs 14.7 us, both mostly fixed cost -- and loses at
+  // K = 4096: 37 vs 26 us)
+  if (!no_gemv && rows >= 1 && rows <= GV_ROWS && p.kpad >= 2048 && p.kpad <= GV_KMAX && p.k % 4 == 0 && ((int64_t)p.lda * esz) % 16 == 0 &&
+      ((uintptr_t)p.a % 16) == 0 && (p.sa * esz) % 16 == 0 && (p.sa_i * esz) % 16 == 0) {
+    if (x3 && lnf) hipLaunchKernelGGL((gemm_skinny_gemv_kernel<true, true>), grid, block, 0, s, p);
+    else if (x3) hipLaunchKernelGGL((gemm_skinny_gemv_kernel<true, false>), grid, block, 0, s, p);
+    else if (lnf) hipLaunchKernelGGL((gemm_skinny_gemv_kernel<false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_skinny_gemv_kernel<false, false>), grid, block, 0, s, p);
+    SIU3R_LAUNCH_CHECK("siu3r_gemm(skinny gemv)");
+    return 0;
+  }
   if (x3 && lnf) hipLaunchKernelGGL((gemm_skinny_kernel<true, true>), grid, block, 0, s, p);
   else if (x3) hipLaunchKernelGGL((gemm_skinny_kernel<true, false>), grid, block, 0, s, p);
   else if (lnf) hipLaunchKernelGGL((gemm_skinny_kernel<false, true>), grid, block, 0, s, p);

@@ -343,16 +343,28 @@ __global__ __launch_bounds__(256) void project_kernel(const Cam* __restrict__ ca
 
 // ---- stable LSD radix sort of the depth keys (per view) --------------------------------------------------------
 // hist[(v * 256 + digit) * nchunks + chunk]: digit-major, so that the scan below reads rows
-__global__ __launch_bounds__(256) void rs_hist_kernel(const uint32_t* __restrict__ keys, int32_t* __restrict__ hist, int64_t G, int shift, int nchunks) {
+// Culled Gaussians (key 0xffffffff) leave the sort in pass 0: they are neither counted nor scattered, so that passes 1-3 (and the
+// binning) only see the n = stats[v][ST_GV] visible ones, compact at the front -- 46 % fewer keys on the 2 M-Gaussian stress frame.
+// nvalid == nullptr: pass 0 (all G keys, culled ones skipped); else the first nvalid[v * ST_N + ST_GV] keys.
+__global__ __launch_bounds__(256) void rs_hist_kernel(const uint32_t* __restrict__ keys, int32_t* __restrict__ hist, int64_t G, int shift, int nchunks,
+                                                      const unsigned long long* __restrict__ nvalid) {
   __shared__ int h[256];
   const int v = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+  const int64_t n = nvalid ? (int64_t)nvalid[v * ST_N + ST_GV] : G;
+  if ((int64_t)chunk * RS_CH >= n) {  // (uniform) nothing of this chunk takes part: its histogram column is zero
+    hist[((int64_t)v * 256 + t) * nchunks + chunk] = 0;
+    return;
+  }
   h[t] = 0;
   __syncthreads();
   const uint32_t* kp = keys + (int64_t)v * G;
 #pragma unroll
   for (int i = 0; i < RS_ITEMS; ++i) {
     const int64_t idx = (int64_t)chunk * RS_CH + i * 256 + t;
-    if (idx < G) atomicAdd(&h[(kp[idx] >> shift) & 255u], 1);
+    if (idx < n) {
+      const uint32_t k = kp[idx];
+      if (k != 0xffffffffu) atomicAdd(&h[(k >> shift) & 255u], 1);
+    }
   }
   __syncthreads();
   hist[((int64_t)v * 256 + t) * nchunks + chunk] = h[t];
@@ -413,19 +425,34 @@ __device__ __forceinline__ int block_excl_scan(int x, int* s_w, int* tot) {
   return off + incl - x;
 }
 
+// Stable scatter of one chunk (RS_CH keys, item order = (i, thread)) with a handful of workgroup barriers instead of three per item:
+//   A  every wave ranks its 64 keys of item slice i among themselves -- the lanes that hold the same digit are found with 8 ballots
+//      (one per digit bit), rank = popcount of that set below the lane -- and the set's first lane notes its size in cnt[i][wave][digit];
+//   B  thread d walks the 64 (i, wave) counts of digit d in item order: exclusive offsets of every (slice, wave) group inside the digit's
+//      run of this chunk;
+//   C  local position = digits below in this chunk + group offset + rank: the chunk is sorted inside LDS;
+//   D  written out in local order: global position = start of the digit in the output (digits below + this digit's keys in earlier
+//      chunks) + index inside the chunk's run of the digit.
 __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in, const int32_t* __restrict__ ids_in,
                                                          uint32_t* __restrict__ keys_out, int32_t* __restrict__ ids_out,
                                                          const int32_t* __restrict__ hist, const int32_t* __restrict__ tot, int64_t G, int shift,
-                                                         int nchunks) {
-  __shared__ __attribute__((aligned(16))) uint32_t M[256 * 8];
-  __shared__ int base[256];
-  __shared__ int s_w[4];
-  const int v = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+                                                         int nchunks, const unsigned long long* __restrict__ nvalid) {
+  __shared__ __attribute__((aligned(16))) unsigned char cnt[RS_ITEMS * 4 * 256];   // [i][wave][digit], <= 64 each
+  __shared__ unsigned short off[RS_ITEMS * 4 * 256];                              // [i][wave][digit], < RS_CH
+  __shared__ int base[256], lbeg[256];
+  __shared__ int32_t sid[RS_CH];
+  __shared__ int s_w[4], s_last;
+  const int v = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t n = nvalid ? (int64_t)nvalid[v * ST_N + ST_GV] : G;
+  if ((int64_t)chunk * RS_CH >= n) return;  // (uniform)
   // start of digit t in the output = digits below + this digit's keys in earlier chunks
   const int ex = block_excl_scan(tot[v * 256 + t], s_w, nullptr);
   base[t] = ex + hist[((int64_t)v * 256 + t) * nchunks + chunk];
+  {
+    uint4* z = (uint4*)cnt;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) M[t * 8 + i] = 0;
+    for (int i = 0; i < RS_ITEMS * 4 * 256 / 16 / 256; ++i) z[i * 256 + t] = make_uint4(0, 0, 0, 0);
+  }
   const uint32_t* kp = keys_in + (int64_t)v * G;
   const int32_t* ip = ids_in ? ids_in + (int64_t)v * G : nullptr;
   uint32_t key[RS_ITEMS];
@@ -433,32 +460,67 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint32_t* __restr
 #pragma unroll
   for (int i = 0; i < RS_ITEMS; ++i) {
     const int64_t idx = (int64_t)chunk * RS_CH + i * 256 + t;
-    key[i] = idx < G ? kp[idx] : 0u;
-    id[i] = idx < G ? (ip ? ip[idx] : (int32_t)idx) : 0;
+    key[i] = idx < n ? kp[idx] : 0xffffffffu;
+    id[i] = idx < n ? (ip ? ip[idx] : (int32_t)idx) : 0;
   }
   __syncthreads();
-  const int wi = t >> 5;
-  const uint32_t bit = 1u << (t & 31);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  unsigned char rank[RS_ITEMS];
 #pragma unroll
   for (int i = 0; i < RS_ITEMS; ++i) {
-    const int64_t idx = (int64_t)chunk * RS_CH + i * 256 + t;
-    const bool ok = idx < G;
-    const int d = (key[i] >> shift) & 255u;
-    if (ok) atomicOr(&M[d * 8 + wi], bit);
-    __syncthreads();
-    int rank = 0, total = 0;
-    if (ok) {
-      row_rank(&M[d * 8], t, rank, total);
-      const int64_t pos = (int64_t)v * G + base[d] + rank;
-      keys_out[pos] = key[i];
-      ids_out[pos] = id[i];
+    const bool ok = key[i] != 0xffffffffu;  // (beyond n, or culled: pass 0 drops those)
+    const uint32_t d = (key[i] >> shift) & 255u;
+    unsigned long long m = __ballot(ok);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
     }
-    __syncthreads();
-    if (ok) {
-      if (rank == 0) base[d] += total;
-      M[d * 8 + wi] = 0;
+    const int r = __popcll(m & below);
+    rank[i] = (unsigned char)r;
+    if (ok && r == 0) cnt[(i * 4 + wave) * 256 + d] = (unsigned char)__popcll(m);
+  }
+  __syncthreads();
+  int run_total = 0;
+  {
+    int run = 0;
+#pragma unroll 8
+    for (int g = 0; g < RS_ITEMS * 4; ++g) {
+      off[g * 256 + t] = (unsigned short)run;
+      run += cnt[g * 256 + t];
     }
-    __syncthreads();
+    run_total = run;  // this chunk's count of digit t
+  }
+  if (t == 255) s_last = run_total;
+  // D: the chunk is first sorted INSIDE LDS (local position = digits below in this chunk + group offset + rank), then written out in
+  // local order: consecutive threads then write consecutive addresses of a digit's run (a wave's store touches a handful of lines
+  // instead of up to 64: the direct scatter was bound by line requests, not by bytes)
+  const int lstart = block_excl_scan(run_total, s_w, nullptr);  // (its barriers also order B's reads of cnt before the reuse below)
+  lbeg[t] = lstart;
+  __syncthreads();
+  uint32_t* skey = (uint32_t*)cnt;  // 16 KiB: the counts are no longer needed
+#pragma unroll
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    if (key[i] != 0xffffffffu) {
+      const uint32_t d = (key[i] >> shift) & 255u;
+      const int lp = lbeg[d] + off[(i * 4 + wave) * 256 + d] + rank[i];
+      skey[lp] = key[i];
+      sid[lp] = id[i];
+    }
+  }
+  __syncthreads();
+  const int nloc = lbeg[255] + s_last;  // keys of this chunk that take part
+#pragma unroll
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const int j = i * 256 + t;
+    if (j < nloc) {
+      const uint32_t k = skey[j];
+      const uint32_t d = (k >> shift) & 255u;
+      const int64_t pos = (int64_t)v * G + base[d] + (j - lbeg[d]);
+      keys_out[pos] = k;
+      ids_out[pos] = sid[j];
+    }
   }
 }
 
@@ -471,9 +533,15 @@ __device__ __forceinline__ void coarse_range(int4 r, int cb, int& cx0, int& cy0,
 }
 
 __global__ __launch_bounds__(256) void bin_count_kernel(Geo geo, const uint32_t* __restrict__ keys, const int32_t* __restrict__ ids,
-                                                        const int32_t* __restrict__ rect, int32_t* __restrict__ bin_hist, int64_t G, int nchunks) {
+                                                        const int32_t* __restrict__ rect, int32_t* __restrict__ bin_hist, int64_t G, int nchunks,
+                                                        const unsigned long long* __restrict__ stats) {
   __shared__ int h[NB_MAX];
   const int v = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+  const int64_t n = (int64_t)stats[v * ST_N + ST_GV];  // the sorted arrays hold the visible Gaussians, compact, in [0, n)
+  if ((int64_t)chunk * BN_CH >= n) {  // (uniform)
+    for (int b = t; b < geo.NB; b += 256) bin_hist[((int64_t)v * geo.NB + b) * nchunks + chunk] = 0;
+    return;
+  }
   for (int b = t; b < geo.NB; b += 256) h[b] = 0;
   __syncthreads();
   const uint32_t* kp = keys + (int64_t)v * G;
@@ -481,7 +549,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(Geo geo, const uint32_t*
 #pragma unroll
   for (int i = 0; i < BN_ITEMS; ++i) {
     const int64_t idx = (int64_t)chunk * BN_CH + i * 256 + t;
-    if (idx < G && kp[idx] != 0xffffffffu) {
+    if (idx < n) {
       const int4 r = *(const int4*)(rect + 4 * ((int64_t)v * G + ip[idx]));
       int cx0, cy0, cx1, cy1;
       coarse_range(r, geo.cb, cx0, cy0, cx1, cy1);
@@ -531,16 +599,17 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(Geo geo, const uint32_
     stats[v * ST_N + ST_E] = (unsigned long long)total_e;
     if (total_e > cap_e) stats[v * ST_N + ST_FLAGS] = 1ull;
   }
+  const int64_t n = (int64_t)stats[v * ST_N + ST_GV];  // the sorted arrays hold the visible Gaussians, compact, in [0, n)
+  if ((int64_t)chunk * BN_CH >= n) return;            // (uniform; chunk 0 has written bin_start and the totals above)
   for (int i = t; i < NB * 8; i += 256) M[i] = 0;
   __syncthreads();
-  const uint32_t* kp = keys + (int64_t)v * G;
   const int32_t* ip = ids + (int64_t)v * G;
   const int wi = t >> 5;
   const uint32_t bit = 1u << (t & 31);
   const int cb = geo.cb, nbx = geo.nbx;
   for (int i = 0; i < BN_ITEMS; ++i) {
     const int64_t idx = (int64_t)chunk * BN_CH + i * 256 + t;
-    const bool ok = idx < G && kp[idx] != 0xffffffffu;
+    const bool ok = idx < n;
     int id = 0, cx0 = 0, cy0 = 0, cx1 = -1, cy1 = -1;
     int4 r = make_int4(0, 0, 0, 0);
     if (ok) {
@@ -1100,10 +1169,10 @@ extern "C" int siu3r_raster_project(const siu3r_raster_cam* cams_host, int V, vo
 }
 
 extern "C" int siu3r_raster_sort(int V, int64_t G, uint32_t* keys_a, uint32_t* keys_b, int32_t* ids_a, int32_t* ids_b, int32_t* rs_hist,
-                                 int32_t* rs_tot, void* stream) {
+                                 int32_t* rs_tot, const uint64_t* stats, void* stream) {
   SIU3R_CHECK(V >= 1 && G >= 0, "raster_sort: bad sizes");
   if (G == 0) return 0;
-  SIU3R_CHECK(keys_a && keys_b && ids_a && ids_b && rs_hist && rs_tot, "raster_sort: null pointer");
+  SIU3R_CHECK(keys_a && keys_b && ids_a && ids_b && rs_hist && rs_tot && stats, "raster_sort: null pointer");
   hipStream_t s = (hipStream_t)stream;
   const int nchunks = (int)cdiv64(G, RS_CH);
   for (int pass = 0; pass < 4; ++pass) {
@@ -1111,9 +1180,10 @@ extern "C" int siu3r_raster_sort(int V, int64_t G, uint32_t* keys_a, uint32_t* k
     uint32_t* kout = (pass & 1) ? keys_a : keys_b;
     const int32_t* iin = pass == 0 ? nullptr : ((pass & 1) ? ids_b : ids_a);  // pass 0: the payload is the index itself
     int32_t* iout = (pass & 1) ? ids_a : ids_b;
-    hipLaunchKernelGGL(rs_hist_kernel, dim3(nchunks, V), dim3(256), 0, s, kin, rs_hist, G, pass * 8, nchunks);
+    const unsigned long long* nv = pass == 0 ? nullptr : (const unsigned long long*)stats;  // pass 0 drops the culled keys: n visible ones remain
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(nchunks, V), dim3(256), 0, s, kin, rs_hist, G, pass * 8, nchunks, nv);
     hipLaunchKernelGGL(row_scan_kernel, dim3(64, V), dim3(256), 0, s, rs_hist, rs_tot, 256, nchunks);
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3(nchunks, V), dim3(256), 0, s, kin, iin, kout, iout, rs_hist, rs_tot, G, pass * 8, nchunks);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(nchunks, V), dim3(256), 0, s, kin, iin, kout, iout, rs_hist, rs_tot, G, pass * 8, nchunks, nv);
   }
   SIU3R_LAUNCH_CHECK("siu3r_raster_sort");
   return 0;  // four passes: the sorted keys / ids are back in keys_a / ids_a
@@ -1136,7 +1206,7 @@ extern "C" int siu3r_raster_bin(const siu3r_raster_cam* cams_host, int V, int64_
     }
     return 0;
   }
-  hipLaunchKernelGGL(bin_count_kernel, dim3(nchunks, V), dim3(256), 0, s, geo, keys, ids, rect, bin_hist, G, nchunks);
+  hipLaunchKernelGGL(bin_count_kernel, dim3(nchunks, V), dim3(256), 0, s, geo, keys, ids, rect, bin_hist, G, nchunks, (const unsigned long long*)stats);
   hipLaunchKernelGGL(row_scan_kernel, dim3((geo.NB + 3) / 4, V), dim3(256), 0, s, bin_hist, bin_tot, geo.NB, nchunks);
   hipLaunchKernelGGL(bin_scatter_kernel, dim3(nchunks, V), dim3(256), (size_t)geo.NB * 40, s, geo, keys, ids, rect, bin_hist, bin_tot, bin_start,
                      (uint2*)entries, cap_e, (unsigned long long*)stats, G, nchunks);

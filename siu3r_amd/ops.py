@@ -270,7 +270,7 @@ def set_plan_log(log: Optional[list]):
 
 
 def gemm_tune(key: int, value: int):
-    """siu3r_gemm_tune: 0 = default tile_cfg (0 auto, -1 128x64 family, 1..3 ping-pong 256x256 / 256x128 / 128x128), 1 = no skinny rows, 2 = no split-K, 3 = ignore the measured-choice table"""
+    """siu3r_gemm_tune: 0 = default tile_cfg (0 auto, -1 128x64 family, 1..3 ping-pong 256x256 / 256x128 / 128x128), 1 = no skinny rows, 2 = no split-K, 3 = ignore the measured-choice table, 4 = skinny rows whenever applicable"""
     check(_lib.lib().siu3r_gemm_tune(key, value))
 
 

@@ -195,7 +195,7 @@ def _project_sort_bin(cams: Sequence[RasterCam], means, cov, opac, colors, chann
                                    int(bool(sh_planar)), _p(st["rec"]), _p(st["radii"]), _p(st["rect"]), _p(st["tiles_touched_all"]),
                                    _p(st["keys"]), _p(st["stats"]), _stream()))
     rs_hist, rs_tot = i32(V, 256, geo["nchunks_sort"]), i32(V, 256)
-    check(lib.siu3r_raster_sort(V, G, _p(st["keys"]), _p(st["keys_b"]), _p(st["sorted_ids"]), _p(st["ids_b"]), _p(rs_hist), _p(rs_tot), _stream()))
+    check(lib.siu3r_raster_sort(V, G, _p(st["keys"]), _p(st["keys_b"]), _p(st["sorted_ids"]), _p(st["ids_b"]), _p(rs_hist), _p(rs_tot), _p(st["stats"]), _stream()))
     bin_hist, bin_tot = i32(V, geo["NB"], geo["nchunks_bin"]), i32(V, geo["NB"])
     st["bin_start"] = i32(V, geo["NB"] + 1)
     st["entries"] = torch.empty((V, cap_e, 2), dtype=torch.int32, device=dev)

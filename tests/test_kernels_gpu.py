@@ -800,6 +800,58 @@ def test_gemm_stub_row_tiles(mode, rows):
 
 
 @pytest.mark.parametrize("mode", [MODES[0], MODES[2]], ids=["bf16", "bf16x3"])
+@pytest.mark.parametrize("rows", [1, 2, 4, 7], ids=["r1", "r2", "r4", "r7"])
+def test_gemm_skinny_remainder_rows(mode, rows):
+    """The last rows of a dense problem on the skinny launch (forced: siu3r_gemm_tune key 4), <= 4 rows on the matrix-vector kernel and
+    more on the MFMA one, through every epilogue feature the network sends there: bias + GELU + residual, K that is not a multiple of
+    the chunk (K = 1000 -> kpad 1024, K = 4096 = 16 chunks), N that is not a multiple of 64, a batched launch with folded LayerNorm +
+    statistics out, RoPE on the output.  The tiled rows of the same launch must be untouched by the remainder launch."""
+    from oracle import siu3r_oracle as O
+
+    ops = _ops()
+    name, adt, split, tol = mode
+    ops.gemm_tune(4, 1)
+    ops.gemm_tune(0, 2)  # the 256 x 128 ping-pong tile (the bf16 mode would otherwise stay on the 128 x 64 family, which has no skinny launch)
+    try:
+        log = []
+        ops.set_plan_log(log)
+        for (M0, N, K) in ((256, 200, 1000), (256, 128, 4096), (512, 1024, 768)):
+            M = M0 + rows
+            a, w, b, r = gen(M, K, seed=91), gen(N, K, seed=92, scale=0.1), gen(N, seed=93), gen(M, N, seed=94)
+            pw = ops.pack_linear(w.cuda(), b.cuda(), split)
+            out = ops.linear(a.cuda().to(adt), pw, out_dtype=torch.float32, act=ops.ACT_GELU, residual=r.cuda())
+            check(f"skinny[{name}] r={rows} {M}x{N}x{K} gelu+residual", out, F.gelu(a.to(adt).float() @ w.t() + b) + r, tol)
+        assert all(pl.skinny_rows == rows for pl in log), [(pl.tile_cfg, pl.skinny_rows) for pl in log]
+        ops.set_plan_log(None)
+        # batched tokens [Z, 256 + rows, C]: producer with statistics out, consumer with the folded LayerNorm and RoPE
+        Z, Nt, C, H, D = 2, 256 + rows, 192, 2, 64
+        x0 = gen(Z, Nt, 96, seed=95)
+        wp, bp = gen(C, 96, seed=96, scale=0.5), gen(C, seed=97) + 2.0
+        x = torch.empty(Z, Nt, C, device="cuda")
+        xb = torch.empty(Z, Nt, C, device="cuda", dtype=torch.bfloat16)
+        st = ops.RowStats(x)
+        ops.linear(x0.cuda().to(adt), ops.pack_linear(wp.cuda(), bp.cuda(), split), out=x, stats_out=st, aux_out=xb)
+        check(f"skinny[{name}] r={rows} producer", x, x0.to(adt).float() @ wp.t() + bp, tol)
+        stats_ref = x.view(Z * Nt, C // 64, 64)
+        check(f"skinny[{name}] r={rows} row statistics (means)", st.buf[..., 0], stats_ref.mean(-1), 1e-5)
+        gamma, beta = 1.0 + 0.3 * gen(C, seed=98), gen(C, seed=99)
+        N3 = H * D
+        w3, b3 = gen(N3, C, seed=100, scale=0.2), gen(N3, seed=101)
+        pw3 = ops.pack_linear_ln(w3.cuda(), b3.cuda(), gamma.cuda(), beta.cuda(), split)
+        pw3.meta["ln_eps"] = 1e-6
+        pos = torch.randint(0, 9, (Z, Nt, 2), generator=torch.Generator().manual_seed(5))
+        cos, sin = O.rope2d_table(9, D)
+        ref = F.layer_norm(x.cpu(), (C,), gamma, beta, 1e-6).to(adt).float() @ w3.t() + b3
+        ref = O.rope2d(ref.view(Z, Nt, H, D).transpose(1, 2), pos).transpose(1, 2).reshape(Z, Nt, N3)
+        out3 = ops.linear(x if split else xb, pw3, out_dtype=torch.float32, ln=st, rope=(cos.cuda(), sin.cuda(), pos.cuda(), N3))
+        check(f"skinny[{name}] r={rows} folded LayerNorm + RoPE", out3, ref, max(tol, 2e-2 if not split else 0))
+    finally:
+        ops.set_plan_log(None)
+        ops.gemm_tune(4, 0)
+        ops.gemm_tune(0, 0)
+
+
+@pytest.mark.parametrize("mode", [MODES[0], MODES[2]], ids=["bf16", "bf16x3"])
 def test_gemm_grouped_two_sides(mode):
     """Two weight sets in one launch (blockIdx.z = b * 2 + side), incl. the flipped read (side s multiplies the OTHER side's rows:
     the cross-attention memory of a decoder block), folded LayerNorm statistics following the flip, RoPE on the output."""
