@@ -62,6 +62,11 @@ class GaussianRasterizer:
         s = self.raster_settings
         cam = make_cam(s)
         if shs is None:  # precomputed colours = SH degree 0 with the DC term that reproduces them: c = 0.28209479 * sh + 0.5
+            # LIMITATION: the SH colour path clamps at zero (max(c, 0)), the upstream package blends precomputed colours unclamped.
+            # The reference only passes shs (use_sh=True, cuda_splatting.py:104-118); negative / feature-valued colors_precomp are refused
+            # instead of being rendered differently from upstream.
+            if bool((colors_precomp < 0).any()):
+                raise Exception("colors_precomp < 0 is not supported by this rasterizer (its colour path clamps at zero); pass shs, or non-negative colours")
             shs = ((colors_precomp - 0.5) / 0.28209479177387814)[:, None, :]
             cam.sh_degree = 0
         o = raster.rasterize_k2(cam, means3D, cov3D_precomp, shs, opacities.reshape(-1))

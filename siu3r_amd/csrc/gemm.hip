@@ -479,15 +479,9 @@ void plan(const siu3r_gemm_params& p, siu3r_gemm_plan_t& pl) {
 }
 }  // namespace
 
-extern "C" int siu3r_gemm_plan(const siu3r_gemm_params* pp, siu3r_gemm_plan_t* out) {
-  SIU3R_CHECK(pp && out, "siu3r_gemm_plan: null argument");
-  SIU3R_CHECK(pp->m > 0 && pp->n > 0 && pp->k > 0 && pp->kpad % BK == 0, "siu3r_gemm_plan: bad problem");
-  plan(*pp, *out);
-  return 0;
-}
-
-extern "C" int siu3r_gemm(const siu3r_gemm_params* pp, void* stream) {
-  const siu3r_gemm_params& p = *pp;
+// parameter validation shared by siu3r_gemm and siu3r_gemm_plan (the plan divides by the conv geometry: a malformed block must come
+// back as an error string from both, not as SIGFPE from the query)
+static int validate_gemm(const siu3r_gemm_params& p) {
   SIU3R_CHECK(p.a && p.w_hi && p.c, "siu3r_gemm: null operand pointer");
   SIU3R_CHECK(p.m > 0 && p.n > 0 && p.k > 0, "siu3r_gemm: empty problem (m=%d n=%d k=%d)", p.m, p.n, p.k);
   SIU3R_CHECK(p.kpad % BK == 0 && p.kpad >= p.k, "siu3r_gemm: kpad=%d must be a multiple of 64 and >= k=%d", p.kpad, p.k);
@@ -495,6 +489,8 @@ extern "C" int siu3r_gemm(const siu3r_gemm_params* pp, void* stream) {
   SIU3R_CHECK(p.c_dtype == SIU3R_BF16 || p.c_dtype == SIU3R_F32, "siu3r_gemm: bad c_dtype %d", p.c_dtype);
   SIU3R_CHECK(!(p.w_lo && p.a_dtype != SIU3R_F32), "siu3r_gemm: bf16x3 mode needs fp32 activations");
   SIU3R_CHECK(p.a_mode >= 0 && p.a_mode <= 2, "siu3r_gemm: bad a_mode %d", p.a_mode);
+  if (p.a_mode != 0) SIU3R_CHECK(p.oh > 0 && p.ow > 0 && p.ih > 0 && p.iw > 0 && (p.a_mode == 2 || (p.cin > 0 && p.kh > 0 && p.kw > 0 && p.stride > 0)),
+                                 "siu3r_gemm: conv geometry must be positive (ih=%d iw=%d cin=%d kh=%d kw=%d stride=%d oh=%d ow=%d)", p.ih, p.iw, p.cin, p.kh, p.kw, p.stride, p.oh, p.ow);
   if (p.a_mode == 0) {
     SIU3R_CHECK(p.k % 8 == 0 && p.lda % 8 == 0, "siu3r_gemm: dense A needs k %% 8 == 0 and lda %% 8 == 0 (k=%d lda=%ld)", p.k, (long)p.lda);
   } else if (p.a_mode == 1) {
@@ -520,6 +516,19 @@ extern "C" int siu3r_gemm(const siu3r_gemm_params* pp, void* stream) {
     SIU3R_CHECK(p.sk_ws && p.sk_cnt && p.splitk <= 64 && p.splitk <= p.kpad / 64, "siu3r_gemm: split-K needs a workspace, zeroed counters and splitk <= kpad / 64 (splitk=%d)", p.splitk);
   SIU3R_CHECK(p.tile_cfg >= -1 && p.tile_cfg <= 3, "siu3r_gemm: bad tile_cfg %d", p.tile_cfg);
   if (p.bmod > 0) SIU3R_CHECK(p.batch > 0 && p.batch % p.bmod == 0, "siu3r_gemm: batch %d is not a multiple of bmod %d", p.batch, p.bmod);
+  return 0;
+}
+
+extern "C" int siu3r_gemm_plan(const siu3r_gemm_params* pp, siu3r_gemm_plan_t* out) {
+  SIU3R_CHECK(pp && out, "siu3r_gemm_plan: null argument");
+  if (int rc = validate_gemm(*pp)) return rc;
+  plan(*pp, *out);
+  return 0;
+}
+
+extern "C" int siu3r_gemm(const siu3r_gemm_params* pp, void* stream) {
+  const siu3r_gemm_params& p = *pp;
+  if (int rc = validate_gemm(p)) return rc;
   siu3r_gemm_plan_t pl;
   plan(p, pl);
   hipStream_t s = (hipStream_t)stream;
@@ -527,6 +536,9 @@ extern "C" int siu3r_gemm(const siu3r_gemm_params* pp, void* stream) {
   q.splitk = pl.splitk;
   if (pl.splitk > 1) SIU3R_CHECK(p.sk_ws && p.sk_cnt && p.sk_ws_floats >= pl.ws_floats && p.sk_cnt_n >= pl.counters,
                                  "siu3r_gemm: split-K workspace too small (%ld floats / %d counters needed)", (long)pl.ws_floats, pl.counters);
+  // "splitk > 1 = exactly that many slices" (include/siu3r_hip.h): a kernel that cannot split is an error, not a silent single slice
+  SIU3R_CHECK(!(p.splitk > 1 && pl.splitk != p.splitk), "siu3r_gemm: splitk=%d was requested but %s cannot split K for this problem (it would run %d slice(s)); "
+              "request 0 / 1 or another tile_cfg", p.splitk, pl.kernel, pl.splitk);
   if (pl.tile_cfg > 0) {
     q.m_main = pl.skinny_rows > 0 ? p.m - pl.skinny_rows : 0;
     if (!(pl.skinny_rows > 0 && q.m_main == 0)) {

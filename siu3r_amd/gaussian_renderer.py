@@ -122,6 +122,13 @@ def lift_query_class_logits(render_qc_logits: List[torch.Tensor], query_scores: 
     return torch.stack(all_sem), torch.stack(all_ins), seg_infos
 
 
+_PREPARED: dict = {}  # rasterize_splats' one-entry cache of the view-independent preparation (release_prepared_splats() drops it)
+
+
+def release_prepared_splats():
+    _PREPARED.clear()
+
+
 def rasterize_splats(splats: dict, camtoworlds: torch.Tensor, Ks: torch.Tensor, width: int, height: int, sh_degree: int = 4,
                      radius_clip: float = 0.1, near_plane: float = 0.01, far_plane: float = 1e10, backgrounds=(1.0, 1.0, 1.0)):
     """The reference viewer's render call (viewer.py:301-336 + 376-401): gsplat.rasterization semantics with
@@ -131,15 +138,18 @@ def rasterize_splats(splats: dict, camtoworlds: torch.Tensor, Ks: torch.Tensor, 
     from . import raster
 
     # view-independent preparation (covariances from quats / scales, activations, the concatenated coefficient block): computed once per
-    # splat set and kept with it -- a viewer renders many frames of one scene (the block alone is 600 MB for 2 M Gaussians)
-    key = tuple(splats[k].data_ptr() if k in splats and splats[k] is not None else 0 for k in ("means", "quats", "scales", "opacities", "sh0", "shN"))
-    prep = splats.get("_prepared")
+    # splat set -- a viewer renders many frames of one scene (the block alone is 600 MB for 2 M Gaussians).  The one-entry cache is keyed
+    # by storage AND version counter of every source tensor (an in-place edit -- scene editing, an optimizer step, copy_ -- bumps
+    # `_version` and invalidates it) and lives in this module: the caller's dict is not touched.
+    names = ("means", "quats", "scales", "opacities", "sh0", "shN")
+    key = tuple((splats[k].data_ptr(), splats[k]._version, tuple(splats[k].shape)) if k in splats and splats[k] is not None else None for k in names)
+    prep = _PREPARED.get("entry")
     if prep is None or prep[0] != key:
         means = splats["means"].float()
         cov6 = raster.quat_scale_to_cov6(splats["quats"], torch.exp(splats["scales"].float()))
         opac = torch.sigmoid(splats["opacities"].float())
         coeffs = torch.cat([splats["sh0"], splats["shN"]], 1).float() if "shN" in splats and splats["shN"] is not None else splats["sh0"].float()
-        prep = splats["_prepared"] = (key, means, cov6, opac, coeffs)
+        prep = _PREPARED["entry"] = (key, means, cov6, opac, coeffs)
     _, means, cov6, opac, coeffs = prep
     assert coeffs.shape[1] >= (sh_degree + 1) ** 2
     cols, alphas, visible, pairs = [], [], [], []

@@ -531,6 +531,82 @@ class _DPTHead:
         return ops.linear(x, ctx.w.linear(f"{p}.dpt.head.4"), out_dtype=torch.float32)  # [B,H,W,83]
 
 
+class _DPTHeadPair:
+    """The two DPT heads of a kind (head1 on view 0, head2 on view 1: reference model.py:352-375 runs them one after the other) as ONE
+    sequence of grouped launches: activations [B, 2, h, w, C], every convolution / linear multiplies image (b, g) by the weights of head
+    g (blockIdx.z = b * 2 + g).  Same arithmetic per head as _DPTHead; half the launches, twice the tiles per launch -- the trunk's
+    convolutions at 16^2 .. 128^2 are a fraction of the 256 CUs each on their own.  Used for V == 2, B == 1 (the stem of the Gaussian
+    head reads its upsample source per head and stays two launches)."""
+
+    def __init__(self, ctx: _Ctx, prefixes: Sequence[str], gs: bool):
+        self.ctx, self.ps, self.gs = ctx, tuple(prefixes), gs
+
+    def _w(self, kind: str, name: str, **kw):
+        """layer `name` (relative to the head prefix) of both heads as one grouped weight"""
+        w = self.ctx.w
+        build = {"conv": lambda q: w.conv(q + name, **kw), "convT": lambda q: w.convT(q + name), "linear": lambda q: w.linear(q + name)}[kind]
+        return w.group("pair:" + "|".join(self.ps) + ":" + name, build, self.ps)
+
+    def _rcu(self, q, x, extra=None):
+        ctx = self.ctx
+        o = ops.conv2d_grouped(x, self._w("conv", q + ".conv1"), pad=1, out_dtype=ctx.act, act=ACT_RELU, relu_in=True)
+        res = x if extra is None else ops.affine_add(x.flatten(0, 1), extra.flatten(0, 1), None, None).view(x.shape)
+        return ops.conv2d_grouped(o, self._w("conv", q + ".conv2"), pad=1, out_dtype=ctx.act, residual=res)
+
+    def _fusion(self, q, x0, x1):
+        ctx = self.ctx
+        out = x0 if x1 is None else self._rcu(q + ".resConfUnit1", x1, extra=x0)
+        out = self._rcu(q + ".resConfUnit2", out)
+        B, G, hh, ww, Cc = out.shape
+        out = ops.linear_grouped(out.view(B, G, hh * ww, Cc), self._w("linear", q + ".out_conv"), out_dtype=ctx.act)
+        return ops.resize_bilinear(out.view(B * G, hh, ww, -1), (2 * hh, 2 * ww), True).view(B, G, 2 * hh, 2 * ww, -1)
+
+    def trunk(self, tokens: Sequence[torch.Tensor], H, W):
+        """tokens: per hooked layer [B, 2, N, C] (strided view: both views' patch tokens)"""
+        ctx = self.ctx
+        nh, nw = H // 16, W // 16
+        layers = []
+        for i, hk in enumerate(DPT_HOOKS):
+            t = tokens[hk]
+            B, G = t.shape[:2]
+            a = f".dpt.act_postprocess.{i}"
+            l = ops.linear_grouped(t, self._w("linear", a + ".0"), out_dtype=ctx.act).view(B, G, nh, nw, -1)
+            if i in (0, 1):
+                l = ops.conv_transpose2d_grouped(l, self._w("convT", a + ".1"), out_dtype=ctx.act)
+            elif i == 3:
+                l = ops.conv2d_grouped(l, self._w("conv", a + ".1"), stride=2, pad=1, out_dtype=ctx.act)
+            layers.append(ops.conv2d_grouped(l, self._w("conv", f".dpt.scratch.layer_rn.{i}"), pad=1, out_dtype=ctx.act))
+        s = ".dpt.scratch"
+        path4 = self._fusion(s + ".refinenet4", layers[3], None)
+        path3 = self._fusion(s + ".refinenet3", path4, layers[2])
+        path2 = self._fusion(s + ".refinenet2", path3, layers[1])
+        return self._fusion(s + ".refinenet1", path2, layers[0])
+
+    def forward_pts3d(self, tokens, H, W):
+        """-> pts3d [B, 2, H, W, 3]"""
+        ctx = self.ctx
+        x = self.trunk(tokens, H, W)
+        x = ops.conv2d_grouped(x, self._w("conv", ".dpt.head.0"), pad=1, out_dtype=ctx.act)
+        B, G = x.shape[:2]
+        x = ops.resize_bilinear(x.flatten(0, 1), (H, W), True).view(B, G, H, W, -1)
+        x = ops.conv2d_grouped(x, self._w("conv", ".dpt.head.2"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
+        xyz = ops.linear_grouped(x.view(B, G, H * W, -1), self._w("linear", ".dpt.head.4"), out_dtype=torch.float32)
+        return ops.pts3d_exp_(xyz).view(B, G, H, W, 3)
+
+    def forward_gs(self, tokens, img_nhwc8, H, W, out):
+        """img_nhwc8 [B, 2, H, W, c]; out: the model's [B, 2, H*W, 83] raw-Gaussian buffer (written in place)"""
+        ctx = self.ctx
+        path1 = self.trunk(tokens, H, W)
+        B, G = path1.shape[:2]
+        assert B == 1
+        x = torch.empty((B, G, H, W, path1.shape[-1]), dtype=ctx.act, device=ctx.dev)
+        for g, q in enumerate(self.ps):  # the stem: 7x7 image convolution + ReLU + x2 upsample-add of this head's path_1
+            ops.conv2d(img_nhwc8[:, g], ctx.w.conv(q + ".dpt.input_merger.0", cin_pad=ops.image_channels(ctx.split)), pad=3, act=ACT_RELU,
+                       up_src=path1[:, g], out=x[:, g])  # (B == 1: the slices of a group are contiguous)
+        x = ops.conv2d_grouped(x, self._w("conv", ".dpt.head.0"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
+        return ops.linear_grouped(x.view(B, G, H * W, -1), self._w("linear", ".dpt.head.4"), out=out)
+
+
 class UnifiedGaussianAdapter:
     """gaussian_adapter.py:50-110."""
 
@@ -913,6 +989,8 @@ class VideoMask2FormerForVideoSegmentation:
 # ==================================================================================================
 _PTS0_MAIN = os.environ.get("SIU3R_PTS0_MAIN", "0") == "1"
 _HEAD_MAP = os.environ.get("SIU3R_HEAD_MAP", "")
+_HEAD_PAIRS = os.environ.get("SIU3R_NO_HEAD_PAIRS", "0") != "1"  # the two heads of a kind as grouped launches (V == 2, B == 1)
+_PAIR_MAP = os.environ.get("SIU3R_PAIR_MAP", "")  # A/B: streams of the (Gaussian pair, pts3d pair) chains, e.g. "0,m"
 _PTS0_OWN = os.environ.get("SIU3R_PTS0_OWN", "0") == "1"  # A/B: a fifth stream for the pts3d head of view 0 (needs GPU_MAX_HW_QUEUES >= 5 to overlap)
 _DEC_PER_LAYER = os.environ.get("SIU3R_DEC_PER_LAYER", "0") == "1"
 _PIPE_PTSR = int(os.environ.get("SIU3R_PIPE_PTSR", "0"))  # forward_async: the head stream (0 / 1) the pts3d head of views 1.. queues on
@@ -957,6 +1035,9 @@ class SIU3RModel:
         self.downstream_head2 = _DPTHead(self._ctx, "downstream_head2", gs=False)
         self.gaussian_param_head1 = _DPTHead(self._ctx, "gaussian_param_head1", gs=True)
         self.gaussian_param_head2 = _DPTHead(self._ctx, "gaussian_param_head2", gs=True)
+        # the two heads of a kind as one sequence of grouped launches (one pair, one item: the benchmarked shape)
+        self.gs_pair = _DPTHeadPair(self._ctx, ("gaussian_param_head1", "gaussian_param_head2"), gs=True)
+        self.pts_pair = _DPTHeadPair(self._ctx, ("downstream_head1", "downstream_head2"), gs=False)
         self.gaussian_adapter = UnifiedGaussianAdapter(sh_degree=sh_degree)
         self.processor = pp.VideoMask2FormerImageProcessor()
         self.raw_gs_dim = (sh_degree + 1) ** 2 * 3 + 3 + 4 + 1
@@ -1194,9 +1275,16 @@ class SIU3RModel:
         enc = [("enc_begin", lambda: self._s_encode_begin(st)), ("spm", lambda: setattr(st, "adapter", ad.spm(st.img8)))]
         for k in range(len(ADAPTER_IDX)):
             enc += [(f"enc{k}", lambda k=k: enc_seg(k)), (f"int{k}", lambda k=k: interact(k))]
-        return enc + [("seg", lambda: self._s_seg(st))] + dec + [
-            ("gs0", lambda: self._s_head(st, 0)), ("gsr", lambda: self._s_head(st, 1)), ("pts0", lambda: self._s_head(st, 2)),
-            ("ptsr", lambda: self._s_head(st, 3)), ("tail", lambda: self._s_tail(st))]
+        if self._paired_heads(st):
+            heads = [("gs", lambda: self._s_head_pair(st, True)), ("pts", lambda: self._s_head_pair(st, False))]
+        else:
+            heads = [("gs0", lambda: self._s_head(st, 0)), ("gsr", lambda: self._s_head(st, 1)), ("pts0", lambda: self._s_head(st, 2)),
+                     ("ptsr", lambda: self._s_head(st, 3))]
+        return enc + [("seg", lambda: self._s_seg(st))] + dec + heads + [("tail", lambda: self._s_tail(st))]
+
+    def _paired_heads(self, st) -> bool:
+        B, V = st.images.shape[:2]
+        return _HEAD_PAIRS and V == 2 and B == 1
 
     def _merged_decoder(self, st) -> bool:
         return self._ctx.fold and st.images.shape[1] == 2
@@ -1265,7 +1353,14 @@ class SIU3RModel:
         pipelined = pipelined and par
         ptsr_stream = hs[_PIPE_PTSR] if pipelined else main  # pipelined: behind one of the Gaussian heads instead of on the encoder's stream
         placement = list(zip(("gs0", "gsr", "ptsr", "pts0"), hs + [ptsr_stream, pts0_stream]))
-        if _HEAD_MAP and par:  # A/B: SIU3R_HEAD_MAP="0,1,m,s" = stream of gs0, gsr, ptsr, pts0 (0 / 1 head streams, m main, s segmentation), in launch order
+        if "gs" in stages:  # paired heads: two chains (both Gaussian heads | both pts3d heads)
+            pick = {"0": hs[0], "1": hs[1], "m": main, "s": seg_stream}
+            k_gs, k_pts = (_PAIR_MAP.split(",") if (_PAIR_MAP and par) else ("0", "1" if pipelined else "m"))
+            placement = [("gs", pick[k_gs] if par else main), ("pts", pick[k_pts] if par else main)]
+            for _, s_ in placement:
+                if s_ is seg_stream and par:
+                    seg_stream.wait_stream(main)
+        elif _HEAD_MAP and par:  # A/B: SIU3R_HEAD_MAP="0,1,m,s" = stream of gs0, gsr, ptsr, pts0 (0 / 1 head streams, m main, s segmentation), in launch order
             pick = {"0": hs[0], "1": hs[1], "m": main, "s": seg_stream}
             placement = [(n_, pick[k_]) for n_, k_ in zip(("gs0", "gsr", "ptsr", "pts0"), _HEAD_MAP.split(","))]
             for _, s_ in placement:
@@ -1317,6 +1412,17 @@ class SIU3RModel:
         else:
             head = self.downstream_head1 if first else self.downstream_head2
             st.pts[0 if first else 1] = head.forward_pts3d(toks, H, W)["pts3d"]
+
+    def _s_head_pair(self, st, gs: bool):
+        """both heads of a kind (view 0 -> head1, view 1 -> head2) as grouped launches"""
+        B, V, _, H, W = st.images.shape
+        toks = [t[..., :-1, :] for t in st.dec["layers"]]  # [B, 2, N, C]: the patch tokens of both views
+        if gs:
+            self.gs_pair.forward_gs(toks, st.img8.view(B, V, H, W, st.img8.shape[-1]), H, W, out=st.raw)
+            st.gs = [st.raw[:, 0], st.raw[:, 1]]
+        else:
+            pts = self.pts_pair.forward_pts3d(toks, H, W)
+            st.pts = [pts[:, 0], pts[:, 1]]
 
     def _s_tail(self, st):
         B, V, _, H, W = st.images.shape

@@ -473,16 +473,18 @@ def bmm_nt(a: torch.Tensor, b_hi: torch.Tensor, b_lo: Optional[torch.Tensor], n:
 
 
 def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride=1, pad=0, out_dtype=torch.float32, act=ACT_NONE,
-           residual=None, relu_in=False, up_src: Optional[torch.Tensor] = None):
-    """NHWC implicit-GEMM convolution: x [B, IH, IW, Cin] -> [B, OH, OW, Cout]."""
-    _gpu(x, residual, up_src)
+           residual=None, relu_in=False, up_src: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """NHWC implicit-GEMM convolution: x [B, IH, IW, Cin] -> [B, OH, OW, Cout] (out: optional contiguous destination)."""
+    _gpu(x, residual, up_src, out)
     assert x.is_contiguous()
     B, IH, IW, Cin = x.shape
     kh, kw = pw.meta["kh"], pw.meta["kw"]
     assert Cin == pw.meta["cin"], (Cin, pw.meta)
     OH = (IH + 2 * pad - kh) // stride + 1
     OW = (IW + 2 * pad - kw) // stride + 1
-    out = torch.empty((B, OH, OW, pw.n), dtype=out_dtype, device=x.device)
+    if out is None:
+        out = torch.empty((B, OH, OW, pw.n), dtype=out_dtype, device=x.device)
+    assert out.shape == (B, OH, OW, pw.n) and out.is_contiguous()
     p = GemmParams()
     _fill_common(p, x, pw, out, act, residual, relu_in)
     p.m, p.ldc, p.ldr = B * OH * OW, pw.n, pw.n
@@ -513,6 +515,56 @@ def conv_transpose2d(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float
         p.m, p.lda = IH * IW, Cin
         p.batch, p.sa, p.sw, p.sc = B, x_bs, 0, out[0].numel()
         p.sr = out[0].numel() if residual is not None else 0
+    _gemm_launch(p)
+    return out
+
+
+def _grouped_common(p: GemmParams, x, pw: PackedWeight, out, residual):
+    """two-level batching of a grouped launch over images [B, G, ...]: blockIdx.z = b * G + g, weight set g"""
+    G = pw.meta["groups"]
+    B = x.shape[0]
+    assert x.shape[1] == G and x.is_contiguous() and out.is_contiguous()
+    p.batch, p.bmod = B * G, G
+    p.sa, p.sa_i, p.sc, p.sc_i = x.stride(0), x.stride(1), out.stride(0), out.stride(1)
+    # (bias elements per weight set: n, or cout for the conv-transpose whose bias is per output channel of the pixel shuffle)
+    p.sw, p.sbias = pw.hi.stride(0), (pw.bias.stride(0) if pw.bias is not None else pw.n)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.is_contiguous()
+        p.sr, p.sr_i = residual.stride(0), residual.stride(1)
+
+
+def conv2d_grouped(x: torch.Tensor, pw: PackedWeight, *, stride=1, pad=0, out_dtype=torch.float32, act=ACT_NONE, residual=None, relu_in=False):
+    """conv2d for G networks of the same shape in ONE launch: x [B, G, IH, IW, Cin] -> [B, G, OH, OW, Cout], image (b, g) convolved with
+    weight set g of pw = stack_packed([...G sets]) (the two DPT heads of a kind: head1 on view 0, head2 on view 1 -- reference
+    model.py:352-375 runs them one after the other)."""
+    _gpu(x, residual)
+    B, G, IH, IW, Cin = x.shape
+    kh, kw = pw.meta["kh"], pw.meta["kw"]
+    assert Cin == pw.meta["cin"], (Cin, pw.meta)
+    OH = (IH + 2 * pad - kh) // stride + 1
+    OW = (IW + 2 * pad - kw) // stride + 1
+    out = torch.empty((B, G, OH, OW, pw.n), dtype=out_dtype, device=x.device)
+    p = GemmParams()
+    _fill_common(p, x, pw, out, act, residual, relu_in)
+    p.m, p.ldc, p.ldr = OH * OW, pw.n, pw.n
+    p.a_mode = 1
+    p.ih, p.iw, p.cin, p.kh, p.kw, p.stride, p.pad, p.oh, p.ow = IH, IW, Cin, kh, kw, stride, pad, OH, OW
+    _grouped_common(p, x, pw, out, residual)
+    _gemm_launch(p)
+    return out
+
+
+def conv_transpose2d_grouped(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32):
+    """conv_transpose2d (kernel == stride) for G weight sets in one launch: x [B, G, IH, IW, Cin] -> [B, G, IH*up, IW*up, Cout]"""
+    _gpu(x)
+    B, G, IH, IW, Cin = x.shape
+    up, cout = pw.meta["up"], pw.meta["cout"]
+    out = torch.empty((B, G, IH * up, IW * up, cout), dtype=out_dtype, device=x.device)
+    p = GemmParams()
+    _fill_common(p, x, pw, out, ACT_NONE, None, False)
+    p.out_mode, p.up, p.cout, p.ih, p.iw = 1, up, cout, IH, IW
+    p.m, p.lda = IH * IW, Cin
+    _grouped_common(p, x, pw, out, None)
     _gemm_launch(p)
     return out
 

@@ -242,6 +242,19 @@ def test_gemm_plan_consults_the_measured_table_then_the_model():
         _lib.check(lib.siu3r_gemm_tune(3, 0))
 
 
+def test_gemm_plan_validates_like_the_launch():
+    """siu3r_gemm_plan runs the same parameter validation as siu3r_gemm: a malformed conv block (oh * ow == 0: the plan divides by it)
+    comes back as an error string, not as SIGFPE; so do a bad kpad and a null operand."""
+    with pytest.raises(RuntimeError, match="conv geometry"):
+        _plan(m=4096, n=256, k=2304, a_mode=1, ih=64, iw=64, cin=256, kh=3, kw=3, stride=1, pad=1, oh=0, ow=0)
+    with pytest.raises(RuntimeError, match="kh\\*kw\\*cin"):
+        _plan(m=4096, n=256, k=2304, a_mode=1, ih=64, iw=64, cin=128, kh=3, kw=3, stride=1, pad=1, oh=64, ow=64)
+    with pytest.raises(RuntimeError, match="null operand"):
+        _plan(m=128, n=128, k=128, a=0)
+    ok = _plan(m=4096, n=256, k=2304, a_mode=1, ih=64, iw=64, cin=256, kh=3, kw=3, stride=1, pad=1, oh=64, ow=64)
+    assert ok.bm > 0 and ok.kernel
+
+
 def test_batch_strided_views_host_logic():
     from siu3r_amd.ops import _batch_strided
 

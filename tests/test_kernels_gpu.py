@@ -851,6 +851,24 @@ def test_gemm_skinny_remainder_rows(mode, rows):
         ops.gemm_tune(0, 0)
 
 
+def test_explicit_splitk_is_honoured_or_refused():
+    """siu3r_gemm_params.splitk > 1 means exactly that many slices: a kernel that cannot split (the register-staged 128 x 128 family
+    is reached by no public path any more; the 128 x 64 LDS-DMA kernel splits) either runs them or the launch fails loudly."""
+    ops = _ops()
+    a, w = gen(256, 2048, seed=5), gen(128, 2048, seed=6, scale=0.05)
+    pw = ops.pack_linear(w.cuda(), None, True)
+    log = []
+    ops.set_plan_log(log)
+    try:
+        out = ops.linear(a.cuda(), pw, out_dtype=torch.float32, splitk=4)
+    finally:
+        ops.set_plan_log(None)
+    assert log[-1].splitk == 4
+    check("explicit split-K 4", out, a @ w.t(), 2e-4)
+    with pytest.raises(RuntimeError, match="splitk"):
+        ops.linear(a.cuda(), pw, out_dtype=torch.float32, splitk=128)  # more slices than kpad / 64 allows
+
+
 @pytest.mark.parametrize("mode", [MODES[0], MODES[2]], ids=["bf16", "bf16x3"])
 def test_gemm_grouped_two_sides(mode):
     """Two weight sets in one launch (blockIdx.z = b * 2 + side), incl. the flipped read (side s multiplies the OTHER side's rows:

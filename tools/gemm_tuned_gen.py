@@ -35,6 +35,13 @@ for key, e in sorted(agg.items()):
         continue
     gain += e["auto"] - full[best]
     lines.append("    {%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d},  // %.1f -> %.1f us per step (%s)" % (*key, best[0], best[1], e["auto"], full[best], e["src"]))
+# measured by hand (tile AND split count swept: the replay tries each tile with the slice count the model would give it)
+MANUAL = [
+    "    {2050, 1024, 4096, 1, 0, 0, 0, 0, 1, 0, 2, 2},  // 88.1 -> 74.5 us (tools/mb_skinny.py, round 4: nine row tiles of 256 x 128, two K slices, no remainder launch)",
+]
+have = {l.split("}")[0] for l in lines}
+lines += [l for l in MANUAL if l.split("}")[0].rsplit(",", 2)[0] not in {h.rsplit(",", 2)[0] for h in have}]
+lines.sort(key=lambda l: [int(v) for v in l.split("{")[1].split("}")[0].split(",")])
 hdr = open(os.path.join(ROOT, "siu3r_amd", "csrc", "gemm_tuned.h")).read()
 head = hdr[:hdr.index("static const siu3r_tuned_entry kTuned[] = {")]
 out = head + "static const siu3r_tuned_entry kTuned[] = {\n" + "\n".join(lines) + ("\n" if lines else "") + "    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},  // (terminator)\n};\n"
