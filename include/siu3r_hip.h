@@ -113,6 +113,7 @@ typedef struct {
   int32_t sk_cnt_n;
   int32_t tile_cfg;               /* 0 = the launcher decides; SIU3R_TILE_* forces a kernel family / tile (tools, tests) */
   int32_t m_main;                 /* internal (launcher): rows covered by the tiled kernel when a skinny launch multiplies the last <= 32 rows */
+  int32_t sk_gx;                  /* internal (launcher): > 0 = the ping-pong launch carries the remainder rows itself, as workgroups blockIdx.x >= sk_gx */
 } siu3r_gemm_params;
 #define SIU3R_TILE_AUTO 0
 #define SIU3R_TILE_128x64 -1   /* the 128 x 64 LDS-DMA / register-staged kernels (gemm_dma.hip, gemm.hip) */

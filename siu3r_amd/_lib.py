@@ -38,7 +38,7 @@ class GemmParams(C.Structure):
         ("stats_out", C.c_void_p), ("st_ldm", C.c_int64), ("st_sz", C.c_int64), ("st_sz_i", C.c_int64),
         ("c_aux", C.c_void_p),
         ("splitk", C.c_int32), ("sk_ws", C.c_void_p), ("sk_cnt", C.c_void_p),
-        ("sk_ws_floats", C.c_int64), ("sk_cnt_n", C.c_int32), ("tile_cfg", C.c_int32), ("m_main", C.c_int32),
+        ("sk_ws_floats", C.c_int64), ("sk_cnt_n", C.c_int32), ("tile_cfg", C.c_int32), ("m_main", C.c_int32), ("sk_gx", C.c_int32),
     ]
 
 

@@ -25,6 +25,7 @@ int siu3r_gemm_pp_mode(const siu3r_gemm_params& p);                           //
 void siu3r_gemm_pp_name(const siu3r_gemm_params& p, int cfg, char* buf, int n);
 int siu3r_gemm_pp_launch(const siu3r_gemm_params& p, int cfg, void* stream);
 int siu3r_gemm_skinny_launch(const siu3r_gemm_params& p, void* stream);
+bool siu3r_gemm_pp_folds_skinny(const siu3r_gemm_params& p);
 static const bool g_disable_dma = getenv("SIU3R_GEMM_NO_DMA") != nullptr;     // debugging / A-B switch
 // 128x64 tiles (two workgroups per CU) beat 128x128 (one per CU: 96 KiB ring) at every size measured on gfx950 --
 // finer wave quantisation and a second workgroup to overlap prologue/epilogue; 128x128 stays reachable for A/B runs
@@ -431,7 +432,8 @@ void plan(const siu3r_gemm_params& p, siu3r_gemm_plan_t& pl) {
         if (mrows == 0) t = 0.f;
         // skinny launch: a kernel boundary plus its K loop (its fragment-shaped loads are address-bound: ~9 us per 1024 k in bf16x3)
         // (<= 4 rows and 2048 <= kpad <= 4096: the matrix-vector kernel of gemm_pp.hip, 26 us at K = 4096 in bf16x3)
-        if (skinny) t += (skinny <= 4 && p.kpad >= 2048 && p.kpad <= 4096) ? 5.0f + (x3 ? 5.0f : 3.0f) * (float)p.kpad / 1024.f : 3.5f + (x3 ? 9.3f : 5.0f) * (float)p.kpad / 1024.f;
+        if (skinny && mrows > 0 && p.kpad <= 2048 && !getenv("SIU3R_GEMM_NO_FOLD")) t += 1.0f + (x3 ? 5.0f : 3.0f) * (float)p.kpad / 1024.f;  // carried by the tile launch (extra workgroups at its tail)
+        else if (skinny) t += (skinny <= 4 && p.kpad >= 2048 && p.kpad <= 4096) ? 5.0f + (x3 ? 5.0f : 3.0f) * (float)p.kpad / 1024.f : 3.5f + (x3 ? 9.3f : 5.0f) * (float)p.kpad / 1024.f;
         if (S > 1) t += 2.5f + (float)(2.0 * S * tiles * c.bm * c.bn * 4.0 / 5.0e6);
         // bf16: the 128 x 64 LDS-DMA kernel is already within a few per cent of the best tile on almost every shape of the network and
         // shares a CU with the other chains' kernels; end to end the ping-pong tiles LOSE 7-11 % there (same-box A/B of bench.py at
@@ -545,7 +547,7 @@ extern "C" int siu3r_gemm(const siu3r_gemm_params* pp, void* stream) {
       const int rc = siu3r_gemm_pp_launch(q, pl.tile_cfg, stream);
       if (rc) return rc;
     }
-    if (pl.skinny_rows > 0) {
+    if (pl.skinny_rows > 0 && !(q.m_main > 0 && siu3r_gemm_pp_folds_skinny(q))) {
       q.splitk = 0;
       return siu3r_gemm_skinny_launch(q, stream);
     }

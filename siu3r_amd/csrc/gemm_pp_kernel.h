@@ -49,6 +49,128 @@ constexpr int smem_bytes() {
 
 #define SIU3R_DS_READ(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory")
 
+// ---- the last <= 32 rows of a dense problem (M = 2 x 1025 tokens = 8 x 256 + 2: a ninth row of tiles that holds two rows would cost a
+// second round of workgroups).  A workgroup multiplies those rows by 64 columns over the whole K: its 8 waves take K slices, load
+// their MFMA fragments straight from global memory (no LDS ring: the W panel is streamed once, 16 bytes per lane, everything of a
+// slice in flight at once), and wave 0 adds the partial blocks through LDS and runs the row pass.  N / 64 workgroups of ~4 us.
+constexpr int SKINNY_SMEM_BYTES = 8 * 8192 + siu3r_epi_pp::WAVE_STAGE_BYTES;
+template <bool X3, bool LNF>
+__device__ __forceinline__ void skinny_rows_body(const siu3r_gemm_params& p, unsigned char* smem, int colgroup, int z) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int ESZ = X3 ? 4 : 2;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int M = p.m, N = p.n, K = p.k, kpad = p.kpad;
+  const int row0 = p.m_main, col0 = colgroup * 64;
+  const siu3r_zoff zof = siu3r_batch_offsets(p, z);
+  const unsigned char* Ab = (const unsigned char*)p.a + zof.a * ESZ;
+  const unsigned char* Wb = X3 ? (const unsigned char*)p.w_x3 + zof.w * 4 : (const unsigned char*)p.w_hi + zof.w * 2;
+  const int WROW = X3 ? kpad * 4 : kpad * 2;
+  __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, (short)0, (int)(((int64_t)(M - 1) * p.lda + K) * ESZ), RSRC_FLAGS);
+  __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, (short)0, (int)((int64_t)N * WROW), RSRC_FLAGS);
+  int m = row0 + l31;
+  if (m > M - 1) m = M - 1;
+  // k16 steps; A: the lane half's 8 values of row m; W: rows n0, n0 + 32 (bf16x3: hi and lo halves of the [hi 32 | lo 32] segment)
+  const unsigned a_voff = (unsigned)((int64_t)m * p.lda * ESZ + lh * (8 * ESZ));
+  unsigned w_voff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int n = col0 + j * 32 + l31;
+    if (n > N - 1) n = N - 1;
+    w_voff[j] = (unsigned)((int64_t)n * WROW + lh * 16);
+  }
+  const int ns_all = kpad / 16;                     // k16 steps (kpad % 64 == 0)
+  const int per = ((ns_all / 4 + 7) / 8) * 4;       // steps per wave, a multiple of 4
+  const int s_begin = wave * per, s_end = min(ns_all, s_begin + per);
+  f32x16 acc[1][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+  for (int s0 = s_begin; s0 < s_end; s0 += 4) {
+    u32x4 fa[4][2], fw[4][2][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int sg = s0 + u;
+      const bool kin = sg * 16 + lh * 8 < K;  // (K % 8 == 0; W is zero padded, A must not be read beyond K)
+      if (X3) {
+        fa[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rA, kin ? a_voff : OOB, sg * 64, 0);
+        fa[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rA, kin ? a_voff + 16 : OOB, sg * 64, 0);
+      } else {
+        fa[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rA, kin ? a_voff : OOB, sg * 32, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (X3) {
+          const int so = (sg >> 1) * 128 + (sg & 1) * 32;
+          fw[u][j][0] = __builtin_amdgcn_raw_buffer_load_b128(rW, w_voff[j], so, 0);
+          fw[u][j][1] = __builtin_amdgcn_raw_buffer_load_b128(rW, w_voff[j] + 64, so, 0);
+        } else {
+          fw[u][j][0] = __builtin_amdgcn_raw_buffer_load_b128(rW, w_voff[j], sg * 32, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      union U8 { u32x4 u; bf16x8 h; };
+      if (X3) {
+        U8 ah, al, bh[2], bl[2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned int x0 = e < 2 ? fa[u][0][2 * e] : fa[u][1][2 * e - 4], x1 = e < 2 ? fa[u][0][2 * e + 1] : fa[u][1][2 * e - 3];
+          ah.u[e] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+          al.u[e] = pack_bf16x2(__uint_as_float(x0) - __uint_as_float(x0 & 0xffff0000u), __uint_as_float(x1) - __uint_as_float(x1 & 0xffff0000u));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bh[j].u = fw[u][j][0];
+          bl[j].u = fw[u][j][1];
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bh[j].h, acc[0][j], 0, 0, 0);
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bl[j].h, acc[0][j], 0, 0, 0);
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.h, bh[j].h, acc[0][j], 0, 0, 0);
+        }
+      } else {
+        U8 a, b;
+        a.u = fa[u][0];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          b.u = fw[u][j][0];
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc[0][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // partial blocks -> wave 0 (same lane, same register <-> same address: conflict-free 16-byte accesses)
+  float* part = (float*)smem;
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int qv = 0; qv < 4; ++qv) {
+        float4 v = make_float4(acc[0][j][4 * qv], acc[0][j][4 * qv + 1], acc[0][j][4 * qv + 2], acc[0][j][4 * qv + 3]);
+        *(float4*)(part + ((wave * 8 + j * 4 + qv) * 64 + lane) * 4) = v;
+      }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll 1
+  for (int w = 1; w < 8; ++w) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int qv = 0; qv < 4; ++qv) {
+        const float4 v = *(const float4*)(part + ((w * 8 + j * 4 + qv) * 64 + lane) * 4);
+        acc[0][j][4 * qv] += v.x;
+        acc[0][j][4 * qv + 1] += v.y;
+        acc[0][j][4 * qv + 2] += v.z;
+        acc[0][j][4 * qv + 3] += v.w;
+      }
+  }
+  siu3r_epi_pp::wave_rows<1, 2, LNF>(p, acc, (float*)(smem + 8 * 8192), row0, col0, M, z, lane);
+#endif
+}
+
 template <bool X3, int MI, int NJ, int MODE, bool RELU, bool LNF>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params p) {
 #if __HIP_DEVICE_COMPILE__
@@ -62,6 +184,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params
   constexpr int CK = 16 / ESZ;                                    // A elements per 16-byte chunk
   static_assert(NJ % 2 == 0, "W pieces are dealt to whole waves");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[smem_bytes<MI, NJ>()];
+  static_assert(smem_bytes<MI, NJ>() >= SKINNY_SMEM_BYTES, "the folded remainder-row workgroups use the ring's LDS");
+
+  // Workgroups behind the tile grid (blockIdx.x >= sk_gx) multiply the problem's remainder rows [m_main, m), 64 columns each: the
+  // dispatcher hands them out last, they run ~4 us on the CUs that finish their tile first -- instead of a launch of their own behind
+  // this one (12.8 us at K = 1024, of which most is a kernel's fixed cost).
+  if constexpr (MODE == 0) {
+    if (p.sk_gx > 0 && (int)blockIdx.x >= p.sk_gx) {
+      const int cg = (int)blockIdx.x - p.sk_gx;
+      if (blockIdx.y == 0 && cg * 64 < p.n) skinny_rows_body<X3, LNF>(p, smem, cg, blockIdx.z);
+      return;
+    }
+  }
 
   const int t = threadIdx.x;
   const int lane = t & 63;
