@@ -132,7 +132,7 @@ for s, ps in sorted(uniq.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2]
             continue
         res[(cfg, pl.splitk)] = t
         if SWEEP_S:
-            for S in (1, 2, 4, 8):
+            for S in (1, 2, 3, 4, 6, 8):
                 if S == pl.splitk or (S > 1 and ksteps // S < (8 if cfg > 0 else 16)):
                     continue
                 t2, pl2 = time_launch(p, cfg, S)
