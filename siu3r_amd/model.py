@@ -989,6 +989,7 @@ class VideoMask2FormerForVideoSegmentation:
 # ==================================================================================================
 _PTS0_MAIN = os.environ.get("SIU3R_PTS0_MAIN", "0") == "1"
 _HEAD_MAP = os.environ.get("SIU3R_HEAD_MAP", "")
+_ADAPTER_LATE = int(os.environ.get("SIU3R_ADAPTER_LATE", "0"))  # A/B: run the ViT-Adapter interactions behind the encoder instead of beside it
 _HEAD_PAIRS = os.environ.get("SIU3R_NO_HEAD_PAIRS", "0") != "1"  # the two heads of a kind as grouped launches (V == 2, B == 1)
 _PAIR_MAP = os.environ.get("SIU3R_PAIR_MAP", "")  # A/B: streams of the (Gaussian pair, pts3d pair) chains, e.g. "0,m"
 _PTS0_OWN = os.environ.get("SIU3R_PTS0_OWN", "0") == "1"  # A/B: a fifth stream for the pts3d head of view 0 (needs GPU_MAX_HW_QUEUES >= 5 to overlap)
@@ -1306,14 +1307,25 @@ class SIU3RModel:
         seg_stream = ctx.side_stream(1) if par else main
         if par:
             seg_stream.wait_stream(main)
-        with torch.cuda.stream(seg_stream):
-            run("spm", stages["spm"])
+        late = _ADAPTER_LATE if par else 0  # A/B: 1 = every interaction behind the whole encoder, 2 = the spatial prior module too
+        if late < 2:
+            with torch.cuda.stream(seg_stream):
+                run("spm", stages["spm"])
         for k in range(len(ADAPTER_IDX)):
             run(f"enc{k}", stages[f"enc{k}"])
+            if late:
+                continue
             if par:
                 seg_stream.wait_stream(main)
             with torch.cuda.stream(seg_stream):
                 run(f"int{k}", stages[f"int{k}"])
+        if late:
+            seg_stream.wait_stream(main)
+            with torch.cuda.stream(seg_stream):
+                if late >= 2:
+                    run("spm", stages["spm"])
+                for k in range(len(ADAPTER_IDX)):
+                    run(f"int{k}", stages[f"int{k}"])
         with torch.cuda.stream(seg_stream):
             run("seg", stages["seg"])
             if after_seg is not None:

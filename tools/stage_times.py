@@ -23,5 +23,5 @@ for name, g in ent["graphs"].items():  # the tail stage is eager (not in this di
 grp = lambda pre: sum(v for k, v in tot.items() if k.startswith(pre))
 print({k: round(v, 3) for k, v in tot.items() if not (k.startswith("dec") and (k[3] in "AB" or k[3].isdigit()))})
 print("encoder", round(grp("enc"), 2), "| spm+int", round(tot["spm"] + grp("int"), 2), "| seg", round(tot["seg"], 2), "| dec pre/post", round(tot["dec_pre"] + tot["dec_post"], 2),
-      "| decA", round(grp("decA"), 2), "| decB", round(grp("decB"), 2), "| dec (merged sides)", round(sum(v for k, v in tot.items() if k.startswith("dec") and k[3].isdigit()), 2), "| heads", {k: round(tot[k], 2) for k in ("gs0", "gsr", "pts0", "ptsr")}, "| tail: eager")
+      "| decA", round(grp("decA"), 2), "| decB", round(grp("decB"), 2), "| dec (merged sides)", round(sum(v for k, v in tot.items() if k.startswith("dec") and k[3].isdigit()), 2), "| heads", {k: round(tot[k], 2) for k in ("gs0", "gsr", "pts0", "ptsr", "gs", "pts") if k in tot}, "| tail: eager")
 print("sum", round(sum(tot.values()), 2))
