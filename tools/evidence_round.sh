@@ -3,7 +3,7 @@
 tag=${1:-r03}
 O=gpurun_out
 mkdir -p $O
-timeout 400 python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
+timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${tag}_bench.json 2> $O/${tag}_bench.err  # (the driver's arguments)
 timeout 400 python bench.py --batch 8 --no-cpu-baseline --no-render > $O/${tag}_bench_b8.json 2>> $O/${tag}_bench.err
 ROCPROF_HEAD=3 bash tools/rocprof_cmd.sh ${tag}_bench python bench.py --no-cpu-baseline > /dev/null
 tail -1 $O/${tag}_bench_out.txt > $O/${tag}_bench_under_rocprof.json
@@ -30,8 +30,11 @@ timeout 600 python tools/config3.py > $O/${tag}_config3.json 2> $O/${tag}_config
 timeout 300 python tools/config5.py bf16x3 > $O/${tag}_config5.json 2> $O/${tag}_config5.err
 timeout 200 python tools/timeline.py bf16x3 1 > $O/${tag}_timeline_bf16x3.txt 2>&1
 timeout 200 python tools/timeline.py bf16 1 > $O/${tag}_timeline_bf16.txt 2>&1
+timeout 200 python tools/stage_times.py bf16x3 > $O/${tag}_stage_times.txt 2>&1
+if [ -n "$EVIDENCE_MICRO" ]; then  # micro-benchmarks and probes of kernels that did not change since round 3: on request
 timeout 400 python tools/mb_pp.py bench big > $O/${tag}_mb_pp.txt 2>&1
 timeout 200 python tools/mb_attn.py > $O/${tag}_mb_attn.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/probes/dma_probe.hip -o /tmp/dma_probe 2>/dev/null && timeout 120 /tmp/dma_probe > $O/${tag}_dma_probe.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/probes/store_probe.hip -o /tmp/store_probe 2>/dev/null && timeout 120 /tmp/store_probe > $O/${tag}_store_probe.txt 2>&1
+fi
 ls -la $O | grep ${tag}_ | wc -l

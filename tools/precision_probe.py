@@ -63,7 +63,8 @@ class Emu(TorchFunctionMode):
         if func in (torch.matmul, torch.Tensor.matmul, torch.Tensor.__matmul__, torch.bmm):
             s = self.spec("mm")
             if s != "f32":
-                args = (rnd(args[0], s), rnd(args[1], s))
+                sa, sb = s.split("|") if "|" in s else (s, s)  # "x3|bf16": first operand (q, p) hi+lo, second (k^T, v) one bf16 plane
+                args = (rnd(args[0], sa), rnd(args[1], sb))
             return func(*args, **kwargs)
         if func is torch.einsum:
             s = self.spec("mm.einsum")

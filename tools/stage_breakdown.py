@@ -7,8 +7,8 @@ n = len(rows)
 # the five replays are identical sequences at the end: find the period by matching the tail
 names = [r["Kernel_Name"] for r in rows]
 per = None
-for L in range(5, n // 5):
-    if names[n - L:] == names[n - 2 * L:n - L] == names[n - 3 * L:n - 2 * L]:
+for L in range(n // 5, 4, -1):  # the LONGEST period that repeats five times at the tail (a stage may itself contain repeating layers)
+    if all(names[n - (r + 1) * L:n - r * L] == names[n - L:] for r in range(1, 5)):
         per = L
         break
 assert per, "no repeating tail found"
