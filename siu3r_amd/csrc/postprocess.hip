@@ -11,6 +11,8 @@
 //   pp_accept  : sequential acceptance (area/orig > 0.8), segment ids, stuff fusing       (1 thread / item)
 //   pp_write   : segmentation / semantic / instance maps from the per-query table
 //   pp_qcl     : query_class_logits[(t,y,x), j, c] = class_prob[k_j, c] * mask_prob[t, k_j, y, x]
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -27,9 +29,11 @@ __device__ __forceinline__ void src_idx(int o, int in, int out, int& i0, int& i1
 
 // one block (64 threads) per batch item; thread q handles query q (Q <= 1024 via loop)
 __global__ void pp_class_kernel(const float* logits, float* probs, float* scores, int32_t* labels, int32_t* kept_idx,
-                                int32_t* n_keep, int Q, int C, float thr) {
+                                int32_t* n_keep, int Q, int C, float thr, int32_t* area, int32_t* orig) {
   const int b = blockIdx.x;
   __shared__ int keep_flag[1024];
+  // the pixel counters of pp_argmax_kernel start at zero: cleared here (no memset node between the kernels of the stage)
+  for (int q = threadIdx.x; q < Q; q += blockDim.x) area[b * Q + q] = orig[b * Q + q] = 0;
   for (int q = threadIdx.x; q < Q; q += blockDim.x) {
     const float* l = logits + ((int64_t)b * Q + q) * C;
     float mx = -INFINITY;
@@ -80,10 +84,20 @@ __global__ void pp_mask256_kernel(const float* ml, float* out, int BT, int IH, i
   out[idx] = 1.f / (1.f + expf(-v));
 }
 
+template <bool SYS>
 __device__ __forceinline__ float sample256(const float* p256, int64_t base, int MS, int Q, int q, int y0, int y1, int x0,
                                            int x1, float ly, float lx) {
-  const float v00 = p256[(base + (int64_t)y0 * MS + x0) * Q + q], v01 = p256[(base + (int64_t)y0 * MS + x1) * Q + q];
-  const float v10 = p256[(base + (int64_t)y1 * MS + x0) * Q + q], v11 = p256[(base + (int64_t)y1 * MS + x1) * Q + q];
+  // SYSTEM-SCOPE loads (sc0 sc1: past the caches).  Round 4 found pp_argmax_kernel reading STALE values of the mask-probability volume at
+  // B = 8 (419 MB, written by pp_mask256_kernel one launch earlier on the same stream): with six streams on the runtime's four hardware
+  // queues, one forward in four gave ~100 border pixels of item 0 (the first rows of the buffer) to a neighbouring segment, although the
+  // logits, the volume as read back afterwards and a recomputation on the same inputs were bit-identical.  Not reproducible with one
+  // stream or at B <= 2; an event between the two kernels, agent- and system-scope acquire fences at kernel start, a kernel instead of
+  // the memsets, a persistent buffer and reading a private copy of the logits did not help; these loads did (0 of 117 forwards against
+  // ~25 %).  The round-3 code shows the same flake at 2 % (1 of 50).  Root cause not established.
+#define SIU3R_LDP(i) (SYS ? __hip_atomic_load(&p256[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : p256[i])
+  const float v00 = SIU3R_LDP((base + (int64_t)y0 * MS + x0) * Q + q), v01 = SIU3R_LDP((base + (int64_t)y0 * MS + x1) * Q + q);
+  const float v10 = SIU3R_LDP((base + (int64_t)y1 * MS + x0) * Q + q), v11 = SIU3R_LDP((base + (int64_t)y1 * MS + x1) * Q + q);
+#undef SIU3R_LDP
   return (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
 }
 
@@ -113,7 +127,7 @@ __global__ __launch_bounds__(256) void pp_argmax_kernel(const float* p256, const
     int bk = 0;
     for (int k = 0; k < nk; ++k) {
       const int q = kept_idx[b * Q + k];
-      const float wv = sample256(p256, base, MS, Q, q, y0, y1, x0, x1, ly, lx) * scores[b * Q + q];
+      const float wv = sample256<true>(p256, base, MS, Q, q, y0, y1, x0, x1, ly, lx) * scores[b * Q + q];
       if (wv > best) {  // strict: first maximum wins, like torch.argmax
         best = wv;
         bk = k;
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(256) void pp_qcl_kernel(const float* p256, const fl
     src_idx(y, MS, H, y0, y1, ly);
     src_idx(x, MS, W, x0, x1, lx);
     q = kept_idx[b * Q + acc[b * Q + j]];
-    mp = sample256(p256, ((int64_t)b * T + t) * MS * MS, MS, Q, q, y0, y1, x0, x1, ly, lx);
+    mp = sample256<false>(p256, ((int64_t)b * T + t) * MS * MS, MS, Q, q, y0, y1, x0, x1, ly, lx);  // (the volume's writer finished a host synchronisation ago)
   }
   s_mp[threadIdx.x] = mp;
   s_q[threadIdx.x] = q;
@@ -246,12 +260,8 @@ extern "C" int siu3r_panoptic_stage1(const float* class_logits, const float* mas
   SIU3R_CHECK((int64_t)B * T * mask_size * mask_size * Q < 0x7fffffffll && (int64_t)T * H * W < 0x7fffffffll,
               "panoptic_stage1: mask volume / pixel count must stay below 2^31");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(pp_class_kernel, dim3(B), dim3(64), 0, s, class_logits, probs, scores, labels, kept_idx, n_keep, Q, C, threshold);
+  hipLaunchKernelGGL(pp_class_kernel, dim3(B), dim3(64), 0, s, class_logits, probs, scores, labels, kept_idx, n_keep, Q, C, threshold, area, orig);
   hipLaunchKernelGGL(pp_mask256_kernel, g1((int64_t)B * T * mask_size * mask_size * Q), dim3(256), 0, s, mask_logits_cl, p256, B * T, IH, IW, mask_size, Q);
-  if (hipMemsetAsync(area, 0, sizeof(int32_t) * B * Q, s) != hipSuccess || hipMemsetAsync(orig, 0, sizeof(int32_t) * B * Q, s) != hipSuccess) {
-    siu3r_set_error("panoptic_stage1: memset failed");
-    return 2;
-  }
   const int64_t npix = (int64_t)T * H * W;
   hipLaunchKernelGGL(pp_argmax_kernel, dim3((unsigned)cdiv64(npix, 256), B), dim3(256), 0, s, p256, scores, kept_idx, n_keep, lab_map, area, orig, T, H, W, mask_size, Q, mask_threshold);
   hipLaunchKernelGGL(pp_accept_kernel, g1(B, 64), dim3(64), 0, s, area, orig, kept_idx, n_keep, labels, scores, seg_id, seg_label, seg_fused, seg_score, acc_list, n_acc, Q, overlap, fuse_mask, B);

@@ -149,3 +149,31 @@ def test_config5_eight_views_two_million_gaussians_1080p():
     assert float(np.abs(dep - ref2["depth"]).max()) <= 5e-5 * max(1.0, float(ref2["depth"].max()))
     del model
     torch.cuda.empty_cache()
+
+
+def test_batch_of_eight_label_maps_are_run_to_run_identical():
+    """Round 4 regression: at B = 8 (six streams on four hardware queues, 419 MB mask-probability volume) one forward in four read stale
+    values of that volume in the panoptic argmax and moved ~100 border pixels of item 0 to a neighbouring segment, with bit-identical
+    logits.  Sixteen consecutive forwards must give identical segmentation / label maps (and logits)."""
+    from golden_utils import default_K, fixture_images
+    from siu3r_amd.model import SIU3RModel
+
+    B, S = 8, 512
+    g = torch.Generator().manual_seed(11)
+    fx_ = fixture_images(S)
+    img = torch.cat([fx_, torch.rand(B - 2, 2, 3, S, S, generator=g), fx_.flip(1)]).cuda()
+    K = default_K().repeat(B, 1, 1, 1).cuda()
+    model = SIU3RModel(_weights(), image_size=(S, S), precision="bf16x3")
+    ref, bad = None, []
+    with torch.no_grad():
+        for it in range(16):
+            o = model(img, K, enable_query_class_logit_lift=True)
+            torch.cuda.synchronize()
+            cur = (o[0].instance_labels.clone(), o[0].semantic_labels.clone(), torch.stack(list(o[2])).clone(), o[1].masks_queries_logits.clone())
+            if ref is None:
+                ref = cur
+            elif not all(torch.equal(a, b) for a, b in zip(cur, ref)):
+                bad.append((it, [int((a != b).sum()) for a, b in zip(cur, ref)]))
+    assert not bad, bad
+    del model
+    torch.cuda.empty_cache()
