@@ -26,7 +26,7 @@ extern "C" {
 #define SIU3R_F64 3
 
 const char* siu3r_last_error(void);
-#define SIU3R_ABI_VERSION 5 /* 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
+#define SIU3R_ABI_VERSION 6 /* 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok); 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
 int siu3r_abi_version(void);
 
 /* ---- seam 1: curope.rope_2d(tokens, positions, base, fwd)
@@ -114,6 +114,16 @@ typedef struct {
   int32_t tile_cfg;               /* 0 = the launcher decides; SIU3R_TILE_* forces a kernel family / tile (tools, tests) */
   int32_t m_main;                 /* internal (launcher): rows covered by the tiled kernel when a skinny launch multiplies the last <= 32 rows */
   int32_t sk_gx;                  /* internal (launcher): > 0 = the ping-pong launch carries the remainder rows itself, as workgroups blockIdx.x >= sk_gx */
+  /* Pre-split bf16x3 activations.  A bf16x3 product multiplies hi = the upper 16 bits of every fp32 activation and lo = bf16(a - hi);
+     the ping-pong kernels normally derive both inside their K loop, which costs 12-18 % of a launch.  c_x3 != NULL: the epilogue ALSO
+     writes the (fp32, post-activation, post-residual) output as those two planes, interleaved per 32 columns like w_x3 -- row m at the
+     byte offset of row m of c, then [n / 32][hi 32 | lo 32] bf16: a buffer of the size and strides of the fp32 output; c may then be
+     NULL (planes only).  a_x3 != 0: `a` points at such planes (dense A only, k % 64 == 0, lda and the batch strides multiples of 32):
+     same products in the same order as with the fp32 operand, hence bit-identical results.  Both need a ping-pong plan and the common
+     output form (siu3r_gemm_plan_t.a_x3_ok / c_x3_ok say whether the plan of THIS block can consume / emit planes; siu3r_gemm fails
+     loudly otherwise). */
+  void* c_x3;
+  int32_t a_x3;
 } siu3r_gemm_params;
 #define SIU3R_TILE_AUTO 0
 #define SIU3R_TILE_128x64 -1   /* the 128 x 64 LDS-DMA / register-staged kernels (gemm_dma.hip, gemm.hip) */
@@ -128,6 +138,7 @@ typedef struct {
   int32_t tile_cfg, bm, bn, splitk, skinny_rows, counters;
   int64_t ws_floats;
   char kernel[160];
+  int32_t a_x3_ok, c_x3_ok; /* this plan can read A as pre-split planes (a_x3) / write the output as planes (c_x3) */
 } siu3r_gemm_plan_t;
 int siu3r_gemm_plan(const siu3r_gemm_params* p, siu3r_gemm_plan_t* out);
 /* tuning aid (tools/, tests): key 0 = process-wide default of siu3r_gemm_params.tile_cfg (SIU3R_TILE_*; also env SIU3R_GEMM_PP), key 1 =

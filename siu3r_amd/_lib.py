@@ -39,6 +39,7 @@ class GemmParams(C.Structure):
         ("c_aux", C.c_void_p),
         ("splitk", C.c_int32), ("sk_ws", C.c_void_p), ("sk_cnt", C.c_void_p),
         ("sk_ws_floats", C.c_int64), ("sk_cnt_n", C.c_int32), ("tile_cfg", C.c_int32), ("m_main", C.c_int32), ("sk_gx", C.c_int32),
+        ("c_x3", C.c_void_p), ("a_x3", C.c_int32),
     ]
 
 
@@ -46,7 +47,7 @@ class GemmPlan(C.Structure):
     """siu3r_gemm_plan_t: what siu3r_gemm launches for a parameter block."""
     _fields_ = [
         ("tile_cfg", C.c_int32), ("bm", C.c_int32), ("bn", C.c_int32), ("splitk", C.c_int32), ("skinny_rows", C.c_int32),
-        ("counters", C.c_int32), ("ws_floats", C.c_int64), ("kernel", C.c_char * 160),
+        ("counters", C.c_int32), ("ws_floats", C.c_int64), ("kernel", C.c_char * 160), ("a_x3_ok", C.c_int32), ("c_x3_ok", C.c_int32),
     ]
 
 
@@ -83,7 +84,7 @@ class RasterCam(C.Structure):
 
 # name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/siu3r_hip.h.
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
-ABI_VERSION = 5  # SIU3R_ABI_VERSION of include/siu3r_hip.h these ctypes declarations mirror
+ABI_VERSION = 6  # SIU3R_ABI_VERSION of include/siu3r_hip.h these ctypes declarations mirror
 
 SIGNATURES = {
     "siu3r_last_error": [],

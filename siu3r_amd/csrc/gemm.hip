@@ -26,6 +26,8 @@ void siu3r_gemm_pp_name(const siu3r_gemm_params& p, int cfg, char* buf, int n);
 int siu3r_gemm_pp_launch(const siu3r_gemm_params& p, int cfg, void* stream);
 int siu3r_gemm_skinny_launch(const siu3r_gemm_params& p, void* stream);
 bool siu3r_gemm_pp_folds_skinny(const siu3r_gemm_params& p);
+bool siu3r_gemm_pp_a_x3_ok(const siu3r_gemm_params& p);          // pre-split A planes readable / output planes writable by a ping-pong launch
+bool siu3r_gemm_pp_c_x3_ok(const siu3r_gemm_params& p, int cfg);
 static const bool g_disable_dma = getenv("SIU3R_GEMM_NO_DMA") != nullptr;     // debugging / A-B switch
 // 128x64 tiles (two workgroups per CU) beat 128x128 (one per CU: 96 KiB ring) at every size measured on gfx950 --
 // finer wave quantisation and a second workgroup to overlap prologue/epilogue; 128x128 stays reachable for A/B runs
@@ -484,7 +486,7 @@ void plan(const siu3r_gemm_params& p, siu3r_gemm_plan_t& pl) {
 // parameter validation shared by siu3r_gemm and siu3r_gemm_plan (the plan divides by the conv geometry: a malformed block must come
 // back as an error string from both, not as SIGFPE from the query)
 static int validate_gemm(const siu3r_gemm_params& p) {
-  SIU3R_CHECK(p.a && p.w_hi && p.c, "siu3r_gemm: null operand pointer");
+  SIU3R_CHECK(p.a && p.w_hi && (p.c || p.c_x3), "siu3r_gemm: null operand pointer");
   SIU3R_CHECK(p.m > 0 && p.n > 0 && p.k > 0, "siu3r_gemm: empty problem (m=%d n=%d k=%d)", p.m, p.n, p.k);
   SIU3R_CHECK(p.kpad % BK == 0 && p.kpad >= p.k, "siu3r_gemm: kpad=%d must be a multiple of 64 and >= k=%d", p.kpad, p.k);
   SIU3R_CHECK(p.a_dtype == SIU3R_BF16 || p.a_dtype == SIU3R_F32, "siu3r_gemm: bad a_dtype %d", p.a_dtype);
@@ -525,6 +527,8 @@ extern "C" int siu3r_gemm_plan(const siu3r_gemm_params* pp, siu3r_gemm_plan_t* o
   SIU3R_CHECK(pp && out, "siu3r_gemm_plan: null argument");
   if (int rc = validate_gemm(*pp)) return rc;
   plan(*pp, *out);
+  out->a_x3_ok = out->tile_cfg > 0 && siu3r_gemm_pp_a_x3_ok(*pp);
+  out->c_x3_ok = out->tile_cfg > 0 && siu3r_gemm_pp_c_x3_ok(*pp, out->tile_cfg);
   return 0;
 }
 
@@ -534,6 +538,12 @@ extern "C" int siu3r_gemm(const siu3r_gemm_params* pp, void* stream) {
   siu3r_gemm_plan_t pl;
   plan(p, pl);
   hipStream_t s = (hipStream_t)stream;
+  // pre-split planes exist on the ping-pong path only: anything else would read / leave garbage
+  SIU3R_CHECK(!p.a_x3 || (pl.tile_cfg > 0 && siu3r_gemm_pp_a_x3_ok(p)), "siu3r_gemm: a_x3 (pre-split A planes) needs a ping-pong plan, bf16x3 weights, dense A, "
+              "k == kpad and lda / batch strides %% 32 == 0 (this block runs %s): query siu3r_gemm_plan_t.a_x3_ok first", pl.kernel);
+  SIU3R_CHECK(!p.c_x3 || (pl.tile_cfg > 0 && siu3r_gemm_pp_c_x3_ok(p, pl.tile_cfg)), "siu3r_gemm: c_x3 (output planes) needs a ping-pong plan and the plain fp32 "
+              "row-major output form with n %% 64 == 0, ldc / batch strides %% 32 == 0 (this block runs %s): query siu3r_gemm_plan_t.c_x3_ok first", pl.kernel);
+  SIU3R_CHECK(p.c || p.c_x3, "siu3r_gemm: null output");
   siu3r_gemm_params q = p;
   q.splitk = pl.splitk;
   if (pl.splitk > 1) SIU3R_CHECK(p.sk_ws && p.sk_cnt && p.sk_ws_floats >= pl.ws_floats && p.sk_cnt_n >= pl.counters,

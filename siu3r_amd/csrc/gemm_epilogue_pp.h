@@ -131,7 +131,11 @@ __device__ __forceinline__ void wave_rows_fast(const siu3r_gemm_params& p, f32x1
   }
   constexpr unsigned OOB = 0x80000000u;  // beyond num_records: the store is dropped, the load returns 0
   const bool res_bf = p.r_dtype == SIU3R_BF16;
-  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned char*)p.c + (zof.c + (int64_t)row_w0 * p.ldc) * (BF ? 2 : 4)), (short)0, 0x7fffffff, 0x00020000);
+  // c_x3: the output ALSO (or, c == NULL, only) as pre-split bf16x3 planes for the next GEMM's A operand (siu3r_hip.h): same row offsets
+  // as the fp32 output, a 32-column segment = one 128-byte line [hi 32 | lo 32]
+  const bool st_c = p.c != nullptr, x3o = !BF && p.c_x3 != nullptr;
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned char*)(st_c ? p.c : p.c_x3) + (zof.c + (int64_t)row_w0 * p.ldc) * (BF ? 2 : 4)), (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned char*)(x3o ? p.c_x3 : p.c) + (zof.c + (int64_t)row_w0 * p.ldc) * 4), (short)0, x3o ? 0x7fffffff : 0, 0x00020000);
   const bool has_res = p.residual != nullptr;
   const int r_esz = res_bf ? 2 : 4;
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
@@ -188,11 +192,13 @@ __device__ __forceinline__ void wave_rows_fast(const siu3r_gemm_params& p, f32x1
           f32x4_t r_lo[HOIST ? 4 : 1], r_hi[HOIST ? 4 : 1];
           int pos0[4], pos1[4];
           unsigned coff[4];
+          bool rok[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int lr = i * 32 + k * 8 + prow;
             const bool ok = row_w0 + lr < M;
-            coff[k] = ok ? (unsigned)((lr * (int)p.ldc + n_lo) * (BF ? 2 : 4)) : OOB;
+            rok[k] = ok;
+            coff[k] = (ok && st_c) ? (unsigned)((lr * (int)p.ldc + n_lo) * (BF ? 2 : 4)) : OOB;
             if constexpr (HOIST) {
               const unsigned roff = ok ? (unsigned)((lr * (int)p.ldr + n_lo) * r_esz) : OOB;
               load_res(roff, r_lo[k], r_hi[k]);
@@ -307,7 +313,7 @@ __device__ __forceinline__ void wave_rows_fast(const siu3r_gemm_params& p, f32x1
                 v_hi[e] += r_hi[k][e];
               }
             } else if (has_res) {
-              const unsigned roff = coff[k] != OOB ? (unsigned)((lr * (int)p.ldr + n_lo) * r_esz) : OOB;
+              const unsigned roff = rok[k] ? (unsigned)((lr * (int)p.ldr + n_lo) * r_esz) : OOB;
               f32x4_t a_, b_;
               load_res(roff, a_, b_);
 #pragma unroll
@@ -332,7 +338,7 @@ __device__ __forceinline__ void wave_rows_fast(const siu3r_gemm_params& p, f32x1
               s2 += __shfl_xor(s2, 1);
               s2 += __shfl_xor(s2, 2);
               s2 += __shfl_xor(s2, 4);
-              if (c == 0 && coff[k] != OOB) {
+              if (c == 0 && rok[k]) {
                 const int64_t row = (int64_t)zof.zo * p.st_sz + (int64_t)zof.zi * p.st_sz_i + (int64_t)(row_w0 + lr) * p.st_ldm;
                 ((float2*)p.stats_out)[row * (N >> 6) + (g0 >> 6)] = make_float2(mean, s2);
               }
@@ -346,7 +352,47 @@ __device__ __forceinline__ void wave_rows_fast(const siu3r_gemm_params& p, f32x1
               __builtin_amdgcn_raw_buffer_store_b128(w, rc, coff[k], 0, 0);
             } else {
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v_lo), rc, coff[k], 0, 0);
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v_hi), rc, coff[k], 128, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v_hi), rc, coff[k] + 128, 0, 0);  // (immediate offset: see the plane stores below)
+              if (x3o) {
+                // hi = upper 16 bits, lo = bf16(v - hi): the expressions of the K loop's in-register split (gemm_pp_kernel.h), so that a
+                // consumer of the planes multiplies bit-identical operands.  A lane holds 4 values of each of the group's two segments =
+                // 8 bytes of a plane; lane pairs (c, c ^ 1) trade halves so that the even lane stores 16 bytes of the hi plane and the odd
+                // lane 16 bytes of the lo plane: 8 lanes x 16 B = the row's full 128-byte segment line per store instruction
+                const bool odd = (c & 1) != 0;
+                const unsigned xoff = rok[k] ? (unsigned)((lr * (int)p.ldc + g0) * 4 + (odd ? 64 : 0) + 8 * (c & ~1)) : OOB;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                  const f32x4_t v = hh == 0 ? v_lo : v_hi;
+                  unsigned int b[4], hi2[2], lo2[2];
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const float f = v[e];  // (a copy: __builtin_bit_cast of the vector ELEMENT lvalue read element 0 for every e)
+                    b[e] = __float_as_uint(f);
+                  }
+#pragma unroll
+                  for (int e = 0; e < 2; ++e) {
+                    hi2[e] = __builtin_amdgcn_perm(b[2 * e + 1], b[2 * e], 0x07060302u);
+                    lo2[e] = pack_bf16x2(__uint_as_float(b[2 * e]) - __uint_as_float(b[2 * e] & 0xffff0000u), __uint_as_float(b[2 * e + 1]) - __uint_as_float(b[2 * e + 1] & 0xffff0000u));
+                  }
+                  unsigned int mine[2], got[2];
+#pragma unroll
+                  for (int e = 0; e < 2; ++e) {
+                    mine[e] = odd ? lo2[e] : hi2[e];
+                    got[e] = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(odd ? hi2[e] : lo2[e]), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+                  }
+                  u32x4_t w;
+                  w[0] = odd ? got[0] : mine[0];
+                  w[1] = odd ? got[1] : mine[1];
+                  w[2] = odd ? mine[0] : got[0];
+                  w[3] = odd ? mine[1] : got[1];
+                  // (the second line's +128 goes into the instruction's IMMEDIATE offset, not into soffset: with an SGPR soffset hipcc assumes
+                  // that a 16-byte store's data registers may be overwritten by the very next VALU instruction -- the ISA manual says so --
+                  // and the next row group's LDS address landed in w[0] of lanes 12..15 of every row of 16 before the store had read it:
+                  // 448 wrong plane words of 4 M on the 256 x 256 tile, none on 256 x 128.  With an immediate offset the compiler keeps its
+                  // wait state.)
+                  __builtin_amdgcn_raw_buffer_store_b128(w, rx, xoff + hh * 128, 0, 0);
+                }
+              }
             }
           }
         }

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(512, 2) void gemm_skinny_kernel(const siu3r_gemm_pa
 // A matrix-vector product has no use for MFMA: the W panel is the only traffic, and the fragment-shaped loads of the kernel above fetch
 // it as 64 scattered 16-byte pieces per instruction (12.8 us at K = 1024, ~40 at K = 4096 -- which kept fc2 on a ninth row of tiles).  Here a wave streams each W row in fully coalesced 1 KiB loads (8 columns' worth of one chunk in flight behind the 8 being
 // consumed), the <= 4 A rows sit in LDS as fp32 and are read once per chunk for all 8 columns, products are plain fp32 FMAs of the
-// exact operands (bf16x3: a * w_hi and a * w_lo accumulate separately -- no rounding of A at all), a lane-level partial sum per
+// operands (bf16x3: a = hi + lo as the MFMA path splits it; a * w_hi and a * w_lo accumulate separately), a lane-level partial sum per
 // (column, row) is reduced across the wave at the end, and wave 0 hands the 64-column block to the common row pass in accumulator layout.
 constexpr int GV_ROWS = 4, GV_KMAX = 4096;
 template <bool X3, bool LNF>
@@ -41,8 +41,20 @@ __global__ __launch_bounds__(512) void gemm_skinny_gemv_kernel(const siu3r_gemm_
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < K) {  // K % 4 == 0 (launcher)
       const unsigned char* src = Ab + ((int64_t)(row0 + r) * p.lda + k) * ESZ;
-      if (X3) {
+      if (X3 && p.a_x3) {  // pre-split planes: a = hi + lo (the 16-bit-mantissa value the MFMA path multiplies)
+        const unsigned char* seg = Ab + (int64_t)(row0 + r) * p.lda * 4 + (k >> 5) * 128 + (k & 31) * 2;
+        const uint2 h = *(const uint2*)seg, l = *(const uint2*)(seg + 64);
+        v = make_float4(__uint_as_float(h.x << 16) + __uint_as_float(l.x << 16), __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u),
+                        __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16), __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u));
+      } else if (X3) {
+        // (the same value from fp32 rows: hi + bf16(a - hi), so that a launch gives the same bits whichever form its A operand has)
         v = *(const float4*)src;
+        float* vf = (float*)&v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float hi = __uint_as_float(__float_as_uint(vf[e]) & 0xffff0000u);
+          vf[e] = hi + __uint_as_float(pack_bf16x2(vf[e] - hi, 0.f) << 16);
+        }
       } else {
         const uint2 u = *(const uint2*)src;
         v = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
@@ -165,8 +177,26 @@ int siu3r_gemm_pp_mode(const siu3r_gemm_params& p) {
 void siu3r_gemm_pp_name(const siu3r_gemm_params& p, int cfg, char* buf, int n) {
   const bool x3 = p.w_x3 != nullptr && p.a_dtype == SIU3R_F32;
   const int mode = siu3r_gemm_pp_mode(p);
-  snprintf(buf, n, "siu3r_gemm_pp::gemm_pp_kernel<%s, %d, %d, %d, %s, %s>", x3 ? "true" : "false", cfg == 3 ? 1 : 2, cfg == 1 ? 4 : 2, mode,
-           (mode == 1 && p.relu_in) ? "true" : "false", (mode == 0 && p.ln_stats) ? "true" : "false");
+  snprintf(buf, n, "siu3r_gemm_pp::gemm_pp_kernel<%s, %d, %d, %d, %s, %s%s>", x3 ? "true" : "false", cfg == 3 ? 1 : 2, cfg == 1 ? 4 : 2, mode,
+           (mode == 1 && p.relu_in) ? "true" : "false", (mode == 0 && p.ln_stats) ? "true" : "false", (x3 && mode == 0 && p.a_x3) ? ", true" : "");
+}
+
+// can a ping-pong launch of this problem read A as pre-split planes (siu3r_gemm_params.a_x3)?  bf16x3, dense rows, whole 64-deep K
+// tiles (no zero-padded tail inside a [hi 32 | lo 32] segment), rows and batch items that start on a segment boundary
+bool siu3r_gemm_pp_a_x3_ok(const siu3r_gemm_params& p) {
+  const bool x3 = p.w_x3 != nullptr && p.a_dtype == SIU3R_F32;
+  return x3 && siu3r_gemm_pp_mode(p) == 0 && p.k == p.kpad && p.lda % 32 == 0 && p.sa % 32 == 0 && p.sa_i % 32 == 0 && ((uintptr_t)p.a % 16) == 0;
+}
+// can it write its output as planes (c_x3)?  The fast fp32 row pass of gemm_epilogue_pp.h must be the one that runs (wave_rows()'s
+// conditions, for every batch item), and rows / batch items must start on a segment boundary
+bool siu3r_gemm_pp_c_x3_ok(const siu3r_gemm_params& p, int cfg) {
+  if (siu3r_epi_pp::g_force_general || siu3r_gemm_pp_mode(p) < 0) return false;
+  const int MI_ = cfg == 3 ? 1 : 2;
+  const int64_t res_b = p.r_dtype == SIU3R_F32 ? 4 : 2;
+  const bool res_ok = !p.residual || (p.r_dtype == SIU3R_F32 && (p.ldr * res_b) % 16 == 0 && ((uintptr_t)p.residual % 16) == 0 && (p.sr * res_b) % 16 == 0 &&
+                                       (p.sr_i * res_b) % 16 == 0 && (int64_t)(32 * MI_) * p.ldr < (1 << 28));
+  return p.out_mode == 0 && !p.up_src && !p.c_aux && p.c_dtype == SIU3R_F32 && p.n % 64 == 0 && (int64_t)(32 * MI_) * p.ldc < (1 << 28) && res_ok &&
+         p.ldc % 32 == 0 && p.sc % 32 == 0 && p.sc_i % 32 == 0 && ((uintptr_t)p.c % 16) == 0 && ((uintptr_t)p.c_x3 % 16) == 0;
 }
 
 // tiled launch with tile cfg (SIU3R_TILE_PP_*); p.splitk, p.m_main as planned

@@ -73,6 +73,8 @@ __device__ __forceinline__ void skinny_rows_body(const siu3r_gemm_params& p, uns
   if (m > M - 1) m = M - 1;
   // k16 steps; A: the lane half's 8 values of row m; W: rows n0, n0 + 32 (bf16x3: hi and lo halves of the [hi 32 | lo 32] segment)
   const unsigned a_voff = (unsigned)((int64_t)m * p.lda * ESZ + lh * (8 * ESZ));
+  const bool aps = X3 && p.a_x3 != 0;  // (wave-uniform)
+  const unsigned a_voff_ps = (unsigned)((int64_t)m * p.lda * ESZ + lh * 16);
   unsigned w_voff[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -94,7 +96,11 @@ __device__ __forceinline__ void skinny_rows_body(const siu3r_gemm_params& p, uns
     for (int u = 0; u < 4; ++u) {
       const int sg = s0 + u;
       const bool kin = sg * 16 + lh * 8 < K;  // (K % 8 == 0; W is zero padded, A must not be read beyond K)
-      if (X3) {
+      if (X3 && aps) {  // pre-split A: the lane half's 8 hi and 8 lo values of the step in the [hi 32 | lo 32] segment (same addressing as W)
+        const int so = (sg >> 1) * 128 + (sg & 1) * 32;
+        fa[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rA, a_voff_ps, so, 0);
+        fa[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rA, a_voff_ps + 64, so, 0);
+      } else if (X3) {
         fa[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rA, kin ? a_voff : OOB, sg * 64, 0);
         fa[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rA, kin ? a_voff + 16 : OOB, sg * 64, 0);
       } else {
@@ -116,11 +122,16 @@ __device__ __forceinline__ void skinny_rows_body(const siu3r_gemm_params& p, uns
       union U8 { u32x4 u; bf16x8 h; };
       if (X3) {
         U8 ah, al, bh[2], bl[2];
+        if (aps) {
+          ah.u = fa[u][0];
+          al.u = fa[u][1];
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const unsigned int x0 = e < 2 ? fa[u][0][2 * e] : fa[u][1][2 * e - 4], x1 = e < 2 ? fa[u][0][2 * e + 1] : fa[u][1][2 * e - 3];
-          ah.u[e] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
-          al.u[e] = pack_bf16x2(__uint_as_float(x0) - __uint_as_float(x0 & 0xffff0000u), __uint_as_float(x1) - __uint_as_float(x1 & 0xffff0000u));
+          for (int e = 0; e < 4; ++e) {
+            const unsigned int x0 = e < 2 ? fa[u][0][2 * e] : fa[u][1][2 * e - 4], x1 = e < 2 ? fa[u][0][2 * e + 1] : fa[u][1][2 * e - 3];
+            ah.u[e] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+            al.u[e] = pack_bf16x2(__uint_as_float(x0) - __uint_as_float(x0 & 0xffff0000u), __uint_as_float(x1) - __uint_as_float(x1 & 0xffff0000u));
+          }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -171,7 +182,11 @@ __device__ __forceinline__ void skinny_rows_body(const siu3r_gemm_params& p, uns
 #endif
 }
 
-template <bool X3, int MI, int NJ, int MODE, bool RELU, bool LNF>
+// APS (bf16x3, dense A): the A operand arrives PRE-SPLIT -- hi | lo bf16 planes interleaved per 32 K elements exactly like w_x3, written
+// by the producing GEMM's epilogue (siu3r_gemm_params.c_x3) -- so A pieces and A fragments are addressed like W's and the MFMA phase
+// carries no conversion: the in-loop split (48 VALU per 12 MFMAs on a SIMD two waves share) costs 12-18 % of a launch
+// (tools/ab_split.sh, profiles/r04_nosplit_ablation.txt).  Same products in the same order: bit-identical results.
+template <bool X3, int MI, int NJ, int MODE, bool RELU, bool LNF, bool APS = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params p) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int BM = 128 * MI, BN = 64 * NJ;
@@ -183,6 +198,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params
   constexpr int KSTEP = X3 ? 16 : 32;                             // K elements per step
   constexpr int CK = 16 / ESZ;                                    // A elements per 16-byte chunk
   static_assert(NJ % 2 == 0, "W pieces are dealt to whole waves");
+  static_assert(!APS || (X3 && MODE == 0 && !RELU), "pre-split A: bf16x3, dense rows");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[smem_bytes<MI, NJ>()];
   static_assert(smem_bytes<MI, NJ>() >= SKINNY_SMEM_BYTES, "the folded remainder-row workgroups use the ring's LDS");
 
@@ -248,7 +264,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params
     a_voff[i] = a_mask[i] = 0;
     a_iy0[i] = a_ix0[i] = 0;
     if (MODE == 0) {
-      a_voff[i] = (unsigned)((int64_t)m * p.lda * ESZ + q * 16);
+      // (pre-split: logical chunks 0,1 = the step's 16 hi values, 2,3 = its 16 lo values, 64 bytes further in the segment)
+      a_voff[i] = (unsigned)((int64_t)m * p.lda * ESZ + q * 16 + ((APS && q >= 2) ? 32 : 0));
     } else {
       const int ohw = p.oh * p.ow;
       const int b = m / ohw, rr = m - b * ohw;
@@ -330,7 +347,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params
     unsigned char* dstW = smem + stage * STAGE_BYTES + BM * 64 + wave * (W_PCS * 1024);
 #pragma unroll
     for (int i = 0; i < A_PCS; ++i) {
-      if (MODE == 0) {
+      if (MODE == 0 && APS) {  // (kpad == K: no tail)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(dstA + i * 1024), 16, a_voff[i], (sg >> 1) * 128 + (sg & 1) * 32, 0, 0);
+      } else if (MODE == 0) {
         unsigned voff = a_voff[i];
         if (ktail && sg >= ks_tail0) voff = (sg * KSTEP + q * CK < K) ? voff : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(dstA + i * 1024), 16, voff, sg * 64, 0, 0);
@@ -365,7 +384,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params
   const int fsw = (l31 >> 2) & 3;
   const unsigned int rowA = (wm * (32 * MI) + l31) * 64, rowB = BM * 64 + (wn * (32 * NJ) + l31) * 64;
   // x3: A chunks (2 lh, 2 lh + 1) = the lane half's 8 fp32; W chunks lh (hi) and 2 + lh (lo).  bf16: chunks lh (k-substep 0), 2 + lh (1)
-  const unsigned int offA0 = rowA + (((X3 ? 2 * lh : lh) ^ fsw) << 4), offA1 = rowA + (((X3 ? 2 * lh + 1 : 2 + lh) ^ fsw) << 4);
+  // (pre-split A: chunks lh (hi) and 2 + lh (lo), as W)
+  const unsigned int offA0 = rowA + ((((X3 && !APS) ? 2 * lh : lh) ^ fsw) << 4), offA1 = rowA + ((((X3 && !APS) ? 2 * lh + 1 : 2 + lh) ^ fsw) << 4);
   const unsigned int offB0 = rowB + ((lh ^ fsw) << 4), offB1 = rowB + (((2 + lh) ^ fsw) << 4);
 
   u32x4 fa[SPP][MI][2], fb[SPP][NJ][2];  // [step of the phase][block][x3: fp32 halves / hi,lo planes; bf16: k-substep]
@@ -493,7 +513,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params
           const unsigned int x0 = relu(raw(i, 2 * e)), x1 = relu(raw(i, 2 * e + 1));
           al[i].u[e] = pack_bf16x2(__uint_as_float(x0) - __uint_as_float(x0 & 0xffff0000u), __uint_as_float(x1) - __uint_as_float(x1 & 0xffff0000u));
         };
-        if constexpr ((dbg & 8) != 0) {
+        constexpr bool nosplit = APS || (dbg & 8) != 0;
+        if constexpr (nosplit) {
 #pragma unroll
           for (int i = 0; i < MI; ++i) {
             ah[i].u = fa[u][i][0];
@@ -512,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params
         for (int g = 0; g < 2 * NM; ++g) {
           const int r = g / NM, ij = g % NM, i = ij / NJ, j = ij % NJ;
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].h, bh[j][r], acc[i][j], 0, 0, 0);
-          if constexpr (!(dbg & 8)) {
+          if constexpr (!nosplit) {
             const int p0 = g * NP / (2 * NM), p1 = (g + 1) * NP / (2 * NM);  // pairs dealt evenly over the 2 NM MFMAs
 #pragma unroll
             for (int pp = p0; pp < p1; ++pp) lo_pair(pp / 4, pp % 4);

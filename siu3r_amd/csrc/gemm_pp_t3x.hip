@@ -7,7 +7,10 @@ void siu3r_gemm_pp_go_t3x(const siu3r_gemm_params& p, int mode, bool lnf, dim3 g
   using namespace siu3r_gemm_pp;
   const dim3 block(512);
 #define SIU3R_PP_GO(MODE_, RELU_, LNF_) hipLaunchKernelGGL((gemm_pp_kernel<true, 1, 2, MODE_, RELU_, LNF_>), grid, block, 0, s, p)
-  if (mode == 0 && lnf) SIU3R_PP_GO(0, false, true);
+  if (mode == 0 && p.a_x3) {  // pre-split A operand (hi | lo planes from the producer's epilogue)
+    if (lnf) hipLaunchKernelGGL((gemm_pp_kernel<true, 1, 2, 0, false, true, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_pp_kernel<true, 1, 2, 0, false, false, true>), grid, block, 0, s, p);
+  } else if (mode == 0 && lnf) SIU3R_PP_GO(0, false, true);
   else if (mode == 0) SIU3R_PP_GO(0, false, false);
   else if (mode == 1 && p.relu_in) SIU3R_PP_GO(1, true, false);
   else if (mode == 1) SIU3R_PP_GO(1, false, false);

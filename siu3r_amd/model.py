@@ -210,18 +210,43 @@ class AsymmetricCroCo:
         """Block.forward (blocks.py:127-130) in 5 launches: norm1 / norm2 ride in the QKV / fc1 GEMMs (ops.pack_linear_ln), the
         proj / fc2 GEMMs write the new residual stream, its row statistics and its bf16 copy.  S = (x fp32, RowStats, bf16 copy)."""
         ctx = self.ctx
-        x, xs, xb = S
+        x, xs, xb = S[:3]
         Z, N, Cc = x.shape
-        A = x if ctx.split else xb
-        qkv = ops.linear(A, ctx.w.linear_ln(p + ".attn.qkv", p + ".norm1"), out_dtype=ctx.act, ln=xs,
+        if ctx.split:
+            return self._enc_block_presplit(p, S, pos, rope)
+        qkv = ops.linear(xb, ctx.w.linear_ln(p + ".attn.qkv", p + ".norm1"), out_dtype=ctx.act, ln=xs,
                          rope=(rope[0], rope[1], pos, 2 * Cc)).view(Z, N, 3, ENC_HEADS, Cc // ENC_HEADS)
         a = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], heads=ENC_HEADS, head_dim=Cc // ENC_HEADS, scale=(Cc // ENC_HEADS) ** -0.5, split3=ctx.split)
         x1, s1, b1 = self._new_stream(x)
         ops.linear(a, ctx.w.linear(p + ".attn.proj"), residual=x, out=x1, stats_out=s1, aux_out=b1)
-        h = ops.linear(x1 if ctx.split else b1, ctx.w.linear_ln(p + ".mlp.fc1", p + ".norm2"), out_dtype=ctx.act, act=ACT_GELU, ln=s1)
+        h = ops.linear(b1, ctx.w.linear_ln(p + ".mlp.fc1", p + ".norm2"), out_dtype=ctx.act, act=ACT_GELU, ln=s1)
         x2, s2, b2 = self._new_stream(x)
         ops.linear(h, ctx.w.linear(p + ".mlp.fc2"), residual=x1, out=x2, stats_out=s2, aux_out=b2)
         return x2, s2, b2
+
+    def _enc_block_presplit(self, p, S, pos, rope):
+        """the same block in the bf16x3 mode: the GEMMs that write the residual stream (proj, fc2) also write it PRE-SPLIT (ops.Planes: the
+        hi | lo bf16 planes a bf16x3 product multiplies), fc1 writes its GELU output as planes only, and QKV / fc1 / fc2 read planes -- the
+        ping-pong kernel's in-loop split of the fp32 A operand is 12-18 % of those launches.  Every use is conditional on the launch's own
+        plan (ops.linear: a_planes / planes_out), results are bit-identical either way.  S = (x fp32, RowStats, None, Planes | None)."""
+        ctx = self.ctx
+        x, xs, _, xp = S if len(S) == 4 else (*S, None)
+        Z, N, Cc = x.shape
+        qkv = ops.linear(x, ctx.w.linear_ln(p + ".attn.qkv", p + ".norm1"), out_dtype=ctx.act, ln=xs, a_planes=xp,
+                         rope=(rope[0], rope[1], pos, 2 * Cc)).view(Z, N, 3, ENC_HEADS, Cc // ENC_HEADS)
+        a = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], heads=ENC_HEADS, head_dim=Cc // ENC_HEADS, scale=(Cc // ENC_HEADS) ** -0.5, split3=True)
+        x1, s1, _ = self._new_stream(x)
+        xp1 = ops.Planes(x1)
+        ops.linear(a, ctx.w.linear(p + ".attn.proj"), residual=x, out=x1, stats_out=s1, planes_out=xp1)
+        x2, s2, _ = self._new_stream(x)
+        xp2 = ops.Planes(x2)
+        w1, w2 = ctx.w.linear_ln(p + ".mlp.fc1", p + ".norm2"), ctx.w.linear(p + ".mlp.fc2")
+        h = torch.empty((Z, N, w1.n), dtype=torch.float32, device=x.device)
+        hp = ops.Planes(h, storage=h)  # planes in place of the fp32 values when fc2 can read them (nothing else reads h)
+        fc2_reads_planes = bool(ops.linear(h, w2, residual=x1, out=x2, stats_out=s2, planes_out=xp2, dry_run=True).a_x3_ok)
+        ops.linear(x1, w1, act=ACT_GELU, ln=s1, a_planes=xp1, out=h, planes_out=hp if fc2_reads_planes else None, planes_only=True)
+        ops.linear(h, w2, residual=x1, out=x2, stats_out=s2, a_planes=hp if fc2_reads_planes else None, planes_out=xp2)
+        return x2, s2, None, xp2
 
     def _dec_block(self, p, x, y, xpos, ypos, rope, out=None):
         """DecoderBlock.forward (blocks.py:186-191); x, y are [B, N, C] fp32 strided views."""

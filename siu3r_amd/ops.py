@@ -5,6 +5,7 @@ arithmetic operation below runs in libsiu3r_hip.so.  No CPU fallback: non-GPU te
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -274,12 +275,35 @@ def gemm_tune(key: int, value: int):
     check(_lib.lib().siu3r_gemm_tune(key, value))
 
 
-def _gemm_launch(p: GemmParams, dev=None):
-    if p.splitk != 1:
+class Planes:
+    """Pre-split bf16x3 copy of an fp32 activation [..., C] (siu3r_gemm_params.c_x3 / a_x3): per row and 32 columns the upper 16 bits of
+    the 32 values, then bf16(value - upper): the two operands a bf16x3 product multiplies, which the ping-pong GEMM otherwise derives
+    inside its K loop (12-18 % of a launch).  Same size and strides as the fp32 tensor (`t`: opaque storage).  A producer writes them
+    when its plan can (`valid`), a consumer reads them when ITS plan can; otherwise both use the fp32 tensor."""
+
+    def __init__(self, like: torch.Tensor, storage: Optional[torch.Tensor] = None):
+        assert like.dtype == torch.float32
+        self.t = storage if storage is not None else torch.empty_like(like)
+        assert self.t.shape == like.shape and self.t.stride() == like.stride() and self.t.dtype == torch.float32
+        self.valid = False
+        self.only = False  # True: the fp32 tensor was NOT written (planes-only output)
+
+
+_NO_PRESPLIT = bool(os.environ.get("SIU3R_NO_PRESPLIT"))  # A/B switch: never emit / consume pre-split planes
+
+
+def _attach_workspace(p: GemmParams, dev=None):
+    """the split-K workspace of the current scope (the plan depends on its capacity)"""
+    if p.splitk != 1 and not p.sk_ws:
         wsp = _splitk_workspace(dev if dev is not None else torch.device("cuda", torch.cuda.current_device()))
         if wsp is not None:
             ws, cnt = wsp
             p.sk_ws, p.sk_cnt, p.sk_ws_floats, p.sk_cnt_n = ws.data_ptr(), cnt.data_ptr(), ws.numel(), cnt.numel()
+
+
+def _gemm_launch(p: GemmParams, dev=None):
+    if p.splitk != 1:
+        _attach_workspace(p, dev)
         if _sk_meter is not None:
             pl = gemm_plan(p)
             if pl.splitk > 1:
@@ -374,13 +398,18 @@ def _apply_ln_stats_aux(p: GemmParams, pw: PackedWeight, x, out, lda, ldc, strid
 def linear(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=ACT_NONE,
            residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, relu_in=False,
            rope=None, ln: Optional[RowStats] = None, stats_out: Optional[RowStats] = None, aux_out: Optional[torch.Tensor] = None,
-           splitk: int = 0):
+           splitk: int = 0, a_planes: Optional[Planes] = None, planes_out: Optional[Planes] = None, planes_only: bool = False,
+           dry_run: bool = False):
     """y[..., N] = act(x[..., K] @ W^T + b) (+ residual).  x / out / residual may be strided views whose last
     dim is contiguous and which decompose into Z batches of M rows (e.g. tokens[:, :-1]).
     rope = (cos, sin, positions int64 [rows, 2] contiguous, ncols): fused RoPE2D on output columns [0, ncols).
     ln: x holds UN-normalised rows and pw was packed by pack_linear_ln: the LayerNorm is applied in the epilogue from these row
     statistics.  stats_out: write the row statistics of the (fp32) output for a later ln=.  aux_out: a bf16 copy of the output.
-    splitk: siu3r_gemm_params.splitk (0 = the library decides, 1 = never, > 1 = exactly that many K slices)."""
+    splitk: siu3r_gemm_params.splitk (0 = the library decides, 1 = never, > 1 = exactly that many K slices).
+    a_planes: pre-split planes of x (Planes): read instead of x when they are valid and this launch's plan can (bit-identical result).
+    planes_out: Planes of the output, written when the plan can (planes_out.valid says so afterwards); planes_only: then do NOT write the
+    fp32 output (`out` stays untouched; planes_out.only = True).  dry_run: launch nothing, return the siu3r_gemm_plan_t of the launch as it
+    would be issued with fp32 A (its a_x3_ok / c_x3_ok tell whether planes could be consumed / emitted)."""
     _gpu(x, residual, out)
     assert x.shape[-1] == pw.k, (x.shape, pw.k)
     if out is None:
@@ -415,6 +444,28 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=AC
         p.rope_cos, p.rope_sin, p.rope_pos, p.rope_ncols = _p(cos), _p(sin), _p(pos), ncols
     _apply_ln_stats_aux(p, pw, x, out, lda, ldc, (bsa, 0, bsc, 0), ln, stats_out, aux_out)
     p.splitk = splitk
+    if dry_run or a_planes is not None or planes_out is not None:
+        _attach_workspace(p)
+        if planes_out is not None:
+            p.c_x3 = _p(planes_out.t)  # (alignment of the destination is part of c_x3_ok)
+        pl = gemm_plan(p)
+        p.c_x3 = None
+        if dry_run:
+            return pl
+        if a_planes is not None and a_planes.valid and not _NO_PRESPLIT:
+            assert a_planes.t.shape == x.shape and a_planes.t.stride() == x.stride()
+            if pl.a_x3_ok:
+                p.a, p.a_x3 = _p(a_planes.t), 1
+            else:
+                assert not a_planes.only, f"the fp32 operand of this GEMM was never written (planes only) and {pl.kernel.decode()} cannot read planes"
+        if planes_out is not None:
+            assert planes_out.t.shape == out.shape and planes_out.t.stride() == out.stride()
+            planes_out.valid = bool(pl.c_x3_ok) and not _NO_PRESPLIT
+            planes_out.only = planes_out.valid and planes_only
+            if planes_out.valid:
+                p.c_x3 = _p(planes_out.t)
+                if planes_only:
+                    p.c = None
     _gemm_launch(p)
     return out
 

@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 import torch
@@ -27,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(l, s), f"{s} declared in include/siu3r_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
     assert set(_lib.SIGNATURES) <= set(syms) | {"siu3r_last_error", "siu3r_abi_version"}
-    assert l.siu3r_abi_version() == _lib.ABI_VERSION == 5
+    assert l.siu3r_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_struct_layouts_match_c():
@@ -265,3 +266,15 @@ def test_batch_strided_views_host_logic():
     assert _batch_strided(seq[:1, :32].view(1, 4, 8, 8), 256) == 256  # one item: its stride does not matter
     with pytest.raises(AssertionError):
         _batch_strided(torch.zeros(2, 4, 8, 16)[..., :8], 256)  # rows that are not dense
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="needs the ROCm LLVM tools")
+def test_no_store_data_register_is_rewritten_without_a_wait_state():
+    """Round 4 found a 16-byte buffer store (SGPR soffset, hence no compiler-inserted s_nop) whose data register the NEXT instruction
+    rewrote: on gfx950 the store read the new value in lanes 12..15 of every row of 16 (448 wrong words of 4 M in the pre-split planes of
+    the 256 x 256 tile).  The round-3 build had 210 such sites in the ping-pong row pass; none may come back (tools/scan_store_hazard.py
+    walks the disassembly of every translation unit)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "scan_store_hazard.py"), "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == "total 0", r.stdout[-3000:]

@@ -963,3 +963,91 @@ def test_gemm_split_k(mode, tile):
         ops.set_plan_log(None)
         ops.gemm_tune(0, 0)
 
+
+
+def _planes_reference(x):
+    """the two bf16 planes a bf16x3 product multiplies, in the c_x3 layout [rows, C / 32, (hi 32 | lo 32)] as int16 bit patterns"""
+    x = x.detach().float().cpu().contiguous()
+    bits = x.view(torch.int32)
+    hi_f = (bits & -65536).view(torch.float32)
+    hi = (bits >> 16).to(torch.int16)
+    lo = (x - hi_f).to(torch.bfloat16).view(torch.int16)
+    R, C = x.shape
+    return torch.stack((hi.view(R, C // 32, 32), lo.view(R, C // 32, 32)), dim=2).reshape(R, C * 2)
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+def test_gemm_presplit_planes(cfg):
+    """Pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, ops.Planes) on every ping-pong tile: the producer's planes are the
+    exact hi / lo bit patterns of its fp32 output (tile rows, remainder rows, split-K launches alike); a consumer that reads them --
+    plain, with a folded LayerNorm, on the long-K matrix-vector remainder rows, from a planes-only GELU output -- returns the SAME BITS
+    as with the fp32 operand; and asking for planes where the plan cannot serve them fails loudly at the C ABI."""
+    import ctypes as C
+
+    from siu3r_amd import _lib
+
+    ops = _ops()
+    ops.gemm_tune(0, cfg)
+    try:
+        M, C0, C1 = 2050, 1024, 4096
+        a = gen(M, C0, seed=201).cuda()
+        r = gen(M, C0, seed=202).cuda()
+        pw = ops.pack_linear(gen(C0, C0, seed=203, scale=0.05).cuda(), gen(C0, seed=204).cuda(), True)
+        x1 = torch.empty(M, C0, device="cuda")
+        st = ops.RowStats(x1)
+        xp = ops.Planes(x1)
+        log = []
+        ops.set_plan_log(log)
+        ops.linear(a, pw, residual=r, out=x1, stats_out=st, planes_out=xp)
+        ops.set_plan_log(None)
+        assert xp.valid and not xp.only and log[-1].tile_cfg == cfg and log[-1].c_x3_ok == 1
+        check(f"presplit[{cfg}] producer (fp32 output unchanged)", x1, a.cpu() @ gen(C0, C0, seed=203, scale=0.05).t() + gen(C0, seed=204) + r.cpu(), TOL_F32)
+        got = xp.t.cpu().contiguous().view(torch.int16)
+        assert torch.equal(got, _planes_reference(x1)), "planes are not the hi / lo bit patterns of the fp32 output"
+        # consumers: folded LayerNorm + GELU (planes-only output) -> long-K GEMM with residual; each against the same launch on fp32 operands
+        gamma, beta = 1.0 + 0.3 * gen(C0, seed=205), gen(C0, seed=206)
+        w1 = ops.pack_linear_ln(gen(C1, C0, seed=207, scale=0.05).cuda(), gen(C1, seed=208).cuda(), gamma.cuda(), beta.cuda(), True)
+        w1.meta["ln_eps"] = 1e-6
+        w2 = ops.pack_linear(gen(C0, C1, seed=209, scale=0.05).cuda(), gen(C0, seed=210).cuda(), True)
+        h_ref = ops.linear(x1, w1, act=ops.ACT_GELU, ln=st)
+        h_a = ops.linear(x1, w1, act=ops.ACT_GELU, ln=st, a_planes=xp)
+        assert torch.equal(h_ref, h_a), "a consumer of the planes must return the bits of the fp32-operand launch"
+        h = torch.empty(M, C1, device="cuda")
+        hp = ops.Planes(h, storage=h)
+        pl2 = ops.linear(h, w2, residual=x1, dry_run=True)
+        assert pl2.a_x3_ok == 1 and pl2.tile_cfg == cfg
+        ops.linear(x1, w1, act=ops.ACT_GELU, ln=st, a_planes=xp, out=h, planes_out=hp, planes_only=True)
+        assert hp.valid and hp.only
+        assert torch.equal(h.cpu().contiguous().view(torch.int16), _planes_reference(h_ref)), "planes-only output"
+        y_ref = ops.linear(h_ref, w2, residual=x1)
+        log = []
+        ops.set_plan_log(log)
+        y = ops.linear(h, w2, residual=x1, a_planes=hp)
+        ops.set_plan_log(None)
+        assert log[-1].kernel.count(b",") == 6 and log[-1].kernel.endswith(b", true>"), log[-1].kernel  # the pre-split instantiation (7th template argument) ran
+        assert torch.equal(y, y_ref), f"long-K consumer (skinny_rows {log[-1].skinny_rows}, splitk {log[-1].splitk}): max diff {(y - y_ref).abs().max().item():.3e}"
+        # a forced split-K producer and consumer
+        x2 = torch.empty(M, C0, device="cuda")
+        xp2 = ops.Planes(x2)
+        ops.linear(h, w2, residual=x1, a_planes=hp, out=x2, planes_out=xp2, splitk=2)
+        y_ref2 = ops.linear(h_ref, w2, residual=x1, splitk=2)
+        assert xp2.valid and torch.equal(x2, y_ref2) and torch.equal(xp2.t.cpu().contiguous().view(torch.int16), _planes_reference(y_ref2))
+        check(f"presplit[{cfg}] chain vs fp32 torch", y_ref2, F.gelu(F.layer_norm(x1.cpu(), (C0,), gamma, beta, 1e-6) @ gen(C1, C0, seed=207, scale=0.05).t() + gen(C1, seed=208))
+              @ gen(C0, C1, seed=209, scale=0.05).t() + gen(C0, seed=210) + x1.cpu(), TOL_F32)
+        # loud failures: planes for a plan that cannot read / write them
+        ops.gemm_tune(0, -1)
+        p = _lib.GemmParams()
+        ops._fill_common(p, x1, pw, x1, 0, None, False)
+        p.m, p.lda, p.ldc = M, C0, C0
+        p.a_x3 = 1
+        assert _lib.lib().siu3r_gemm(C.byref(p), 0) != 0 and b"a_x3" in _lib.lib().siu3r_last_error()
+        p.a_x3, p.c_x3 = 0, xp.t.data_ptr()
+        assert _lib.lib().siu3r_gemm(C.byref(p), 0) != 0 and b"c_x3" in _lib.lib().siu3r_last_error()
+        pl = ops.linear(x1, pw, dry_run=True)
+        assert pl.a_x3_ok == 0 and pl.c_x3_ok == 0
+        xq = ops.Planes(x1)
+        ops.linear(a, pw, residual=r, out=x1, planes_out=xq)  # the 128 x 64 family: no planes, and the caller is told so
+        assert not xq.valid
+    finally:
+        ops.set_plan_log(None)
+        ops.gemm_tune(0, 0)

@@ -327,6 +327,46 @@ def test_graph_replay_with_new_inputs_equals_eager():
     torch.cuda.empty_cache()
 
 
+def test_presplit_activations_do_not_change_a_bit():
+    """The encoder's pre-split bf16x3 activations (ops.Planes: proj / fc2 write the residual stream also as hi | lo planes, fc1 writes its
+    GELU output as planes only; QKV / fc1 / fc2 read planes) are an operand FORMAT, not an approximation: the forward with them gives the
+    bits of the forward without them, and they are really in use (the plan log shows the pre-split kernel instantiation)."""
+    from oracle import weights as OW
+    from siu3r_amd import ops
+    from siu3r_amd.model import SIU3RModel
+
+    if "sd" not in _STATE:
+        _STATE["sd"] = OW.make_weights(0)
+    g = torch.Generator().manual_seed(23)
+    img = torch.rand(1, 2, 3, 512, 512, generator=g).cuda()
+    K = torch.tensor([[318 / 256, 0, 0.5], [0, 318 / 256, 0.5], [0, 0, 1]])[None, None].repeat(1, 2, 1, 1).cuda()
+    outs, kernels = [], []
+    saved = ops._NO_PRESPLIT
+    try:
+        for off in (False, True):
+            ops._NO_PRESPLIT = off
+            m = SIU3RModel(_STATE["sd"], image_size=(512, 512), precision="bf16x3")
+            m.use_graph = False
+            log = []
+            ops.set_plan_log(log)
+            with torch.no_grad():
+                outs.append(m(img, K, enable_query_class_logit_lift=True))
+            torch.cuda.synchronize()
+            ops.set_plan_log(None)
+            kernels.append(sum(1 for pl in log if b"gemm_pp_kernel<true" in pl.kernel and pl.kernel.count(b",") == 6 and pl.kernel.endswith(b", true>")))  # 7th template argument = pre-split A
+            del m
+    finally:
+        ops._NO_PRESPLIT = saved
+        ops.set_plan_log(None)
+    a, b = outs
+    for f in ("means", "covariances", "harmonics", "opacities", "semantic_labels", "instance_labels"):
+        assert torch.equal(getattr(a[0], f), getattr(b[0], f)), f
+    assert torch.equal(a[1].class_queries_logits, b[1].class_queries_logits) and torch.equal(a[1].masks_queries_logits, b[1].masks_queries_logits)
+    print(f"[presplit] launches on the pre-split instantiation: {kernels[0]} with planes, {kernels[1]} without")
+    assert kernels[0] >= 24 and kernels[1] == 0, kernels
+    torch.cuda.empty_cache()
+
+
 def test_forward_async_interleaved():
     """forward_async(): three steps pending at once over three slots, results picked up out of phase with the submissions, every slot
     used for its eager / capture / replay rounds -- each step's result must be bit for bit what a graph-free synchronous forward()
