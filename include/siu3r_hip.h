@@ -26,7 +26,7 @@ extern "C" {
 #define SIU3R_F64 3
 
 const char* siu3r_last_error(void);
-#define SIU3R_ABI_VERSION 6 /* 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok); 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
+#define SIU3R_ABI_VERSION 6 /* 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok), siu3r_attn_params.kv_bxor; 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
 int siu3r_abi_version(void);
 
 /* ---- seam 1: curope.rope_2d(tokens, positions, base, fwd)
@@ -180,6 +180,10 @@ typedef struct {
   int32_t splits;       /* > 1: the keys are cut into `splits` ranges of whole 64-key tiles, one workgroup per (query tile, range),
                            combined by a second kernel.  Fast paths only (bf16, or fp32 with split3; no RoPE-on-load): few query tiles
                            against many keys (Mask2Former's 100 queries x 512..8192 keys) */
+  int32_t kv_bxor;      /* batch item b reads the K / V of batch item b ^ kv_bxor (0: its own).  The two decoder sides of a pair are batch items
+                           2b and 2b + 1 and a side's cross-attention memory is projected from the OTHER side's rows: with the K / V
+                           projection merged into the launch that also makes q / k / v of the row's own side, the memory of side g lies in
+                           the row block of side 1 - g (kv_bxor = 1).  B must be a multiple of kv_bxor + 1 (power of two). */
 } siu3r_attn_params;
 int siu3r_attention(const siu3r_attn_params* p, void* stream);
 

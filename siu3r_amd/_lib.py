@@ -63,7 +63,7 @@ class AttnParams(C.Structure):
         ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("rope_max_pos", C.c_int32),
         ("qpos", C.c_void_p), ("kpos", C.c_void_p), ("mask", C.c_void_p),
         ("split3", C.c_int32), ("mask_ld", C.c_int64),
-        ("ws", C.c_void_p), ("splits", C.c_int32),
+        ("ws", C.c_void_p), ("splits", C.c_int32), ("kv_bxor", C.c_int32),
     ]
 
 

@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const siu3r_attn_params p) {
     int key = kt * KT + ld_key;
     rg.ok = key < p.Nk;
     if (key > p.Nk - 1) key = p.Nk - 1;  // clamped address, zeroed at store time (branch-free loads)
-    const unsigned char* kp = (const unsigned char*)p.k + ((int64_t)b * p.k_sb + (int64_t)key * p.k_sn + (int64_t)h * p.k_sh) * esz;
-    const unsigned char* vp = (const unsigned char*)p.v + ((int64_t)b * p.v_sb + (int64_t)key * p.v_sn + (int64_t)h * p.v_sh) * esz;
+    const unsigned char* kp = (const unsigned char*)p.k + ((int64_t)(b ^ p.kv_bxor) * p.k_sb + (int64_t)key * p.k_sn + (int64_t)h * p.k_sh) * esz;
+    const unsigned char* vp = (const unsigned char*)p.v + ((int64_t)(b ^ p.kv_bxor) * p.v_sb + (int64_t)key * p.v_sn + (int64_t)h * p.v_sh) * esz;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int ch = ld_c0 + 2 * c;
@@ -432,8 +432,8 @@ __global__ __launch_bounds__(256) void attn_fast_kernel(const siu3r_attn_params 
   const int ld_c0 = (D == 64) ? ((t & 1) + 4 * ((t >> 1) & 1)) : (t & 3);
   struct KVRegs { u32x4v kb[X3 ? 2 * CH : CH], vb[X3 ? 2 * CH : CH]; };
   constexpr int ESZ = X3 ? 4 : 2;
-  const unsigned char* kbase = (const unsigned char*)p.k + ((int64_t)b * p.k_sb + (int64_t)h * p.k_sh) * ESZ;
-  const unsigned char* vbase = (const unsigned char*)p.v + ((int64_t)b * p.v_sb + (int64_t)h * p.v_sh) * ESZ;
+  const unsigned char* kbase = (const unsigned char*)p.k + ((int64_t)(b ^ p.kv_bxor) * p.k_sb + (int64_t)h * p.k_sh) * ESZ;
+  const unsigned char* vbase = (const unsigned char*)p.v + ((int64_t)(b ^ p.kv_bxor) * p.v_sb + (int64_t)h * p.v_sh) * ESZ;
   auto load_tile = [&](int kt, KVRegs& rg) {
     int key = kt * KT + ld_key;
     if (key > p.Nk - 1) key = p.Nk - 1;  // clamped: finite garbage, its scores are masked and its P is 0
@@ -819,6 +819,8 @@ extern "C" int siu3r_attention(const siu3r_attn_params* pp, void* stream) {
   SIU3R_CHECK(!(p.split3 && p.dtype != SIU3R_F32), "siu3r_attention: bf16x3 mode needs fp32 tensors");
   SIU3R_CHECK(!(p.mask && (p.mask_ld % 64 != 0 || p.mask_ld < p.Nk || ((uintptr_t)p.mask & 15) != 0)),
               "siu3r_attention: the key mask needs a 16-byte aligned buffer with row stride mask_ld %% 64 == 0 and >= Nk (mask_ld=%ld Nk=%d)", (long)p.mask_ld, p.Nk);
+  SIU3R_CHECK(p.kv_bxor >= 0 && (p.kv_bxor & (p.kv_bxor + 1)) == 0 && p.B % (p.kv_bxor + 1) == 0 && !(p.kv_bxor && p.rope_cos),
+              "siu3r_attention: kv_bxor=%d must be 2^n - 1 with B a multiple of 2^n, and excludes RoPE on load", p.kv_bxor);
   SIU3R_CHECK(!(p.rope_cos && p.D != 64), "siu3r_attention: RoPE2D path is specialised for head_dim 64");
   SIU3R_CHECK(!(p.rope_cos && !(p.rope_sin && p.qpos && p.kpos)), "siu3r_attention: rope tables/positions missing");
   const int64_t al = p.dtype == SIU3R_F32 ? 4 : 8;  // 16-byte vector loads

@@ -97,8 +97,8 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p
   // ---- staging: thread -> (key = t >> 3, 8-element chunk t & 7) of every tile
   const int ld_key = t >> 3, ch = t & 7;
   constexpr int ESZ = X3 ? 4 : 2;
-  const unsigned char* kbase = (const unsigned char*)p.k + ((int64_t)b * p.k_sb + (int64_t)h * p.k_sh) * ESZ + ch * (8 * ESZ);
-  const unsigned char* vbase = (const unsigned char*)p.v + ((int64_t)b * p.v_sb + (int64_t)h * p.v_sh) * ESZ + ch * (8 * ESZ);
+  const unsigned char* kbase = (const unsigned char*)p.k + ((int64_t)(b ^ p.kv_bxor) * p.k_sb + (int64_t)h * p.k_sh) * ESZ + ch * (8 * ESZ);
+  const unsigned char* vbase = (const unsigned char*)p.v + ((int64_t)(b ^ p.kv_bxor) * p.v_sb + (int64_t)h * p.v_sh) * ESZ + ch * (8 * ESZ);
   auto load_rows = [&](const unsigned char* base, int64_t row_stride, int kt, u32x4v (&r)[NR]) {
     int key = kt * KT + ld_key;
     if (key > p.Nk - 1) key = p.Nk - 1;  // clamped: finite values, their scores are masked / never read

@@ -70,6 +70,17 @@ class _Weights:
             self.lin[key] = pw
         return self.lin[key]
 
+    def linear_ln_rows(self, name, rows, ln_name, eps=1e-6):
+        """rows [lo, hi) of Linear `name` behind the LayerNorm `ln_name`, folded (a slice of a fused qkv weight)"""
+        key = f"{name}[{rows[0]}:{rows[1]}]#ln:{ln_name}"
+        if key not in self.lin:
+            w = self.t(name + ".weight")[rows[0]:rows[1]]
+            b = self.t(name + ".bias")[rows[0]:rows[1]] if (name + ".bias") in self.sd else None
+            pw = ops.pack_linear_ln(w, b, self.t(ln_name + ".weight"), self.t(ln_name + ".bias"), self.split)
+            pw.meta["ln_eps"] = eps
+            self.lin[key] = pw
+        return self.lin[key]
+
     def group(self, key, build, prefixes):
         """the same layer of several blocks (the two decoder sides) as one grouped weight: build(prefix) -> PackedWeight"""
         if key not in self.lin:
@@ -369,16 +380,34 @@ class AsymmetricCroCo:
         W_ = ctx.w
         grp = lambda tag, build: W_.group(f"dec{i}.{tag}", build, sides)
         A = lambda t, tb: t if ctx.split else tb
-        qkv = ops.linear_grouped(A(x, xb), grp("qkv", lambda q: W_.linear_ln(q + ".attn.qkv", q + ".norm1")), out_dtype=ctx.act, ln=xs,
-                                 rope=(rope[0], rope[1], pos, 2 * Cc)).view(B * V, N + 1, 3, DEC_HEADS, hd)
-        a = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], heads=DEC_HEADS, head_dim=hd, scale=hd ** -0.5, split3=ctx.split)
+        if _DEC_QKVX:
+            # ONE projection launch per layer input: a side's rows make their own q | k | v (norm1 folded) AND the cross-attention memory
+            # k | v of the OTHER side (that side's norm_y and projk / projv): both read the same un-normalised rows with the same row
+            # statistics, the folded LayerNorms differ per output column only.  Columns [q | k | xk | v | xv]: RoPE covers the first 3 C.
+            # (two launches of 144 + 96 workgroups become one that fills the chip: 70 -> ~48 us per layer)
+            other = {sides[0]: sides[1], sides[1]: sides[0]}
+            build = lambda q: ops.cat_packed([W_.linear_ln_rows(q + ".attn.qkv", (0, 2 * Cc), q + ".norm1"),
+                                              W_.linear_ln(other[q] + ".cross_attn.projk", other[q] + ".norm_y"),
+                                              W_.linear_ln_rows(q + ".attn.qkv", (2 * Cc, 3 * Cc), q + ".norm1"),
+                                              W_.linear_ln(other[q] + ".cross_attn.projv", other[q] + ".norm_y")])
+            pj = ops.linear_grouped(A(x, xb), grp("qkvx", build), out_dtype=ctx.act, ln=xs, rope=(rope[0], rope[1], pos, 3 * Cc)).view(B * V, N + 1, 5, DEC_HEADS, hd)
+            a = ops.attention(pj[:, :, 0], pj[:, :, 1], pj[:, :, 3], heads=DEC_HEADS, head_dim=hd, scale=hd ** -0.5, split3=ctx.split)
+        else:
+            pj = None
+            qkv = ops.linear_grouped(A(x, xb), grp("qkv", lambda q: W_.linear_ln(q + ".attn.qkv", q + ".norm1")), out_dtype=ctx.act, ln=xs,
+                                     rope=(rope[0], rope[1], pos, 2 * Cc)).view(B * V, N + 1, 3, DEC_HEADS, hd)
+            a = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], heads=DEC_HEADS, head_dim=hd, scale=hd ** -0.5, split3=ctx.split)
         x1, s1, b1 = self._new_stream(x)
         ops.linear_grouped(a.view(B, V, N + 1, Cc), grp("proj", lambda q: W_.linear(q + ".attn.proj")), residual=x, out=x1, stats_out=s1, aux_out=b1)
         qq = ops.linear_grouped(A(x1, b1), grp("projq", lambda q: W_.linear_ln(q + ".cross_attn.projq", q + ".norm2")), out_dtype=ctx.act, ln=s1,
                                 rope=(rope[0], rope[1], pos, Cc)).view(B * V, N + 1, DEC_HEADS, hd)
-        kv = ops.linear_grouped(A(x, xb), grp("projkv", lambda q: W_.linear_ln([q + ".cross_attn.projk", q + ".cross_attn.projv"], q + ".norm_y")),
-                                out_dtype=ctx.act, ln=xs, flip=True, rope=(rope[0], rope[1], pos, Cc)).view(B * V, N + 1, 2, DEC_HEADS, hd)
-        a = ops.attention(qq, kv[:, :, 0], kv[:, :, 1], heads=DEC_HEADS, head_dim=hd, scale=hd ** -0.5, split3=ctx.split)
+        if pj is not None:
+            # side g's memory was projected from side (1 - g)'s rows: batch item b ^ 1 of the merged projection
+            a = ops.attention(qq, pj[:, :, 2], pj[:, :, 4], heads=DEC_HEADS, head_dim=hd, scale=hd ** -0.5, split3=ctx.split, kv_bxor=1)
+        else:
+            kv = ops.linear_grouped(A(x, xb), grp("projkv", lambda q: W_.linear_ln([q + ".cross_attn.projk", q + ".cross_attn.projv"], q + ".norm_y")),
+                                    out_dtype=ctx.act, ln=xs, flip=True, rope=(rope[0], rope[1], pos, Cc)).view(B * V, N + 1, 2, DEC_HEADS, hd)
+            a = ops.attention(qq, kv[:, :, 0], kv[:, :, 1], heads=DEC_HEADS, head_dim=hd, scale=hd ** -0.5, split3=ctx.split)
         x2, s2, b2 = self._new_stream(x)
         ops.linear_grouped(a.view(B, V, N + 1, Cc), grp("xproj", lambda q: W_.linear(q + ".cross_attn.proj")), residual=x1, out=x2, stats_out=s2, aux_out=b2)
         h = ops.linear_grouped(A(x2, b2), grp("fc1", lambda q: W_.linear_ln(q + ".mlp.fc1", q + ".norm3")), out_dtype=ctx.act, act=ACT_GELU, ln=s2)
@@ -1014,6 +1043,7 @@ class VideoMask2FormerForVideoSegmentation:
 # ==================================================================================================
 _PTS0_MAIN = os.environ.get("SIU3R_PTS0_MAIN", "0") == "1"
 _HEAD_MAP = os.environ.get("SIU3R_HEAD_MAP", "")
+_DEC_QKVX = not os.environ.get("SIU3R_NO_DEC_QKVX")  # A/B: the decoder's self-attention q | k | v and the other side's cross-attention k | v as one launch
 _ADAPTER_LATE = int(os.environ.get("SIU3R_ADAPTER_LATE", "0"))  # A/B: run the ViT-Adapter interactions behind the encoder instead of beside it
 _HEAD_PAIRS = os.environ.get("SIU3R_NO_HEAD_PAIRS", "0") != "1"  # the two heads of a kind as grouped launches (V == 2, B == 1)
 _PAIR_MAP = os.environ.get("SIU3R_PAIR_MAP", "")  # A/B: streams of the (Gaussian pair, pts3d pair) chains, e.g. "0,m"

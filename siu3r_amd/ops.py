@@ -97,6 +97,18 @@ def pack_linear_ln(weight, bias, gamma, beta, split) -> PackedWeight:
     return pw
 
 
+def cat_packed(pws: Sequence[PackedWeight]) -> PackedWeight:
+    """Packed weights with the same K concatenated along the OUTPUT axis (several Linears that read the same rows as one GEMM); folded
+    LayerNorms may differ per part (their c1 / c2 are per output column)."""
+    assert all(w.k == pws[0].k and w.kpad == pws[0].kpad and (w.bias is None) == (pws[0].bias is None) for w in pws)
+    ct = lambda k: None if getattr(pws[0], k) is None else torch.cat([getattr(w, k) for w in pws], 0).contiguous()
+    meta = dict(pws[0].meta or {})
+    for k in ("ln_c1", "ln_c2"):
+        if k in meta:
+            meta[k] = torch.cat([w.meta[k] for w in pws]).contiguous()
+    return PackedWeight(hi=ct("hi"), lo=ct("lo"), bias=ct("bias"), x3=ct("x3"), n=sum(w.n for w in pws), k=pws[0].k, kpad=pws[0].kpad, meta=meta)
+
+
 def stack_packed(pws: Sequence[PackedWeight]) -> PackedWeight:
     """Weight sets of equal shape as ONE packed tensor with a leading group axis (the two decoder sides in one launch)."""
     st = lambda k: None if getattr(pws[0], k) is None else torch.stack([getattr(w, k) for w in pws]).contiguous()
@@ -654,8 +666,9 @@ _ATTN_SPLITKV = __import__("os").environ.get("SIU3R_NO_ATTN_SPLITKV", "0") != "1
 
 
 def attention(q, k, v, *, heads: int, head_dim: int, scale: float, rope=None, qpos=None, kpos=None,
-              mask: Optional[torch.Tensor] = None, split3=False):
-    """q [B,Nq,H,D] / k,v [B,Nk,H,D] strided views (D contiguous) -> out [B,Nq,H*D]."""
+              mask: Optional[torch.Tensor] = None, split3=False, kv_bxor: int = 0):
+    """q [B,Nq,H,D] / k,v [B,Nk,H,D] strided views (D contiguous) -> out [B,Nq,H*D].  kv_bxor: batch item b attends to the keys / values
+    of batch item b ^ kv_bxor (siu3r_attn_params.kv_bxor)."""
     _gpu(q, k, v, mask)
     B, Nq = q.shape[0], q.shape[1]
     Nk = k.shape[1]
@@ -677,6 +690,7 @@ def attention(q, k, v, *, heads: int, head_dim: int, scale: float, rope=None, qp
         assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.shape[:2] == (B, Nq) and mask.shape[2] >= Nk
         p.mask, p.mask_ld = _p(mask), mask.shape[2]
     p.split3 = int(split3)
+    p.kv_bxor = kv_bxor
     ws = None
     fast = rope is None and ((q.dtype == torch.bfloat16 and not split3) or (q.dtype == torch.float32 and split3))
     if fast and _ATTN_SPLITKV:

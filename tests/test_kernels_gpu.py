@@ -1051,3 +1051,37 @@ def test_gemm_presplit_planes(cfg):
     finally:
         ops.set_plan_log(None)
         ops.gemm_tune(0, 0)
+
+
+@pytest.mark.parametrize("mode", [MODES[0], MODES[2]], ids=["bf16", "bf16x3"])
+def test_attention_kv_of_the_partner_batch_item(mode):
+    """siu3r_attn_params.kv_bxor: batch item b attends to the keys / values of item b ^ 1 (the decoder's merged projection leaves a
+    side's cross-attention memory in the OTHER side's row block) -- on the pair shape of the pipelined kernel, on a short one of the
+    generic kernels, with strided q / k / v views -- bit for bit what the launch on explicitly swapped K / V tensors returns; and the
+    concatenated packed weights (ops.cat_packed) of two LayerNorm-folded Linears with DIFFERENT LayerNorms equal the two GEMMs."""
+    ops = _ops()
+    name, adt, split, tol = mode
+    for (B, Nq, Nk, H, D) in ((4, 1025, 1025, 12, 64), (2, 100, 77, 8, 32), (6, 40, 260, 4, 64)):
+        buf = gen(B, max(Nq, Nk), 5, H, D, seed=300 + B).cuda().to(adt)   # [q | k | xk | v | xv]-style interleaved storage: strided views
+        q, k, v = buf[:, :Nq, 0], buf[:, :Nk, 2], buf[:, :Nk, 4]
+        swap = torch.arange(B).view(-1, 2).flip(1).reshape(-1).cuda()
+        ref = ops.attention(q, k[swap].contiguous(), v[swap].contiguous(), heads=H, head_dim=D, scale=D ** -0.5, split3=split)
+        got = ops.attention(q, k, v, heads=H, head_dim=D, scale=D ** -0.5, split3=split, kv_bxor=1)
+        assert torch.equal(got, ref), (name, B, Nq, Nk, (got.float() - ref.float()).abs().max().item())
+    with pytest.raises(RuntimeError, match="kv_bxor"):
+        ops.attention(buf[:3, :, 0], buf[:3, :, 2], buf[:3, :, 4], heads=H, head_dim=D, scale=1.0, split3=split, kv_bxor=1)  # odd batch
+    # two folded Linears behind different LayerNorms, as one GEMM
+    M, C, N1, N2 = 300, 192, 128, 64
+    x = gen(M, C, seed=310).cuda() + 1.5
+    st = ops.RowStats(x)
+    xb = torch.empty(M, C, device="cuda", dtype=torch.bfloat16)
+    ops.linear(gen(M, 64, seed=311).cuda().to(adt), ops.pack_linear(gen(C, 64, seed=312, scale=0.5).cuda(), gen(C, seed=313).cuda() + 1.5, split), out=x, stats_out=st, aux_out=xb)
+    parts = []
+    for i, n in enumerate((N1, N2)):
+        pw = ops.pack_linear_ln(gen(n, C, seed=320 + i, scale=0.2).cuda(), gen(n, seed=330 + i).cuda(), (1.0 + 0.3 * gen(C, seed=340 + i)).cuda(), gen(C, seed=350 + i).cuda(), split)
+        pw.meta["ln_eps"] = 1e-6
+        parts.append(pw)
+    A = x if split else xb
+    both = ops.linear(A, ops.cat_packed(parts), ln=st, out_dtype=torch.float32)
+    sep = torch.cat([ops.linear(A, pw, ln=st, out_dtype=torch.float32) for pw in parts], 1)
+    check(f"cat_packed[{name}] vs separate launches", both, sep, 1e-6)

@@ -94,6 +94,8 @@ def time_launch(p, cfg, S=0, n=10):
     pl = ops.gemm_plan(q)
     if (cfg != 0 and pl.tile_cfg != cfg) or (S != 0 and pl.splitk != S):
         return None, pl
+    if (q.a_x3 and not pl.a_x3_ok) or (q.c_x3 and not pl.c_x3_ok):
+        return None, pl  # the recorded launch reads / writes pre-split planes: only plans that can are candidates
     st = torch.cuda.current_stream().cuda_stream
     lib = _lib.lib()
     lib.siu3r_gemm(C.byref(q), st)
