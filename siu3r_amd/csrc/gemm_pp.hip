@@ -178,14 +178,17 @@ void siu3r_gemm_pp_name(const siu3r_gemm_params& p, int cfg, char* buf, int n) {
   const bool x3 = p.w_x3 != nullptr && p.a_dtype == SIU3R_F32;
   const int mode = siu3r_gemm_pp_mode(p);
   snprintf(buf, n, "siu3r_gemm_pp::gemm_pp_kernel<%s, %d, %d, %d, %s, %s%s>", x3 ? "true" : "false", cfg == 3 ? 1 : 2, cfg == 1 ? 4 : 2, mode,
-           (mode == 1 && p.relu_in) ? "true" : "false", (mode == 0 && p.ln_stats) ? "true" : "false", (x3 && mode == 0 && p.a_x3) ? ", true" : "");
+           (mode == 1 && p.relu_in) ? "true" : "false", (mode == 0 && p.ln_stats) ? "true" : "false", (x3 && mode <= 1 && p.a_x3) ? ", true" : "");
 }
 
 // can a ping-pong launch of this problem read A as pre-split planes (siu3r_gemm_params.a_x3)?  bf16x3, dense rows, whole 64-deep K
 // tiles (no zero-padded tail inside a [hi 32 | lo 32] segment), rows and batch items that start on a segment boundary
 bool siu3r_gemm_pp_a_x3_ok(const siu3r_gemm_params& p) {
   const bool x3 = p.w_x3 != nullptr && p.a_dtype == SIU3R_F32;
-  return x3 && siu3r_gemm_pp_mode(p) == 0 && p.k == p.kpad && p.lda % 32 == 0 && p.sa % 32 == 0 && p.sa_i % 32 == 0 && ((uintptr_t)p.a % 16) == 0;
+  if (!x3 || ((uintptr_t)p.a % 16) != 0 || p.sa % 32 != 0 || p.sa_i % 32 != 0) return false;
+  const int mode = siu3r_gemm_pp_mode(p);
+  if (mode == 0) return p.k == p.kpad && p.lda % 32 == 0;
+  return mode == 1 && p.cin % 32 == 0 && !p.relu_in;  // the tap-cursor gather over an NHWC map of whole segments (a zero-padded K tail lands on a masked tap)
 }
 // can it write its output as planes (c_x3)?  The fast fp32 row pass of gemm_epilogue_pp.h must be the one that runs (wave_rows()'s
 // conditions, for every batch item), and rows / batch items must start on a segment boundary
@@ -195,7 +198,8 @@ bool siu3r_gemm_pp_c_x3_ok(const siu3r_gemm_params& p, int cfg) {
   const int64_t res_b = p.r_dtype == SIU3R_F32 ? 4 : 2;
   const bool res_ok = !p.residual || (p.r_dtype == SIU3R_F32 && (p.ldr * res_b) % 16 == 0 && ((uintptr_t)p.residual % 16) == 0 && (p.sr * res_b) % 16 == 0 &&
                                        (p.sr_i * res_b) % 16 == 0 && (int64_t)(32 * MI_) * p.ldr < (1 << 28));
-  return p.out_mode == 0 && !p.up_src && !p.c_aux && p.c_dtype == SIU3R_F32 && p.n % 64 == 0 && (int64_t)(32 * MI_) * p.ldc < (1 << 28) && res_ok &&
+  const bool up_ok = !p.up_src || (p.up_dtype == SIU3R_F32 && ((uintptr_t)p.up_src % 16) == 0 && (int64_t)p.m * p.n < (1 << 29));
+  return p.out_mode == 0 && up_ok && !p.c_aux && p.c_dtype == SIU3R_F32 && p.n % 64 == 0 && (int64_t)(32 * MI_) * p.ldc < (1 << 28) && res_ok &&
          p.ldc % 32 == 0 && p.sc % 32 == 0 && p.sc_i % 32 == 0 && ((uintptr_t)p.c % 16) == 0 && ((uintptr_t)p.c_x3 % 16) == 0;
 }
 

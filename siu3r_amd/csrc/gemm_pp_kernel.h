@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params
   constexpr int KSTEP = X3 ? 16 : 32;                             // K elements per step
   constexpr int CK = 16 / ESZ;                                    // A elements per 16-byte chunk
   static_assert(NJ % 2 == 0, "W pieces are dealt to whole waves");
-  static_assert(!APS || (X3 && MODE == 0 && !RELU), "pre-split A: bf16x3, dense rows");
+  static_assert(!APS || (X3 && MODE <= 1 && !RELU), "pre-split A: bf16x3, dense rows or the tap-cursor gather (cin % 32 == 0)");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[smem_bytes<MI, NJ>()];
   static_assert(smem_bytes<MI, NJ>() >= SKINNY_SMEM_BYTES, "the folded remainder-row workgroups use the ring's LDS");
 
@@ -267,12 +267,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params
       // (pre-split: logical chunks 0,1 = the step's 16 hi values, 2,3 = its 16 lo values, 64 bytes further in the segment)
       a_voff[i] = (unsigned)((int64_t)m * p.lda * ESZ + q * 16 + ((APS && q >= 2) ? 32 : 0));
     } else {
+      // (pre-split NHWC map: a pixel is cin / 32 segments [hi 32 | lo 32]; the cursor below walks them in 16-channel halves)
       const int ohw = p.oh * p.ow;
       const int b = m / ohw, rr = m - b * ohw;
       const int oy = rr / p.ow, ox = rr - oy * p.ow;
       const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
       if (MODE == 1) {
-        a_voff[i] = (unsigned)((((b * ih + iy0) * iw + ix0) * cin) * ESZ + q * 16 + pad_bias);
+        a_voff[i] = (unsigned)((((b * ih + iy0) * iw + ix0) * cin) * ESZ + q * 16 + ((APS && q >= 2) ? 32 : 0) + pad_bias);
         unsigned mk = 0;  // (a zero-padded K tail lands on tap kh*kw, whose bit is never set)
         for (int ky = 0; ky < kh; ++ky)
           for (int kx = 0; kx < kw; ++kx)
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params
   unsigned cur_bit = 1u;
   auto cursor_advance = [&]() {
     cur_c0 += KSTEP;
-    cur_toff += KSTEP * ESZ;
+    cur_toff += APS ? ((cur_c0 & 16) ? 32 : 96) : KSTEP * ESZ;  // (planes: second half of the segment, or the next segment's first half)
     if (cur_c0 == cin) {
       cur_c0 = 0;
       cur_bit <<= 1;

@@ -12,6 +12,7 @@ void siu3r_gemm_pp_go_t1x(const siu3r_gemm_params& p, int mode, bool lnf, dim3 g
     else hipLaunchKernelGGL((gemm_pp_kernel<true, 2, 4, 0, false, false, true>), grid, block, 0, s, p);
   } else if (mode == 0 && lnf) SIU3R_PP_GO(0, false, true);
   else if (mode == 0) SIU3R_PP_GO(0, false, false);
+  else if (mode == 1 && p.a_x3) hipLaunchKernelGGL((gemm_pp_kernel<true, 2, 4, 1, false, false, true>), grid, block, 0, s, p);
   else if (mode == 1 && p.relu_in) SIU3R_PP_GO(1, true, false);
   else if (mode == 1) SIU3R_PP_GO(1, false, false);
   else SIU3R_PP_GO(2, false, false);

@@ -603,9 +603,17 @@ class _DPTHeadPair:
 
     def _rcu(self, q, x, extra=None):
         ctx = self.ctx
-        o = ops.conv2d_grouped(x, self._w("conv", q + ".conv1"), pad=1, out_dtype=ctx.act, act=ACT_RELU, relu_in=True)
+        w1, w2 = self._w("conv", q + ".conv1"), self._w("conv", q + ".conv2")
         res = x if extra is None else ops.affine_add(x.flatten(0, 1), extra.flatten(0, 1), None, None).view(x.shape)
-        return ops.conv2d_grouped(o, self._w("conv", q + ".conv2"), pad=1, out_dtype=ctx.act, residual=res)
+        if not (ctx.split and _CONV_PLANES):
+            o = ops.conv2d_grouped(x, w1, pad=1, out_dtype=ctx.act, act=ACT_RELU, relu_in=True)
+            return ops.conv2d_grouped(o, w2, pad=1, out_dtype=ctx.act, residual=res)
+        # bf16x3: conv1's ReLU'd output feeds conv2 only -- written as pre-split planes (ops.Planes) when conv2's plan reads them
+        o = torch.empty(x.shape[:-1] + (w1.n,), dtype=torch.float32, device=x.device)
+        op = ops.Planes(o, storage=o)
+        reads = bool(ops.conv2d_grouped(o, w2, pad=1, residual=res, dry_run=True).a_x3_ok)
+        ops.conv2d_grouped(x, w1, pad=1, act=ACT_RELU, relu_in=True, out=o, planes_out=op if reads else None, planes_only=True)
+        return ops.conv2d_grouped(o, w2, pad=1, residual=res, a_planes=op if reads else None)
 
     def _fusion(self, q, x0, x1):
         ctx = self.ctx
@@ -654,10 +662,20 @@ class _DPTHeadPair:
         B, G = path1.shape[:2]
         assert B == 1
         x = torch.empty((B, G, H, W, path1.shape[-1]), dtype=ctx.act, device=ctx.dev)
+        w0 = self._w("conv", ".dpt.head.0")
+        # bf16x3: the stem's full-resolution map (268 MB per view) is read by head.0 only: pre-split planes when head.0's plan reads them
+        xp = ops.Planes(x, storage=x) if (ctx.split and _CONV_PLANES) else None
+        reads = xp is not None and bool(ops.conv2d_grouped(x, w0, pad=1, act=ACT_RELU, dry_run=True).a_x3_ok)
+        wrote = []
         for g, q in enumerate(self.ps):  # the stem: 7x7 image convolution + ReLU + x2 upsample-add of this head's path_1
+            xg = ops.Planes(x[:, g], storage=x[:, g]) if reads else None
             ops.conv2d(img_nhwc8[:, g], ctx.w.conv(q + ".dpt.input_merger.0", cin_pad=ops.image_channels(ctx.split)), pad=3, act=ACT_RELU,
-                       up_src=path1[:, g], out=x[:, g])  # (B == 1: the slices of a group are contiguous)
-        x = ops.conv2d_grouped(x, self._w("conv", ".dpt.head.0"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
+                       up_src=path1[:, g], out=x[:, g], planes_out=xg, planes_only=True)  # (B == 1: the slices of a group are contiguous)
+            wrote.append(xg is not None and xg.valid)
+        if reads and any(wrote):
+            assert all(wrote), "the two stems of a pair run the same plan"
+            xp.valid = xp.only = True
+        x = ops.conv2d_grouped(x, w0, pad=1, out_dtype=ctx.act, act=ACT_RELU, a_planes=xp if (reads and all(wrote)) else None)
         return ops.linear_grouped(x.view(B, G, H * W, -1), self._w("linear", ".dpt.head.4"), out=out)
 
 
@@ -1043,6 +1061,7 @@ class VideoMask2FormerForVideoSegmentation:
 # ==================================================================================================
 _PTS0_MAIN = os.environ.get("SIU3R_PTS0_MAIN", "0") == "1"
 _HEAD_MAP = os.environ.get("SIU3R_HEAD_MAP", "")
+_CONV_PLANES = not os.environ.get("SIU3R_NO_CONV_PLANES")  # A/B: pre-split planes between the convolutions of the paired DPT heads
 _DEC_QKVX = not os.environ.get("SIU3R_NO_DEC_QKVX")  # A/B: the decoder's self-attention q | k | v and the other side's cross-attention k | v as one launch
 _ADAPTER_LATE = int(os.environ.get("SIU3R_ADAPTER_LATE", "0"))  # A/B: run the ViT-Adapter interactions behind the encoder instead of beside it
 _HEAD_PAIRS = os.environ.get("SIU3R_NO_HEAD_PAIRS", "0") != "1"  # the two heads of a kind as grouped launches (V == 2, B == 1)

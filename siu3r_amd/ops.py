@@ -457,29 +457,38 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=AC
     _apply_ln_stats_aux(p, pw, x, out, lda, ldc, (bsa, 0, bsc, 0), ln, stats_out, aux_out)
     p.splitk = splitk
     if dry_run or a_planes is not None or planes_out is not None:
-        _attach_workspace(p)
-        if planes_out is not None:
-            p.c_x3 = _p(planes_out.t)  # (alignment of the destination is part of c_x3_ok)
-        pl = gemm_plan(p)
-        p.c_x3 = None
+        pl = _apply_planes(p, x, out, a_planes, planes_out, planes_only, dry_run)
         if dry_run:
             return pl
-        if a_planes is not None and a_planes.valid and not _NO_PRESPLIT:
-            assert a_planes.t.shape == x.shape and a_planes.t.stride() == x.stride()
-            if pl.a_x3_ok:
-                p.a, p.a_x3 = _p(a_planes.t), 1
-            else:
-                assert not a_planes.only, f"the fp32 operand of this GEMM was never written (planes only) and {pl.kernel.decode()} cannot read planes"
-        if planes_out is not None:
-            assert planes_out.t.shape == out.shape and planes_out.t.stride() == out.stride()
-            planes_out.valid = bool(pl.c_x3_ok) and not _NO_PRESPLIT
-            planes_out.only = planes_out.valid and planes_only
-            if planes_out.valid:
-                p.c_x3 = _p(planes_out.t)
-                if planes_only:
-                    p.c = None
     _gemm_launch(p)
     return out
+
+
+def _apply_planes(p: GemmParams, x, out, a_planes, planes_out, planes_only, dry_run):
+    """pre-split operands of a prepared launch (see linear()): query the plan with fp32 A, switch A / add the plane output where the plan
+    can and the planes exist.  Returns the plan."""
+    _attach_workspace(p)
+    if planes_out is not None:
+        p.c_x3 = _p(planes_out.t)  # (alignment of the destination is part of c_x3_ok)
+    pl = gemm_plan(p)
+    p.c_x3 = None
+    if dry_run:
+        return pl
+    if a_planes is not None and a_planes.valid and not _NO_PRESPLIT:
+        assert a_planes.t.shape == x.shape and a_planes.t.stride() == x.stride()
+        if pl.a_x3_ok:
+            p.a, p.a_x3 = _p(a_planes.t), 1
+        else:
+            assert not a_planes.only, f"the fp32 operand of this GEMM was never written (planes only) and {pl.kernel.decode()} cannot read planes"
+    if planes_out is not None:
+        assert planes_out.t.shape == out.shape and planes_out.t.stride() == out.stride()
+        planes_out.valid = bool(pl.c_x3_ok) and not _NO_PRESPLIT
+        planes_out.only = planes_out.valid and planes_only
+        if planes_out.valid:
+            p.c_x3 = _p(planes_out.t)
+            if planes_only:
+                p.c = None
+    return pl
 
 
 def linear_grouped(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=ACT_NONE, residual: Optional[torch.Tensor] = None,
@@ -536,8 +545,10 @@ def bmm_nt(a: torch.Tensor, b_hi: torch.Tensor, b_lo: Optional[torch.Tensor], n:
 
 
 def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride=1, pad=0, out_dtype=torch.float32, act=ACT_NONE,
-           residual=None, relu_in=False, up_src: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
-    """NHWC implicit-GEMM convolution: x [B, IH, IW, Cin] -> [B, OH, OW, Cout] (out: optional contiguous destination)."""
+           residual=None, relu_in=False, up_src: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+           a_planes: Optional[Planes] = None, planes_out: Optional[Planes] = None, planes_only: bool = False, dry_run: bool = False):
+    """NHWC implicit-GEMM convolution: x [B, IH, IW, Cin] -> [B, OH, OW, Cout] (out: optional contiguous destination).
+    a_planes / planes_out / planes_only / dry_run: pre-split bf16x3 operands, as in linear()."""
     _gpu(x, residual, up_src, out)
     assert x.is_contiguous()
     B, IH, IW, Cin = x.shape
@@ -556,6 +567,10 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride=1, pad=0, out_dtype=torc
     if up_src is not None:
         assert up_src.is_contiguous() and up_src.shape == (B, OH // 2, OW // 2, pw.n)
         p.up_src, p.up_dtype = _p(up_src), _dt(up_src)
+    if dry_run or a_planes is not None or planes_out is not None:
+        pl = _apply_planes(p, x, out, a_planes, planes_out, planes_only, dry_run)
+        if dry_run:
+            return pl
     _gemm_launch(p)
     return out
 
@@ -596,7 +611,9 @@ def _grouped_common(p: GemmParams, x, pw: PackedWeight, out, residual):
         p.sr, p.sr_i = residual.stride(0), residual.stride(1)
 
 
-def conv2d_grouped(x: torch.Tensor, pw: PackedWeight, *, stride=1, pad=0, out_dtype=torch.float32, act=ACT_NONE, residual=None, relu_in=False):
+def conv2d_grouped(x: torch.Tensor, pw: PackedWeight, *, stride=1, pad=0, out_dtype=torch.float32, act=ACT_NONE, residual=None, relu_in=False,
+                   out: Optional[torch.Tensor] = None, a_planes: Optional[Planes] = None, planes_out: Optional[Planes] = None, planes_only: bool = False,
+                   dry_run: bool = False):
     """conv2d for G networks of the same shape in ONE launch: x [B, G, IH, IW, Cin] -> [B, G, OH, OW, Cout], image (b, g) convolved with
     weight set g of pw = stack_packed([...G sets]) (the two DPT heads of a kind: head1 on view 0, head2 on view 1 -- reference
     model.py:352-375 runs them one after the other)."""
@@ -606,13 +623,19 @@ def conv2d_grouped(x: torch.Tensor, pw: PackedWeight, *, stride=1, pad=0, out_dt
     assert Cin == pw.meta["cin"], (Cin, pw.meta)
     OH = (IH + 2 * pad - kh) // stride + 1
     OW = (IW + 2 * pad - kw) // stride + 1
-    out = torch.empty((B, G, OH, OW, pw.n), dtype=out_dtype, device=x.device)
+    if out is None:
+        out = torch.empty((B, G, OH, OW, pw.n), dtype=out_dtype, device=x.device)
+    assert out.shape == (B, G, OH, OW, pw.n) and out.is_contiguous()
     p = GemmParams()
     _fill_common(p, x, pw, out, act, residual, relu_in)
     p.m, p.ldc, p.ldr = OH * OW, pw.n, pw.n
     p.a_mode = 1
     p.ih, p.iw, p.cin, p.kh, p.kw, p.stride, p.pad, p.oh, p.ow = IH, IW, Cin, kh, kw, stride, pad, OH, OW
     _grouped_common(p, x, pw, out, residual)
+    if dry_run or a_planes is not None or planes_out is not None:  # pre-split bf16x3 operands, as in linear()
+        pl = _apply_planes(p, x, out, a_planes, planes_out, planes_only, dry_run)
+        if dry_run:
+            return pl
     _gemm_launch(p)
     return out
 

@@ -1034,6 +1034,24 @@ def test_gemm_presplit_planes(cfg):
         assert xp2.valid and torch.equal(x2, y_ref2) and torch.equal(xp2.t.cpu().contiguous().view(torch.int16), _planes_reference(y_ref2))
         check(f"presplit[{cfg}] chain vs fp32 torch", y_ref2, F.gelu(F.layer_norm(x1.cpu(), (C0,), gamma, beta, 1e-6) @ gen(C1, C0, seed=207, scale=0.05).t() + gen(C1, seed=208))
               @ gen(C0, C1, seed=209, scale=0.05).t() + gen(C0, seed=210) + x1.cpu(), TOL_F32)
+        # convolutions: a 3 x 3 convolution writes its ReLU'd map as planes only, the next one gathers its taps from the planes
+        # (padding taps, a batch of two images, cin = 64 = two segments per pixel)
+        xin = gen(2, 24, 40, 64, seed=220).cuda()
+        c1 = ops.pack_conv(gen(64, 64, 3, 3, seed=221, scale=0.1).cuda(), gen(64, seed=222).cuda(), True)
+        c2 = ops.pack_conv(gen(128, 64, 3, 3, seed=223, scale=0.1).cuda(), gen(128, seed=224).cuda(), True)
+        o_ref = ops.conv2d(xin, c1, pad=1, act=ops.ACT_RELU, relu_in=True)
+        y_ref = ops.conv2d(o_ref, c2, pad=1)
+        o = torch.empty_like(o_ref)
+        op = ops.Planes(o, storage=o)
+        assert ops.conv2d(o, c2, pad=1, dry_run=True).a_x3_ok == 1
+        ops.conv2d(xin, c1, pad=1, act=ops.ACT_RELU, relu_in=True, out=o, planes_out=op, planes_only=True)
+        assert op.valid and op.only and torch.equal(o.view(-1, 64).cpu().contiguous().view(torch.int16), _planes_reference(o_ref.view(-1, 64)))
+        log = []
+        ops.set_plan_log(log)
+        yc = ops.conv2d(o, c2, pad=1, a_planes=op)
+        ops.set_plan_log(None)
+        assert log[-1].kernel.count(b",") == 6 and b", 1, false, false, true>" in log[-1].kernel, log[-1].kernel
+        assert torch.equal(yc, y_ref), f"convolution on planes: max diff {(yc - y_ref).abs().max().item():.3e}"
         # loud failures: planes for a plan that cannot read / write them
         ops.gemm_tune(0, -1)
         p = _lib.GemmParams()
