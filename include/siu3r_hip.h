@@ -26,7 +26,7 @@ extern "C" {
 #define SIU3R_F64 3
 
 const char* siu3r_last_error(void);
-#define SIU3R_ABI_VERSION 6 /* 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok), siu3r_attn_params.kv_bxor; 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
+#define SIU3R_ABI_VERSION 6 /* 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok), siu3r_attn_params.kv_bxor / kv_x3, siu3r_gemm_params.c_x3_col0; 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
 int siu3r_abi_version(void);
 
 /* ---- seam 1: curope.rope_2d(tokens, positions, base, fwd)
@@ -124,6 +124,9 @@ typedef struct {
      loudly otherwise). */
   void* c_x3;
   int32_t a_x3;
+  int32_t c_x3_col0;              /* planes are written for output columns >= c_x3_col0 only (a multiple of 64; 0 = all).  With c_x3 == c the
+                                     buffer is MIXED: fp32 in columns [0, c_x3_col0), planes behind them (the q | k | v projection: q stays
+                                     fp32, k and v are pre-split for the attention kernel) */
 } siu3r_gemm_params;
 #define SIU3R_TILE_AUTO 0
 #define SIU3R_TILE_128x64 -1   /* the 128 x 64 LDS-DMA / register-staged kernels (gemm_dma.hip, gemm.hip) */
@@ -184,8 +187,14 @@ typedef struct {
                            2b and 2b + 1 and a side's cross-attention memory is projected from the OTHER side's rows: with the K / V
                            projection merged into the launch that also makes q / k / v of the row's own side, the memory of side g lies in
                            the row block of side 1 - g (kv_bxor = 1).  B must be a multiple of kv_bxor + 1 (power of two). */
+  int32_t kv_x3;        /* bf16x3 (fp32 tensors, split3): k and v point at PRE-SPLIT planes -- per token and head the 64 dims as two 128-byte
+                           segments [hi 32 | lo 32] bf16, as a projection GEMM writes them with c_x3 / c_x3_col0 -- same strides as the
+                           fp32 tensors.  Served by the pipelined kernel only (siu3r_attention_kv_x3_ok); anything else is an error. */
 } siu3r_attn_params;
 int siu3r_attention(const siu3r_attn_params* p, void* stream);
+/* 1 if siu3r_attention would accept these parameters with kv_x3 = 1 (head_dim 64, no mask / RoPE-on-load / key split, >= 64 keys,
+ * fp32 + split3, segment-aligned K / V rows), else 0 */
+int siu3r_attention_kv_x3_ok(const siu3r_attn_params* p);
 
 /* ---- element-wise / gather kernels (see DESIGN.md for the HBM roofline of each) ---------- */
 /* y = a + b (b broadcast over rows when b_rows < rows: row r uses b[r % b_rows]) */

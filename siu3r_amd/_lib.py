@@ -39,7 +39,7 @@ class GemmParams(C.Structure):
         ("c_aux", C.c_void_p),
         ("splitk", C.c_int32), ("sk_ws", C.c_void_p), ("sk_cnt", C.c_void_p),
         ("sk_ws_floats", C.c_int64), ("sk_cnt_n", C.c_int32), ("tile_cfg", C.c_int32), ("m_main", C.c_int32), ("sk_gx", C.c_int32),
-        ("c_x3", C.c_void_p), ("a_x3", C.c_int32),
+        ("c_x3", C.c_void_p), ("a_x3", C.c_int32), ("c_x3_col0", C.c_int32),
     ]
 
 
@@ -63,7 +63,7 @@ class AttnParams(C.Structure):
         ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("rope_max_pos", C.c_int32),
         ("qpos", C.c_void_p), ("kpos", C.c_void_p), ("mask", C.c_void_p),
         ("split3", C.c_int32), ("mask_ld", C.c_int64),
-        ("ws", C.c_void_p), ("splits", C.c_int32), ("kv_bxor", C.c_int32),
+        ("ws", C.c_void_p), ("splits", C.c_int32), ("kv_bxor", C.c_int32), ("kv_x3", C.c_int32),
     ]
 
 
@@ -96,6 +96,7 @@ SIGNATURES = {
     "siu3r_layernorm": [_P, _P, _I, _P, _P, _L, _I, _L, _L, _F, _P],
     "siu3r_layernorm2": [_P, _P, _I, _P, _P, _P, _L, _I, _L, _L, _L, _F, _P],
     "siu3r_attention": [C.POINTER(AttnParams), _P],
+    "siu3r_attention_kv_x3_ok": [C.POINTER(AttnParams)],
     "siu3r_add": [_P, _P, _P, _L, _L, _I, _P],
     "siu3r_pack_image_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "siu3r_resize_bilinear": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -810,6 +810,16 @@ int launch(const siu3r_attn_params& p, hipStream_t s) {
 
 }  // namespace
 
+static bool kv_x3_ok(const siu3r_attn_params& p) {
+  static const bool no_fast = getenv("SIU3R_ATTN_NO_FAST") != nullptr;
+  // whole segments: a head's 64 dims start on a 32-column boundary of the projection output, rows and batch items likewise
+  const bool seg = p.k_sh % 32 == 0 && p.k_sn % 32 == 0 && p.k_sb % 32 == 0 && p.v_sh % 32 == 0 && p.v_sn % 32 == 0 && p.v_sb % 32 == 0 &&
+                   ((uintptr_t)p.k % 128) == 0 && ((uintptr_t)p.v % 128) == 0;
+  return !no_fast && p.dtype == SIU3R_F32 && p.split3 && seg && siu3r_attn_pipe_ok(p);
+}
+
+extern "C" int siu3r_attention_kv_x3_ok(const siu3r_attn_params* pp) { return pp && kv_x3_ok(*pp) ? 1 : 0; }
+
 extern "C" int siu3r_attention(const siu3r_attn_params* pp, void* stream) {
   const siu3r_attn_params& p = *pp;
   SIU3R_CHECK(p.q && p.k && p.v && p.out, "siu3r_attention: null pointer");
@@ -827,6 +837,8 @@ extern "C" int siu3r_attention(const siu3r_attn_params* pp, void* stream) {
   SIU3R_CHECK(p.q_sn % al == 0 && p.q_sh % al == 0 && p.q_sb % al == 0 && p.k_sn % al == 0 && p.k_sh % al == 0 &&
                   p.k_sb % al == 0 && p.v_sn % al == 0 && p.v_sh % al == 0 && p.v_sb % al == 0,
               "siu3r_attention: q/k/v strides must keep 16-byte alignment");
+  SIU3R_CHECK(!p.kv_x3 || kv_x3_ok(p), "siu3r_attention: kv_x3 (pre-split K / V planes) needs the pipelined bf16x3 kernel (head_dim 64, no mask / RoPE on load / "
+              "key split, >= 64 keys) and segment-aligned K / V: query siu3r_attention_kv_x3_ok first");
   hipStream_t s = (hipStream_t)stream;
   static const bool no_fast = getenv("SIU3R_ATTN_NO_FAST") != nullptr;  // A/B switch
   if (!no_fast && siu3r_attn_pipe_ok(p)) return siu3r_attn_pipe_launch(p, s);

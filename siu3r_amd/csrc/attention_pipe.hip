@@ -39,8 +39,12 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4v;
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
-template <bool X3>
+// KVP (bf16x3): K and V arrive PRE-SPLIT -- hi | lo bf16 planes per 32 columns, written by the projection GEMM's epilogue
+// (siu3r_gemm_params.c_x3 / c_x3_col0) -- and go from global memory to the LDS stages without conversion.  The in-kernel split of fp32
+// K / V uses the same definition (hi = upper 16 bits, lo = bf16(x - hi)), so both forms give the same bits.
+template <bool X3, bool KVP = false>
 __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p, const int q_tiles, const int has_x) {
+  static_assert(!KVP || X3, "pre-split K / V: bf16x3");
   constexpr int TST = (X3 ? 2 : 1) * PL;    // one staged tile of K or V (X3: [hi | lo])
   constexpr int KLO = PL, VLO = PL;
   constexpr int VBASE = NKS * TST;          // LDS: NKS K stages, then NVS V stages
@@ -97,19 +101,28 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p
   // ---- staging: thread -> (key = t >> 3, 8-element chunk t & 7) of every tile
   const int ld_key = t >> 3, ch = t & 7;
   constexpr int ESZ = X3 ? 4 : 2;
-  const unsigned char* kbase = (const unsigned char*)p.k + ((int64_t)(b ^ p.kv_bxor) * p.k_sb + (int64_t)h * p.k_sh) * ESZ + ch * (8 * ESZ);
-  const unsigned char* vbase = (const unsigned char*)p.v + ((int64_t)(b ^ p.kv_bxor) * p.v_sb + (int64_t)h * p.v_sh) * ESZ + ch * (8 * ESZ);
+  // (planes: the thread's 8 dims are 16 bytes of the hi half of their 32-column segment, the lo half 64 bytes further)
+  const int ch_off = KVP ? (ch >> 2) * 128 + (ch & 3) * 16 : ch * (8 * ESZ);
+  const unsigned char* kbase = (const unsigned char*)p.k + ((int64_t)(b ^ p.kv_bxor) * p.k_sb + (int64_t)h * p.k_sh) * ESZ + ch_off;
+  const unsigned char* vbase = (const unsigned char*)p.v + ((int64_t)(b ^ p.kv_bxor) * p.v_sb + (int64_t)h * p.v_sh) * ESZ + ch_off;
   auto load_rows = [&](const unsigned char* base, int64_t row_stride, int kt, u32x4v (&r)[NR]) {
     int key = kt * KT + ld_key;
     if (key > p.Nk - 1) key = p.Nk - 1;  // clamped: finite values, their scores are masked / never read
     const unsigned char* rp = base + (int64_t)key * row_stride * ESZ;
 #pragma unroll
-    for (int c = 0; c < NR; ++c) r[c] = *(const u32x4v*)(rp + 16 * c);
+    for (int c = 0; c < NR; ++c) r[c] = *(const u32x4v*)(rp + (KVP ? 64 : 16) * c);
   };
   auto load_k = [&](int kt, u32x4v (&r)[NR]) { load_rows(kbase, p.k_sn, kt, r); };
   auto load_v = [&](int kt, u32x4v (&r)[NR]) { load_rows(vbase, p.v_sn, kt, r); };
   auto chunk_floats = [&](const u32x4v (&r)[NR], float (&f)[8]) {
-    if constexpr (X3) {
+    if constexpr (KVP) {  // (side path only: the value the MFMA path multiplies, hi + lo)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned wh = r[0][j], wl = r[X3 ? 1 : 0][j];
+        f[2 * j] = __uint_as_float(wh << 16) + __uint_as_float(wl << 16);
+        f[2 * j + 1] = __uint_as_float(wh & 0xffff0000u) + __uint_as_float(wl & 0xffff0000u);
+      }
+    } else if constexpr (X3) {
       const f32x4v a = __builtin_bit_cast(f32x4v, r[0]), c = __builtin_bit_cast(f32x4v, r[1]);
       f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = c[0]; f[5] = c[1]; f[6] = c[2]; f[7] = c[3];
     } else {
@@ -125,11 +138,14 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p
   const int v_st = ld_key * RS + ((((ch >> 2) ^ ((ld_key >> 1) & 1)) << 2) | (ch & 3)) * 16;  // 64-byte halves swapped by key bit 1
   auto store_k = [&](int stage, const u32x4v (&r)[NR]) {
     unsigned char* sK = smem + stage * TST;
-    if constexpr (X3) {
+    if constexpr (KVP) {
+      *(u32x4v*)(sK + k_st) = r[0];
+      *(u32x4v*)(sK + KLO + k_st) = r[X3 ? 1 : 0];
+    } else if constexpr (X3) {
       float f[8];
       chunk_floats(r, f);
       uint4 hi, lo;
-      split_bf16x8(f, hi, lo);
+      split_trunc_bf16x8(f, hi, lo);
       *(uint4*)(sK + k_st) = hi;
       *(uint4*)(sK + KLO + k_st) = lo;
     } else {
@@ -138,11 +154,14 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p
   };
   auto store_v = [&](int stage, const u32x4v (&r)[NR]) {
     unsigned char* sV = smem + VBASE + stage * TST;
-    if constexpr (X3) {
+    if constexpr (KVP) {
+      *(u32x4v*)(sV + v_st) = r[0];
+      *(u32x4v*)(sV + VLO + v_st) = r[X3 ? 1 : 0];
+    } else if constexpr (X3) {
       float f[8];
       chunk_floats(r, f);
       uint4 hi, lo;
-      split_bf16x8(f, hi, lo);
+      split_trunc_bf16x8(f, hi, lo);
       *(uint4*)(sV + v_st) = hi;
       *(uint4*)(sV + VLO + v_st) = lo;
     } else {
@@ -159,14 +178,33 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p
     u32x4v r[NR];
 #pragma unroll
     for (int c = 0; c < NR; ++c) r[c] = *(const u32x4v*)(qp + 16 * c);
-    chunk_floats(r, qx);
+    if constexpr (X3) {  // (q is always fp32)
+      const f32x4v a = __builtin_bit_cast(f32x4v, r[0]), c = __builtin_bit_cast(f32x4v, r[X3 ? 1 : 0]);
+      qx[0] = a[0]; qx[1] = a[1]; qx[2] = a[2]; qx[3] = a[3]; qx[4] = c[0]; qx[5] = c[1]; qx[6] = c[2]; qx[7] = c[3];
+    } else {
+      chunk_floats(r, qx);
+    }
   }
 #define SIU3R_DPP_ADD(x, ctrl) ((x) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), 0xf, 0xf, true)))
   // the score of the group's key of a tile is taken while that tile's K row is in the staging registers; it meets the tile's V row
   // (staged one iteration later) in side_consume
+  // (bf16x3, fp32 K / V: the side path multiplies hi + lo of the split as well, so that both operand forms give the same bits)
+  auto side_floats = [&](const u32x4v (&r)[NR], float (&f)[8]) {
+    chunk_floats(r, f);
+    if constexpr (X3 && !KVP) {
+      uint4 hi, lo;
+      split_trunc_bf16x8(f, hi, lo);
+      const unsigned hw[4] = {hi.x, hi.y, hi.z, hi.w}, lw[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f[2 * j] = __uint_as_float(hw[j] << 16) + __uint_as_float(lw[j] << 16);
+        f[2 * j + 1] = __uint_as_float(hw[j] & 0xffff0000u) + __uint_as_float(lw[j] & 0xffff0000u);
+      }
+    }
+  };
   auto side_score = [&](int tile, const u32x4v (&rk)[NR]) {
     float kf_[8];
-    chunk_floats(rk, kf_);
+    side_floats(rk, kf_);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) s = __builtin_fmaf(kf_[e], qx[e], s);
@@ -177,7 +215,7 @@ __global__ __launch_bounds__(NT) void attn_pipe_kernel(const siu3r_attn_params p
   };
   auto side_consume = [&](float s, const u32x4v (&rv)[NR]) {
     float vf_[8];
-    chunk_floats(rv, vf_);
+    side_floats(rv, vf_);
     const float m_new = fmaxf(mx, s);
     const float a = __builtin_amdgcn_exp2f((mx - m_new) * sl2), pw = __builtin_amdgcn_exp2f((s - m_new) * sl2);
     mx = m_new;
@@ -513,7 +551,9 @@ int siu3r_attn_pipe_launch(const siu3r_attn_params& p, hipStream_t s) {
   const int has_x = (p.Nq > QT && (p.Nq & (QT - 1)) == 1) ? 1 : 0;
   const int q_tiles = has_x ? (p.Nq - 1) / QT : (p.Nq + QT - 1) / QT;
   const dim3 grid((unsigned)(q_tiles * p.H * p.B)), block(NT);
-  if (p.dtype == SIU3R_F32)
+  if (p.dtype == SIU3R_F32 && p.kv_x3)
+    hipLaunchKernelGGL((attn_pipe_kernel<true, true>), grid, block, 0, s, p, q_tiles, has_x);
+  else if (p.dtype == SIU3R_F32)
     hipLaunchKernelGGL((attn_pipe_kernel<true>), grid, block, 0, s, p, q_tiles, has_x);
   else
     hipLaunchKernelGGL((attn_pipe_kernel<false>), grid, block, 0, s, p, q_tiles, has_x);

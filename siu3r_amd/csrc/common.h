@@ -135,6 +135,25 @@ __device__ inline void split_bf16x8(const float* f, uint4& hi, uint4& lo) {
   lo = pack_bf16x8(r);
 }
 
+// the split of the GEMM K loop and of the pre-split planes (siu3r_gemm_params.c_x3): hi = the UPPER 16 BITS, lo = bf16(f - hi)
+__device__ inline void split_trunc_bf16x8(const float* f, uint4& hi, uint4& lo) {
+  float r[8];
+  uint32_t h[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t u0 = __float_as_uint(f[2 * j]), u1 = __float_as_uint(f[2 * j + 1]);
+#if __HIP_DEVICE_COMPILE__
+    h[j] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+#else
+    h[j] = (u1 & 0xffff0000u) | (u0 >> 16);
+#endif
+    r[2 * j] = f[2 * j] - __uint_as_float(u0 & 0xffff0000u);
+    r[2 * j + 1] = f[2 * j + 1] - __uint_as_float(u1 & 0xffff0000u);
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = pack_bf16x8(r);
+}
+
 __device__ inline bf16x8 as_bf16x8(uint4 u) {
   union { uint4 u; bf16x8 b; } c;
   c.u = u;

@@ -133,9 +133,12 @@ __device__ __forceinline__ void wave_rows_fast(const siu3r_gemm_params& p, f32x1
   const bool res_bf = p.r_dtype == SIU3R_BF16;
   // c_x3: the output ALSO (or, c == NULL, only) as pre-split bf16x3 planes for the next GEMM's A operand (siu3r_hip.h): same row offsets
   // as the fp32 output, a 32-column segment = one 128-byte line [hi 32 | lo 32]
-  const bool st_c = p.c != nullptr, x3o = !BF && p.c_x3 != nullptr;
+  // c_x3_col0: planes for the 64-column groups at or behind that column only; with c_x3 == c those groups are NOT written as fp32 (a mixed
+  // buffer: the q | k | v projection keeps q in fp32 and hands k, v to the attention kernel pre-split)
+  const bool st_c_any = p.c != nullptr, x3o_any = !BF && p.c_x3 != nullptr, mixed = x3o_any && p.c_x3 == p.c;
+  const bool st_c = st_c_any;
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned char*)(st_c ? p.c : p.c_x3) + (zof.c + (int64_t)row_w0 * p.ldc) * (BF ? 2 : 4)), (short)0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned char*)(x3o ? p.c_x3 : p.c) + (zof.c + (int64_t)row_w0 * p.ldc) * 4), (short)0, x3o ? 0x7fffffff : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned char*)(x3o_any ? p.c_x3 : p.c) + (zof.c + (int64_t)row_w0 * p.ldc) * 4), (short)0, x3o_any ? 0x7fffffff : 0, 0x00020000);
   const bool has_res = p.residual != nullptr;
   const int r_esz = res_bf ? 2 : 4;
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
@@ -172,6 +175,8 @@ __device__ __forceinline__ void wave_rows_fast(const siu3r_gemm_params& p, f32x1
     const int g0 = col_w0 + jp * 64;  // the 64-column group (one RoPE head, one statistics group)
     if (g0 < N) {                     // (wave-uniform; N % 64 == 0: a group is whole or absent)
       const int n_lo = g0 + o_lo, n_hi = g0 + o_hi;
+      const bool x3o = x3o_any && g0 >= p.c_x3_col0;  // (wave-uniform)
+      const bool c_here = st_c_any && !(mixed && x3o);
       const bool rope = !BF && p.rope_cos != nullptr && g0 < p.rope_ncols;
       f32x4_t b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = b_lo, c1_lo = b_lo, c1_hi = b_lo;
       if (addp) {
@@ -198,7 +203,7 @@ __device__ __forceinline__ void wave_rows_fast(const siu3r_gemm_params& p, f32x1
             const int lr = i * 32 + k * 8 + prow;
             const bool ok = row_w0 + lr < M;
             rok[k] = ok;
-            coff[k] = (ok && st_c) ? (unsigned)((lr * (int)p.ldc + n_lo) * (BF ? 2 : 4)) : OOB;
+            coff[k] = (ok && c_here) ? (unsigned)((lr * (int)p.ldc + n_lo) * (BF ? 2 : 4)) : OOB;
             if constexpr (HOIST) {
               const unsigned roff = ok ? (unsigned)((lr * (int)p.ldr + n_lo) * r_esz) : OOB;
               load_res(roff, r_lo[k], r_hi[k]);

@@ -200,7 +200,8 @@ bool siu3r_gemm_pp_c_x3_ok(const siu3r_gemm_params& p, int cfg) {
                                        (p.sr_i * res_b) % 16 == 0 && (int64_t)(32 * MI_) * p.ldr < (1 << 28));
   const bool up_ok = !p.up_src || (p.up_dtype == SIU3R_F32 && ((uintptr_t)p.up_src % 16) == 0 && (int64_t)p.m * p.n < (1 << 29));
   return p.out_mode == 0 && up_ok && !p.c_aux && p.c_dtype == SIU3R_F32 && p.n % 64 == 0 && (int64_t)(32 * MI_) * p.ldc < (1 << 28) && res_ok &&
-         p.ldc % 32 == 0 && p.sc % 32 == 0 && p.sc_i % 32 == 0 && ((uintptr_t)p.c % 16) == 0 && ((uintptr_t)p.c_x3 % 16) == 0;
+         p.ldc % 32 == 0 && p.sc % 32 == 0 && p.sc_i % 32 == 0 && ((uintptr_t)p.c % 16) == 0 && ((uintptr_t)p.c_x3 % 16) == 0 &&
+         p.c_x3_col0 >= 0 && p.c_x3_col0 % 64 == 0;
 }
 
 // tiled launch with tile cfg (SIU3R_TILE_PP_*); p.splitk, p.m_main as planned

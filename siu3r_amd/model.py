@@ -243,9 +243,14 @@ class AsymmetricCroCo:
         ctx = self.ctx
         x, xs, _, xp = S if len(S) == 4 else (*S, None)
         Z, N, Cc = x.shape
-        qkv = ops.linear(x, ctx.w.linear_ln(p + ".attn.qkv", p + ".norm1"), out_dtype=ctx.act, ln=xs, a_planes=xp,
-                         rope=(rope[0], rope[1], pos, 2 * Cc)).view(Z, N, 3, ENC_HEADS, Cc // ENC_HEADS)
-        a = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], heads=ENC_HEADS, head_dim=Cc // ENC_HEADS, scale=(Cc // ENC_HEADS) ** -0.5, split3=True)
+        # q stays fp32, k and v leave the projection pre-split (the attention kernel stages them without conversion) when it can read them
+        qkv_buf = torch.empty((Z, N, 3 * Cc), dtype=torch.float32, device=x.device)
+        qkv = qkv_buf.view(Z, N, 3, ENC_HEADS, Cc // ENC_HEADS)
+        att = dict(heads=ENC_HEADS, head_dim=Cc // ENC_HEADS, scale=(Cc // ENC_HEADS) ** -0.5, split3=True)
+        kvp = ops.Planes(qkv_buf, storage=qkv_buf) if (_KV_PLANES and ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dry_run=True, **att)) else None
+        ops.linear(x, ctx.w.linear_ln(p + ".attn.qkv", p + ".norm1"), ln=xs, a_planes=xp, rope=(rope[0], rope[1], pos, 2 * Cc), out=qkv_buf,
+                   planes_out=kvp, planes_from_col=Cc)
+        a = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], kv_planes=kvp is not None and kvp.valid, **att)
         x1, s1, _ = self._new_stream(x)
         xp1 = ops.Planes(x1)
         ops.linear(a, ctx.w.linear(p + ".attn.proj"), residual=x, out=x1, stats_out=s1, planes_out=xp1)
@@ -390,8 +395,14 @@ class AsymmetricCroCo:
                                               W_.linear_ln(other[q] + ".cross_attn.projk", other[q] + ".norm_y"),
                                               W_.linear_ln_rows(q + ".attn.qkv", (2 * Cc, 3 * Cc), q + ".norm1"),
                                               W_.linear_ln(other[q] + ".cross_attn.projv", other[q] + ".norm_y")])
-            pj = ops.linear_grouped(A(x, xb), grp("qkvx", build), out_dtype=ctx.act, ln=xs, rope=(rope[0], rope[1], pos, 3 * Cc)).view(B * V, N + 1, 5, DEC_HEADS, hd)
-            a = ops.attention(pj[:, :, 0], pj[:, :, 1], pj[:, :, 3], heads=DEC_HEADS, head_dim=hd, scale=hd ** -0.5, split3=ctx.split)
+            pj_buf = torch.empty((B, V, N + 1, 5 * Cc), dtype=ctx.act, device=x.device)
+            pj = pj_buf.view(B * V, N + 1, 5, DEC_HEADS, hd)
+            att = dict(heads=DEC_HEADS, head_dim=hd, scale=hd ** -0.5, split3=ctx.split)
+            # bf16x3: k | xk | v | xv leave the projection pre-split (ops.Planes) when the attention kernel can read them; q stays fp32
+            kvp = ops.Planes(pj_buf, storage=pj_buf) if (ctx.split and _KV_PLANES and ops.attention(pj[:, :, 0], pj[:, :, 1], pj[:, :, 3], dry_run=True, **att)) else None
+            ops.linear_grouped(A(x, xb), grp("qkvx", build), ln=xs, rope=(rope[0], rope[1], pos, 3 * Cc), out=pj_buf, planes_out=kvp, planes_from_col=Cc)
+            kvp = kvp is not None and kvp.valid
+            a = ops.attention(pj[:, :, 0], pj[:, :, 1], pj[:, :, 3], kv_planes=kvp, **att)
         else:
             pj = None
             qkv = ops.linear_grouped(A(x, xb), grp("qkv", lambda q: W_.linear_ln(q + ".attn.qkv", q + ".norm1")), out_dtype=ctx.act, ln=xs,
@@ -403,7 +414,7 @@ class AsymmetricCroCo:
                                 rope=(rope[0], rope[1], pos, Cc)).view(B * V, N + 1, DEC_HEADS, hd)
         if pj is not None:
             # side g's memory was projected from side (1 - g)'s rows: batch item b ^ 1 of the merged projection
-            a = ops.attention(qq, pj[:, :, 2], pj[:, :, 4], heads=DEC_HEADS, head_dim=hd, scale=hd ** -0.5, split3=ctx.split, kv_bxor=1)
+            a = ops.attention(qq, pj[:, :, 2], pj[:, :, 4], kv_bxor=1, kv_planes=kvp, **att)
         else:
             kv = ops.linear_grouped(A(x, xb), grp("projkv", lambda q: W_.linear_ln([q + ".cross_attn.projk", q + ".cross_attn.projv"], q + ".norm_y")),
                                     out_dtype=ctx.act, ln=xs, flip=True, rope=(rope[0], rope[1], pos, Cc)).view(B * V, N + 1, 2, DEC_HEADS, hd)
@@ -1061,6 +1072,7 @@ class VideoMask2FormerForVideoSegmentation:
 # ==================================================================================================
 _PTS0_MAIN = os.environ.get("SIU3R_PTS0_MAIN", "0") == "1"
 _HEAD_MAP = os.environ.get("SIU3R_HEAD_MAP", "")
+_KV_PLANES = not os.environ.get("SIU3R_NO_KV_PLANES")  # A/B: k / v written pre-split by the q | k | v projections (bf16x3)
 _CONV_PLANES = not os.environ.get("SIU3R_NO_CONV_PLANES")  # A/B: pre-split planes between the convolutions of the paired DPT heads
 _DEC_QKVX = not os.environ.get("SIU3R_NO_DEC_QKVX")  # A/B: the decoder's self-attention q | k | v and the other side's cross-attention k | v as one launch
 _ADAPTER_LATE = int(os.environ.get("SIU3R_ADAPTER_LATE", "0"))  # A/B: run the ViT-Adapter interactions behind the encoder instead of beside it

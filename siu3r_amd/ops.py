@@ -411,7 +411,7 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=AC
            residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, relu_in=False,
            rope=None, ln: Optional[RowStats] = None, stats_out: Optional[RowStats] = None, aux_out: Optional[torch.Tensor] = None,
            splitk: int = 0, a_planes: Optional[Planes] = None, planes_out: Optional[Planes] = None, planes_only: bool = False,
-           dry_run: bool = False):
+           dry_run: bool = False, planes_from_col: int = 0):
     """y[..., N] = act(x[..., K] @ W^T + b) (+ residual).  x / out / residual may be strided views whose last
     dim is contiguous and which decompose into Z batches of M rows (e.g. tokens[:, :-1]).
     rope = (cos, sin, positions int64 [rows, 2] contiguous, ncols): fused RoPE2D on output columns [0, ncols).
@@ -421,7 +421,8 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=AC
     a_planes: pre-split planes of x (Planes): read instead of x when they are valid and this launch's plan can (bit-identical result).
     planes_out: Planes of the output, written when the plan can (planes_out.valid says so afterwards); planes_only: then do NOT write the
     fp32 output (`out` stays untouched; planes_out.only = True).  dry_run: launch nothing, return the siu3r_gemm_plan_t of the launch as it
-    would be issued with fp32 A (its a_x3_ok / c_x3_ok tell whether planes could be consumed / emitted)."""
+    would be issued with fp32 A (its a_x3_ok / c_x3_ok tell whether planes could be consumed / emitted).  planes_from_col (with
+    planes_out whose storage IS `out`): a mixed output -- fp32 in columns [0, planes_from_col), planes behind them."""
     _gpu(x, residual, out)
     assert x.shape[-1] == pw.k, (x.shape, pw.k)
     if out is None:
@@ -457,7 +458,8 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=AC
     _apply_ln_stats_aux(p, pw, x, out, lda, ldc, (bsa, 0, bsc, 0), ln, stats_out, aux_out)
     p.splitk = splitk
     if dry_run or a_planes is not None or planes_out is not None:
-        pl = _apply_planes(p, x, out, a_planes, planes_out, planes_only, dry_run)
+        p.c_x3_col0 = planes_from_col
+        pl = _apply_planes(p, x, out, a_planes, planes_out, planes_only and planes_from_col == 0, dry_run)
         if dry_run:
             return pl
     _gemm_launch(p)
@@ -493,10 +495,11 @@ def _apply_planes(p: GemmParams, x, out, a_planes, planes_out, planes_only, dry_
 
 def linear_grouped(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32, act=ACT_NONE, residual: Optional[torch.Tensor] = None,
                    out: Optional[torch.Tensor] = None, rope=None, ln: Optional[RowStats] = None, stats_out: Optional[RowStats] = None,
-                   aux_out: Optional[torch.Tensor] = None, flip: bool = False):
+                   aux_out: Optional[torch.Tensor] = None, flip: bool = False, planes_out: Optional[Planes] = None, planes_from_col: int = 0):
     """G weight sets in ONE launch: x [B, G, M, K] (strided, last dim contiguous) times pw = stack_packed([...G sets]) ->
     out [B, G, M, N]; group g of every batch item uses weight set g (blockIdx.z = b * G + g).  flip: group g reads the rows of
-    group G-1-g of x (and their statistics) -- the cross-attention memory of a decoder side is the other view's tokens."""
+    group G-1-g of x (and their statistics) -- the cross-attention memory of a decoder side is the other view's tokens.
+    planes_out / planes_from_col: pre-split output columns, as in linear()."""
     _gpu(x, residual, out)
     G = pw.meta["groups"]
     assert x.dim() == 4 and x.shape[1] == G and x.shape[-1] == pw.k and x.stride(3) == 1, (x.shape, G, pw.k)
@@ -521,6 +524,9 @@ def linear_grouped(x: torch.Tensor, pw: PackedWeight, *, out_dtype=torch.float32
         assert pos.dtype == torch.int64 and pos.is_contiguous() and pos.numel() == 2 * B * G * M and cos.shape[1] == 16
         p.rope_cos, p.rope_sin, p.rope_pos, p.rope_ncols = _p(cos), _p(sin), _p(pos), ncols
     _apply_ln_stats_aux(p, pw, x, out, p.lda, p.ldc, (p.sa, sa_i, p.sc, p.sc_i), ln, stats_out, aux_out, x_first=xf)
+    if planes_out is not None:
+        p.c_x3_col0 = planes_from_col
+        _apply_planes(p, x, out, None, planes_out, False, False)
     _gemm_launch(p)
     return out
 
@@ -689,9 +695,10 @@ _ATTN_SPLITKV = __import__("os").environ.get("SIU3R_NO_ATTN_SPLITKV", "0") != "1
 
 
 def attention(q, k, v, *, heads: int, head_dim: int, scale: float, rope=None, qpos=None, kpos=None,
-              mask: Optional[torch.Tensor] = None, split3=False, kv_bxor: int = 0):
+              mask: Optional[torch.Tensor] = None, split3=False, kv_bxor: int = 0, kv_planes: bool = False, dry_run: bool = False):
     """q [B,Nq,H,D] / k,v [B,Nk,H,D] strided views (D contiguous) -> out [B,Nq,H*D].  kv_bxor: batch item b attends to the keys / values
-    of batch item b ^ kv_bxor (siu3r_attn_params.kv_bxor)."""
+    of batch item b ^ kv_bxor (siu3r_attn_params.kv_bxor).  kv_planes: k and v are views of PRE-SPLIT planes (a projection written with
+    planes_from_col); dry_run: launch nothing, return whether this launch could read such planes (siu3r_attention_kv_x3_ok)."""
     _gpu(q, k, v, mask)
     B, Nq = q.shape[0], q.shape[1]
     Nk = k.shape[1]
@@ -714,6 +721,9 @@ def attention(q, k, v, *, heads: int, head_dim: int, scale: float, rope=None, qp
         p.mask, p.mask_ld = _p(mask), mask.shape[2]
     p.split3 = int(split3)
     p.kv_bxor = kv_bxor
+    p.kv_x3 = int(kv_planes)
+    if dry_run:
+        return bool(_lib.lib().siu3r_attention_kv_x3_ok(C.byref(p))) and not (q.shape[1] <= 128 and Nk >= 1024) and not _NO_PRESPLIT
     ws = None
     fast = rope is None and ((q.dtype == torch.bfloat16 and not split3) or (q.dtype == torch.float32 and split3))
     if fast and _ATTN_SPLITKV:

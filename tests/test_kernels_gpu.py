@@ -1103,3 +1103,48 @@ def test_attention_kv_of_the_partner_batch_item(mode):
     both = ops.linear(A, ops.cat_packed(parts), ln=st, out_dtype=torch.float32)
     sep = torch.cat([ops.linear(A, pw, ln=st, out_dtype=torch.float32) for pw in parts], 1)
     check(f"cat_packed[{name}] vs separate launches", both, sep, 1e-6)
+
+
+def test_attention_on_presplit_keys_and_values():
+    """The q | k | v projection writes a MIXED buffer -- q as fp32, k and v pre-split (siu3r_gemm_params.c_x3 == c, c_x3_col0 = C) -- and
+    the pipelined attention kernel reads those planes (siu3r_attn_params.kv_x3): the same bits as the fp32 route (both split K / V as
+    hi = upper 16 bits, lo = bf16(x - hi)), on the pair shape with its odd last query (side path) and with the partner batch item's
+    keys; RoPE is applied before the split; asking a kernel that cannot read planes fails loudly."""
+    from oracle import siu3r_oracle as O
+
+    ops = _ops()
+    ops.gemm_tune(0, 2)
+    try:
+        Z, N, C, H, D = 2, 1025, 768, 12, 64
+        x = gen(Z, N, C, seed=400).cuda()
+        st = ops.RowStats(x)
+        ops.linear(gen(Z, N, 64, seed=401).cuda(), ops.pack_linear(gen(C, 64, seed=402, scale=0.5).cuda(), gen(C, seed=403).cuda(), True), out=x, stats_out=st)
+        pw = ops.pack_linear_ln(gen(3 * C, C, seed=404, scale=0.05).cuda(), gen(3 * C, seed=405).cuda(), (1 + 0.2 * gen(C, seed=406)).cuda(), gen(C, seed=407).cuda(), True)
+        pw.meta["ln_eps"] = 1e-6
+        pos = torch.randint(0, 33, (Z, N, 2), generator=torch.Generator().manual_seed(9)).cuda()
+        cos, sin = O.rope2d_table(33, D)
+        rope = (cos.cuda(), sin.cuda(), pos, 2 * C)
+        att = dict(heads=H, head_dim=D, scale=D ** -0.5, split3=True)
+        ref_buf = ops.linear(x, pw, ln=st, rope=rope)
+        r5 = ref_buf.view(Z, N, 3, H, D)
+        ref = ops.attention(r5[:, :, 0], r5[:, :, 1], r5[:, :, 2], **att)
+        ref_x = ops.attention(r5[:, :, 0], r5[:, :, 1], r5[:, :, 2], kv_bxor=1, **att)
+        buf = torch.empty_like(ref_buf)
+        b5 = buf.view(Z, N, 3, H, D)
+        assert ops.attention(b5[:, :, 0], b5[:, :, 1], b5[:, :, 2], dry_run=True, **att)
+        P = ops.Planes(buf, storage=buf)
+        ops.linear(x, pw, ln=st, rope=rope, out=buf, planes_out=P, planes_from_col=C)
+        assert P.valid and not P.only
+        assert torch.equal(buf[..., :C], ref_buf[..., :C]), "q columns stay fp32"
+        got_kv = buf[..., C:].reshape(Z * N, 2 * C).cpu().contiguous().view(torch.int16)
+        assert torch.equal(got_kv, _planes_reference(ref_buf[..., C:].reshape(Z * N, 2 * C))), "k | v columns: planes of the (RoPE'd) fp32 values"
+        got = ops.attention(b5[:, :, 0], b5[:, :, 1], b5[:, :, 2], kv_planes=True, **att)
+        assert torch.equal(got, ref), f"attention on planes: max diff {(got - ref).abs().max().item():.3e}"
+        got_x = ops.attention(b5[:, :, 0], b5[:, :, 1], b5[:, :, 2], kv_planes=True, kv_bxor=1, **att)
+        assert torch.equal(got_x, ref_x)
+        qf, kf, vf = (r5[:, :, i].permute(0, 2, 1, 3).cpu() for i in range(3))
+        check("attention on planes vs fp32 torch", got, F.scaled_dot_product_attention(qf, kf, vf).permute(0, 2, 1, 3).reshape(Z, N, C), TOL_F32)
+        with pytest.raises(RuntimeError, match="kv_x3"):  # 40 keys: not the pipelined kernel
+            ops.attention(b5[:, :40, 0], b5[:, :40, 1], b5[:, :40, 2], kv_planes=True, **att)
+    finally:
+        ops.gemm_tune(0, 0)
