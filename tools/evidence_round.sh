@@ -31,6 +31,10 @@ timeout 300 python tools/config5.py bf16x3 > $O/${tag}_config5.json 2> $O/${tag}
 timeout 200 python tools/timeline.py bf16x3 1 > $O/${tag}_timeline_bf16x3.txt 2>&1
 timeout 200 python tools/timeline.py bf16 1 > $O/${tag}_timeline_bf16.txt 2>&1
 timeout 200 python tools/stage_times.py bf16x3 > $O/${tag}_stage_times.txt 2>&1
+timeout 200 python tools/mb_presplit.py > $O/${tag}_mb_presplit.txt 2>&1   # the encoder block's GEMMs with fp32 and with pre-split operands
+( for e in SIU3R_NO_PRESPLIT SIU3R_NO_DEC_QKVX SIU3R_NO_CONV_PLANES SIU3R_NO_KV_PLANES NONE; do   # same-box A/B of the round's switches
+    env $e=1 python bench.py --gpus 1 --steps 20 --warmup 5 --no-second-mode --no-roofline --no-render --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$e=1', round(d['value'], 2), 'pairs/s', round(d['ms_per_step'], 3), 'ms')"
+  done ) > $O/${tag}_switches.txt 2>&1
 if [ -n "$EVIDENCE_MICRO" ]; then  # micro-benchmarks and probes of kernels that did not change since round 3: on request
 timeout 400 python tools/mb_pp.py bench big > $O/${tag}_mb_pp.txt 2>&1
 timeout 200 python tools/mb_attn.py > $O/${tag}_mb_attn.txt 2>&1
