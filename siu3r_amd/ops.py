@@ -298,7 +298,8 @@ class Planes:
         self.t = storage if storage is not None else torch.empty_like(like)
         assert self.t.shape == like.shape and self.t.stride() == like.stride() and self.t.dtype == torch.float32
         self.valid = False
-        self.only = False  # True: the fp32 tensor was NOT written (planes-only output)
+        self.only = False  # True: the fp32 tensor was NOT written (planes-only output).  A MIXED buffer (planes_from_col: storage is the
+        # fp32 output itself, planes behind that column) keeps `only` False: its reader must know the column split, as the q | k | v users do
 
 
 _NO_PRESPLIT = bool(os.environ.get("SIU3R_NO_PRESPLIT"))  # A/B switch: never emit / consume pre-split planes
@@ -722,8 +723,6 @@ def attention(q, k, v, *, heads: int, head_dim: int, scale: float, rope=None, qp
     p.split3 = int(split3)
     p.kv_bxor = kv_bxor
     p.kv_x3 = int(kv_planes)
-    if dry_run:
-        return bool(_lib.lib().siu3r_attention_kv_x3_ok(C.byref(p))) and not (q.shape[1] <= 128 and Nk >= 1024) and not _NO_PRESPLIT
     ws = None
     fast = rope is None and ((q.dtype == torch.bfloat16 and not split3) or (q.dtype == torch.float32 and split3))
     if fast and _ATTN_SPLITKV:
@@ -739,6 +738,8 @@ def attention(q, k, v, *, heads: int, head_dim: int, scale: float, rope=None, qp
             p.splits = splits
             ws = torch.empty((B, heads, splits, qt * 128, head_dim + 4), dtype=torch.float32, device=q.device)
             p.ws = _p(ws)
+    if dry_run:  # (asked of exactly the parameter block the launch would carry, key split included)
+        return bool(_lib.lib().siu3r_attention_kv_x3_ok(C.byref(p))) and not _NO_PRESPLIT
     check(_lib.lib().siu3r_attention(C.byref(p), _stream()))
     return out
 
