@@ -389,7 +389,7 @@ class AsymmetricCroCo:
             # ONE projection launch per layer input: a side's rows make their own q | k | v (norm1 folded) AND the cross-attention memory
             # k | v of the OTHER side (that side's norm_y and projk / projv): both read the same un-normalised rows with the same row
             # statistics, the folded LayerNorms differ per output column only.  Columns [q | k | xk | v | xv]: RoPE covers the first 3 C.
-            # (two launches of 144 + 96 workgroups become one that fills the chip: 70 -> ~48 us per layer)
+            # (two launches of 144 + 96 workgroups become one of 240 that fills the chip: 70.5 -> 55.8 us per layer)
             other = {sides[0]: sides[1], sides[1]: sides[0]}
             build = lambda q: ops.cat_packed([W_.linear_ln_rows(q + ".attn.qkv", (0, 2 * Cc), q + ".norm1"),
                                               W_.linear_ln(other[q] + ".cross_attn.projk", other[q] + ".norm_y"),
