@@ -49,9 +49,9 @@ def _collective_device(device):
 
 def all_gather_stats(vec: torch.Tensor, device=None) -> torch.Tensor:
     """The single collective of the path: [world, len(STAT_KEYS)] fp64 on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return vec[None].clone()
-    world = dist.get_world_size()
+    world = dist.get_world_size()  # (a group of one still runs the collective: the single-GPU RCCL test relies on it)
     device = _collective_device(device)
     v = vec.to(device) if device is not None else vec.cpu()
     out = [torch.empty_like(v) for _ in range(world)]
@@ -67,7 +67,7 @@ def reduce_stats(gathered: torch.Tensor) -> Dict[str, float]:
 
 
 def max_over_ranks(x: float, device=None) -> float:
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return x
     t = torch.tensor([x], dtype=torch.float64, device=_collective_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -75,5 +75,5 @@ def max_over_ranks(x: float, device=None) -> float:
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
