@@ -37,6 +37,7 @@ for key, e in sorted(agg.items()):
     lines.append("    {%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d},  // %.1f -> %.1f us per step (%s)" % (*key, best[0], best[1], e["auto"], full[best], e["src"]))
 # measured by hand (tile AND split count swept: the replay tries each tile with the slice count the model would give it)
 MANUAL = [
+    "    {262144, 83, 256, 2, 0, 0, 0, 0, 1, 0, -1, 1},  // 310 -> 267 us (tools/mb_head4.py, round 4: the Gaussian head's last layer, ragged N = 83: the replay of this round measured 272 vs 249 us, under the generator's margin, and the entry fell out)",
     "    {2050, 1024, 4096, 1, 0, 0, 0, 0, 1, 0, 2, 2},  // 88.1 -> 74.5 us (tools/mb_skinny.py, round 4: nine row tiles of 256 x 128, two K slices, no remainder launch)",
 ]
 have = {l.split("}")[0] for l in lines}
