@@ -129,15 +129,31 @@ def main():
     ap.add_argument("--no-render", action="store_true")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, the contract's own command line)
+        # instead of silently timing one rank and printing n_gpus = 1
+        if torch.cuda.device_count() < args.gpus:
+            raise RuntimeError(f"--gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s)")
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+
     from siu3r_amd import distributed as D
     from siu3r_amd import ops
     from siu3r_amd.model import SIU3RModel
     from siu3r_amd import synthetic_weights as OW  # shared synthetic-weight generator (no checkpoint offline)
 
     rank, local, world = D.init_from_env()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    if not torch.cuda.is_available():
-        raise RuntimeError("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if world != args.gpus:
+        raise RuntimeError(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or without a launcher: bench.py spawns the ranks itself)")
     local = local % torch.cuda.device_count()  # (lets a gloo dry run put two ranks on one GPU; one GPU per rank otherwise)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -230,29 +246,68 @@ def main():
             second["roofline"] = gemm_roofline(m2, step2, second["precision"], B, H, W)
 
     if not args.no_render:
-        result.update(render_legs(gauss, B, H, W, dev, world))
+        result.update(render_legs(gauss, B, H, W, dev, world, step=step))
 
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baselines(images, K, H, W)
     print(json.dumps(result))
 
 
-def gemm_roofline(model, step, precision, B, H, W):
-    """roofline object of the mode's dominant kernel: HIP events around every GEMM launch of one eager single-stream step, queued behind
-    a sleep kernel so that the pairs time the kernels back to back (after the timed region).  "Kernel" = the source-level kernel (a
+def _profile_kernel_stats():
+    """newest committed rocprofv3 --kernel-trace --stats summary of this command: {kernel name: (calls, average ns)}"""
+    import csv
+    path = _latest_profile("bench_kernel_stats.csv")
+    if not os.path.exists(path):
+        return None, {}
+    rows = {}
+    for r in csv.DictReader(open(path)):
+        try:
+            rows[r["Name"]] = (int(r["Calls"]), float(r["TotalDurationNs"]) / max(1, int(r["Calls"])))
+        except (KeyError, ValueError):
+            pass
+    return "profiles/" + os.path.basename(path), rows
+
+
+def gemm_roofline(model, step, precision, B, H, W, passes=3):
+    """roofline object of the mode's dominant kernel, MEASURED in this run: HIP events around every GEMM launch (on the launch stream)
+    of eager single-stream steps, each queued behind a sleep kernel so that the event pairs time the kernels back to back.  One
+    UNTIMED eager pass first (the eager path's own buffers, split-K workspaces and lazily packed operands are touched for the first
+    time there: round 4's single un-warmed pass read 4-9x too slow on two instantiations), then `passes` timed passes; every
+    instantiation's time is the MEDIAN over the passes of its summed launch time in a pass.  "Kernel" = the source-level kernel (a
     function template: rocprofv3 lists each instantiation -- tile shape, A-operand mode, fused LayerNorm -- as its own row, and the
     ping-pong GEMM runs as a dozen of them); the dominant one is the one with the largest summed launch time.  achieved = its
-    launches' 2 M N K / their summed durations; `instantiations` lists the rows it is made of."""
+    launches' 2 M N K / their summed (median) durations; `instantiations` lists the rows it is made of.  `traffic` and
+    `mfma_busy_counter_frac` need hardware counters (rocprofv3 --pmc: not collectable from inside the process): they are read from the
+    newest committed counter pass and say so (`traffic_live` / `mfma_busy_live` = false)."""
+    import statistics
     from siu3r_amd import ops
 
-    timer = ops.KernelTimer()
-    ops.set_kernel_timer(timer)
     conc, model._ctx.concurrent = model._ctx.concurrent, False  # one stream: every launch between its own two events
-    torch.cuda._sleep(int(2.0e8))  # ~0.1 s: the whole step is enqueued before it runs
-    step()
-    model._ctx.concurrent = conc
-    ops.set_kernel_timer(None)
-    summ = timer.summary()
+
+    def eager_pass(timed):
+        timer = ops.KernelTimer() if timed else None
+        ops.set_kernel_timer(timer)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(int(2.0e8))  # ~0.1 s: the whole step is enqueued before it runs
+        e0.record()
+        step()
+        e1.record()
+        ops.set_kernel_timer(None)
+        torch.cuda.synchronize()
+        return (timer.summary() if timed else None), e0.elapsed_time(e1)
+
+    try:
+        eager_pass(False)
+        runs = [eager_pass(True) for _ in range(max(3, passes))]
+    finally:
+        model._ctx.concurrent = conc
+        ops.set_kernel_timer(None)
+    eager_step_ms = statistics.median(r[1] for r in runs)
+    summ = {}
+    for k in runs[0][0]:
+        per = [r[0][k] for r in runs if k in r[0]]
+        summ[k] = dict(launches=per[0]["launches"], flops=per[0]["flops"], ms=statistics.median(p_["ms"] for p_ in per),
+                       ms_min=min(p_["ms"] for p_ in per), ms_max=max(p_["ms"] for p_ in per))
     fams = {}
     for k, v in summ.items():
         f = fams.setdefault(_family(k), dict(launches=0, flops=0.0, ms=0.0))
@@ -260,7 +315,7 @@ def gemm_roofline(model, step, precision, B, H, W):
             f[key] += v[key]
     name, d = max(fams.items(), key=lambda kv: kv[1]["ms"])
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-    passes = 3 if precision == "bf16x3" else 1
+    npass = 3 if precision == "bf16x3" else 1
     traffic, traffic_src = (None, None)
     if B == 1 and (H, W) == (512, 512):
         traffic, traffic_src = pmc_bytes(f"bench_{precision}", name)
@@ -271,24 +326,41 @@ def gemm_roofline(model, step, precision, B, H, W):
         if act > 0:
             busy = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] for v in rows) / (act / 8.0 * 1024.0)
     variants = lambda pred: {k: {"launches": v["launches"], "ms": v["ms"], "avg_launch_us": v["ms"] * 1e3 / v["launches"],
+                                 "avg_launch_us_min_max_over_passes": [v["ms_min"] * 1e3 / v["launches"], v["ms_max"] * 1e3 / v["launches"]],
                                  "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]) if pred(k)}
+    # consistency: (i) the kernels of one serial step cannot take longer than the step; (ii) the committed rocprofv3 summary of the
+    # same command must agree on the dominant kernel's average launch duration
+    gemm_ms = sum(v["ms"] for v in summ.values())
+    avg_us = d["ms"] * 1e3 / d["launches"]
+    prof_name, prof = _profile_kernel_stats()
+    prow = [(c, ns) for n, (c, ns) in prof.items() if _family(n.replace("void ", "")) == name and (("<true" in n) == (precision == "bf16x3"))]
+    prof_avg_us = sum(c * ns for c, ns in prow) / max(1, sum(c for c, _ in prow)) / 1e3 if prow else None
+    check = {"dominant_ms_le_eager_step": bool(d["ms"] <= eager_step_ms), "gemm_ms_le_eager_step": bool(gemm_ms <= eager_step_ms),
+             "eager_single_stream_step_ms": eager_step_ms, "profile": prof_name, "profile_avg_launch_us": prof_avg_us,
+             "ratio_to_profile": (avg_us / prof_avg_us) if prof_avg_us else None,
+             "agrees_with_profile_within_10pct": bool(abs(avg_us / prof_avg_us - 1.0) <= 0.10) if prof_avg_us else None}
+    if not check["gemm_ms_le_eager_step"] or check["agrees_with_profile_within_10pct"] is False:
+        print(f"bench.py: roofline consistency check: {check}", file=sys.stderr)
     return {
         "kernel": name,
         "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-        "mfma_passes_per_product": passes, "mfma_issue_frac": achieved * passes / MFMA_BF16_PEAK_TFLOPS,
-        "mfma_busy_counter_frac": busy, "mfma_busy_source": "profiles/" + os.path.basename(BUSY_FILE) + " (SQ_VALU_MFMA_BUSY_CYCLES pass, all instantiations)" if busy is not None else None,
-        "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+        "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "traffic_live": False,
+        "timing": f"HIP events per launch on the launch stream, {len(runs)} warm eager single-stream passes after one untimed pass, median per instantiation",
+        "mfma_passes_per_product": npass, "mfma_issue_frac": achieved * npass / MFMA_BF16_PEAK_TFLOPS,
+        "mfma_busy_counter_frac": busy, "mfma_busy_live": False,
+        "mfma_busy_source": "profiles/" + os.path.basename(BUSY_FILE) + " (SQ_VALU_MFMA_BUSY_CYCLES pass, all instantiations)" if busy is not None else None,
+        "launches_per_step": d["launches"], "avg_launch_us": avg_us,
         "algorithmic_flops_per_launch_avg": d["flops"] / d["launches"],
-        "share_of_gemm_time": d["ms"] / sum(v["ms"] for v in summ.values()),
-        "gemm_time_ms_per_step": sum(v["ms"] for v in summ.values()),
-        "gemm_tflops_all_kernels": sum(v["flops"] for v in summ.values()) / (sum(v["ms"] for v in summ.values()) * 1e-3) / 1e12,
+        "share_of_gemm_time": d["ms"] / gemm_ms,
+        "gemm_time_ms_per_step": gemm_ms,
+        "gemm_tflops_all_kernels": sum(v["flops"] for v in summ.values()) / (gemm_ms * 1e-3) / 1e12,
+        "consistency": check,
         "instantiations": variants(lambda k: _family(k) == name),
         "other_gemm_kernels": variants(lambda k: _family(k) != name),
     }
 
 
-def render_legs(gauss, B, H, W, dev, world):
+def render_legs(gauss, B, H, W, dev, world, step=None):
     """render ms/frame (the metric's second half) through the product path, K2 semantics (SplattingCUDA.forward: colour + depth):
       render             the network's own Gaussians (synthetic weights: few of them land in view)
       render_pair_scene  a pixel-aligned 2 x H x W Gaussian set as a trained network emits for an indoor pair (>= 50 % in view)
@@ -333,11 +405,34 @@ def render_legs(gauss, B, H, W, dev, world):
                              "note": "whole per-frame pipeline (project, per-view radix sort, coarse binning, composite), incl. host-side camera prep"}}
 
     out["render"] = leg(gauss.means, gauss.covariances, gauss.harmonics, gauss.opacities, "the network's own output (synthetic weights)")
+
+    if step is not None:
+        # SURVEY 8(d) config 2, second figure: network + 6-view colour render per pair, every step complete (forward incl. its host
+        # pick-up of the segment table, then SplattingCUDA.forward on that step's own Gaussians: in-place x10 rescale as in the reference)
+        ext_b, Kt_b = ext1[None].repeat(B, 1, 1, 1), Kt1[None].repeat(B, 1, 1, 1)
+
+        def both():
+            g_ = step()[0]
+            return rend.forward(g_, ext_b, Kt_b, (H, W), render_color=True)
+
+        both()
+        torch.cuda.synchronize()
+        n_it = 10
+        t0 = time.perf_counter()
+        for _ in range(n_it):
+            both()
+        torch.cuda.synchronize()
+        dt_b = (time.perf_counter() - t0) / n_it
+        rend.check_pending()
+        out["network_plus_render"] = {"value": B / dt_b, "unit": "image-pairs/s", "ms_per_step": dt_b * 1e3, "views_rendered_per_pair": nv,
+                                      "resolution": [H, W], "what": "forward (as in the timed region) + SplattingCUDA.forward colour + depth of 6 target views per pair, "
+                                      f"wall clock over {n_it} steps on this rank"}
     pm, pc, po, ps = (t.to(dev) for t in synthetic.pixel_aligned_scene(H, W, 2, seed=0))
     out["render_pair_scene"] = leg(pm[None], pc[None], ps[None], po[None], "siu3r_amd.synthetic.pixel_aligned_scene(seed=0): 2 views x H x W pixel-aligned Gaussians of an indoor pair")
     if (H, W) == (512, 512):
         t, src = pmc_frame_bytes("raster_pair", nv)
         out["render_pair_scene"]["roofline"]["traffic"], out["render_pair_scene"]["roofline"]["traffic_source"] = t, src
+    out["render_qc_logits"] = logit_leg(pm, pc, po, ext1, Kt1, H, W, nv, q=8, classes=21)
     del pm, pc, po, ps
 
     if world == 1:
@@ -367,6 +462,42 @@ def render_legs(gauss, B, H, W, dev, world):
                                              "frac": b_s / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_view": b_s, "traffic": t, "traffic_source": src}}
         del m_, cov_, op_, sh_, o
     return out
+
+
+def logit_leg(means, cov, opac, ext, Kt, H, W, nv, q=8, classes=21):
+    """SURVEY 8(d) config 5, C-channel variant: the query x class logit render of the evaluation loop (reference
+    src/models/gaussian_renderer.py:81-110: gsplat semantics, C = q * 21 feature channels per Gaussian, rendered in 32-channel chunks
+    over one set of materialised per-tile lists), q = 8 kept queries -> 168 channels, the pixel-aligned pair scene, 6 views in one
+    call.  Algorithmic bytes per view: (44 + 4C) G + 36 G_v + (76 + 4C) D + (4C + 4) P."""
+    from siu3r_amd import raster
+
+    dev = means.device
+    G, Cc = means.shape[0], q * classes
+    gen = torch.Generator().manual_seed(5)
+    feats = torch.randn(G, Cc, generator=gen).to(dev)
+    e = ext.clone()
+    e[:, :3, 3] *= 10.0  # SplattingCUDA.forward's scene rescale (x10 means, x100 covariances, near = 1, far = 1000)
+    m10, c100 = (means * 10.0).contiguous(), (cov * 100.0).contiguous()
+    cams = []
+    for j in range(nv):
+        Kp = Kt[j].clone()
+        Kp[0, :] *= W
+        Kp[1, :] *= H
+        cams.append(raster.make_cam_k3(torch.linalg.inv(e[j]), Kp[0, 0], Kp[1, 1], Kp[0, 2], Kp[1, 2], W, H, near_plane=1.0, far_plane=1000.0))
+    run = lambda: raster.rasterize_views_k3(cams, m10, c100, opac, feats)
+    o = run()
+    o = run()  # (pair-list capacity remembered by the first call)
+    st = o["state"]
+    Gv, Dp = st.totals(0), st.totals(1)
+    ms_frame = event_ms(run, 5) / nv
+    bytes_alg = sum(raster.algorithmic_bytes(G, gv, d, H * W, channels=Cc) for gv, d in zip(Gv, Dp)) / nv
+    ach = bytes_alg / (ms_frame * 1e-3) / 1e9
+    return {"ms_per_frame": ms_frame, "views": nv, "resolution": [H, W], "gaussians": G, "channels": Cc, "kept_queries": q, "visible_mean": sum(Gv) / nv,
+            "tile_pairs_mean": sum(Dp) / nv, "scene": "siu3r_amd.synthetic.pixel_aligned_scene(seed=0) with seeded normal features [G, q*21]",
+            "semantics": "K3 (gsplat.rasterization family): N-channel features, per-tile lists materialised once, 32 channels per composite pass; "
+                         "overflow counters read after every call (one device synchronisation per call, as the evaluation loop runs it)",
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_view": bytes_alg, "formula": "(44+4C) G + 36 G_v + (76+4C) D + (4C+4) P", "traffic": None}}
 
 
 def cpu_baselines(images, K, H, W):

@@ -117,7 +117,8 @@ def panoptic_stats(pred_sem, pred_ins, gt_sem, gt_ins, things: Sequence[int] = T
                    num_classes: int = NUM_CLASSES) -> np.ndarray:
     """One update of PanopticQuality: returns [num_classes, 4] = (sum IoU of TPs, TP, FP, FN) per category.
     A predicted and a ground-truth segment of the same category match iff IoU > 0.5 (unique by construction), where the union
-    excludes the part of the prediction that lies on void ground truth; unmatched predictions mostly (> 50 %) on void ground truth
+    excludes the part of the prediction that lies on void ground truth AND the part of the ground-truth segment that lies under
+    void prediction (torchmetrics _calculate_iou: both void overlaps leave the union); unmatched predictions mostly (> 50 %) on void ground truth
     are not FPs and, symmetrically, unmatched ground-truth segments mostly covered by void PREDICTION (unknown categories become
     void under allow_unknown_preds_category) are not FNs (torchmetrics _panoptic_quality_update_sample, after COCO panopticapi)."""
     p_col, p_cat = _segments(np.asarray(pred_sem), np.asarray(pred_ins), things, stuffs, True)
@@ -133,7 +134,8 @@ def panoptic_stats(pred_sem, pred_ins, gt_sem, gt_ins, things: Sequence[int] = T
     for (pc, gc), n in inter.items():
         if pc // 100000 == 0 or gc // 100000 == 0 or pc // 100000 != gc // 100000:
             continue
-        union = p_area[pc] + g_area[gc] - n - inter.get((pc, 0), 0)
+        # torchmetrics _calculate_iou: union = pred - pred_on_void_target + target - target_under_void_prediction - intersection
+        union = p_area[pc] + g_area[gc] - n - inter.get((pc, 0), 0) - inter.get((0, gc), 0)
         iou = n / union
         if iou > 0.5:
             c = pc // 100000
