@@ -26,7 +26,7 @@ extern "C" {
 #define SIU3R_F64 3
 
 const char* siu3r_last_error(void);
-#define SIU3R_ABI_VERSION 6 /* 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok), siu3r_attn_params.kv_bxor / kv_x3, siu3r_gemm_params.c_x3_col0; 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
+#define SIU3R_ABI_VERSION 7 /* 7: device-side poses for the gsplat seam (siu3r_raster_project_dp, siu3r_sh_eval_dp, siu3r_blend_background_dp), precomputed K2 colours (sh_degree < 0), all-channel list composite; 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok), siu3r_attn_params.kv_bxor / kv_x3, siu3r_gemm_params.c_x3_col0; 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
 int siu3r_abi_version(void);
 
 /* ---- seam 1: curope.rope_2d(tokens, positions, base, fwd)
@@ -263,7 +263,7 @@ typedef struct {
   float tanfovx, tanfovy;
   float campos[3];
   float bg[3];
-  int32_t sh_degree;   /* K2: 0..4 */
+  int32_t sh_degree;   /* K2: 0..4; -1 = `colors` are precomputed [G,3] colours, blended as given (no SH, no +0.5, no clamp) */
   int32_t sh_band4;    /* K2: evaluate SH coefficients 16..24 (open question of the fork; default 0) */
   float k2_znear_cull; /* 0.2 */
   float fx, fy, cx, cy; /* K3: pixel-unit intrinsics */
@@ -292,6 +292,14 @@ int siu3r_raster_geometry(int width, int height, int64_t G, int32_t* out8);
 int siu3r_raster_project(const siu3r_raster_cam* cams_host, int V, void* cams_dev, int64_t G, const float* means, const float* cov,
                          int cov_stride, const float* opacities, const float* colors, int channels, int sh_planar, float* rec,
                          int32_t* radii, int32_t* rect, int32_t* tiles_touched, uint32_t* keys, uint64_t* stats, void* stream);
+/* the same with the POSE in device memory, gsplat family (mode 1) only -- what gsplat.rasterization receives (reference
+ * src/models/gaussian_renderer.py:92-106, viewer.py:319-335): viewmats_dev [V,4,4] world->camera and Ks_dev [V,3,3] pixel-unit
+ * intrinsics, row-major fp32 device tensors; they overwrite w2c / fx / fy / cx / cy of the uploaded camera blocks on the stream, so that
+ * the host never reads a pose back (no synchronisation).  cams_host carries everything else (frame size, planes, thresholds). */
+int siu3r_raster_project_dp(const siu3r_raster_cam* cams_host, int V, void* cams_dev, const float* viewmats_dev, const float* Ks_dev, int64_t G,
+                            const float* means, const float* cov, int cov_stride, const float* opacities, const float* colors, int channels,
+                            int sh_planar, float* rec, int32_t* radii, int32_t* rect, int32_t* tiles_touched, uint32_t* keys, uint64_t* stats,
+                            void* stream);
 /* stage 2: per view, stable LSD radix sort (4 x 8 bits) of keys_a [V,G] with the Gaussian index as payload; keys_b / ids_a / ids_b
  * [V,G] ping-pong buffers; rs_hist i32 [V,256,nchunks_sort], rs_tot i32 [V,256]; stats: stage 1's counters (device).  Culled Gaussians
  * (key 0xffffffff) leave the sort in its first pass: the result is the (depth, id)-ordered list of the n = stats[v][0] VISIBLE Gaussians in
@@ -356,6 +364,10 @@ int siu3r_quat_scale_to_cov6(const float* quats_wxyz, const float* scales, float
 int siu3r_sh_eval(const float* means, const float* campos3_host, const float* sh, int ncoef, int degree, float* rgb, int64_t G, void* stream);
 /* colors[pixels, channels] += (1 - alpha[pixels]) * bg[channels]; bg_host is a HOST pointer, channels <= 3 */
 int siu3r_blend_background(float* colors, const float* alpha, const float* bg_host, int channels, int64_t pixels, void* stream);
+/* the two helpers with their small operand in DEVICE memory (no host round trip of a pose / background tensor): campos3_dev = 3 floats,
+ * bg_dev = `channels` floats (any channel count) */
+int siu3r_sh_eval_dp(const float* means, const float* campos3_dev, const float* sh, int ncoef, int degree, float* rgb, int64_t G, void* stream);
+int siu3r_blend_background_dp(float* colors, const float* alpha, const float* bg_dev, int channels, int64_t pixels, void* stream);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,7 @@ typedef struct {
   float tanfovx, tanfovy;
   float campos[3];
   float bg[3];
-  int32_t sh_degree;   /* 0..4; band 4 (coefficients 16..24) only evaluated when sh_band4 != 0 */
+  int32_t sh_degree;   /* 0..4; band 4 (coefficients 16..24) only evaluated when sh_band4 != 0; -1: colors = precomputed [G,3] */
   int32_t sh_band4;
   float k2_znear_cull; /* 0.2: p_view.z <= this is culled (the constant inside the CUDA kernel) */
   /* K3 */
@@ -73,6 +73,12 @@ static void sh_to_rgb(const raster_cam* c, const float* mean, const float* sh, f
   float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
   float x = dx * inv, y = dy * inv, z = dz * inv;
   int deg = c->sh_degree;
+  if (deg < 0) { /* `colors_precomp` of the CUDA package (cuda_splatting.py:112, use_sh = False): blended as given */
+    rgb[0] = sh[0];
+    rgb[1] = sh[1];
+    rgb[2] = sh[2];
+    return;
+  }
   for (int ch = 0; ch < 3; ++ch) {
 #define S(i) sh[(i) * 3 + ch]
     float r = SH_C0 * S(0);

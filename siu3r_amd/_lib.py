@@ -84,7 +84,7 @@ class RasterCam(C.Structure):
 
 # name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/siu3r_hip.h.
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
-ABI_VERSION = 6  # SIU3R_ABI_VERSION of include/siu3r_hip.h these ctypes declarations mirror
+ABI_VERSION = 7  # SIU3R_ABI_VERSION of include/siu3r_hip.h these ctypes declarations mirror
 
 SIGNATURES = {
     "siu3r_last_error": [],
@@ -122,6 +122,9 @@ SIGNATURES = {
     "siu3r_quat_scale_to_cov6": [_P, _P, _P, _L, _P],
     "siu3r_sh_eval": [_P, _P, _P, _I, _I, _P, _L, _P],
     "siu3r_blend_background": [_P, _P, _P, _I, _L, _P],
+    "siu3r_sh_eval_dp": [_P, _P, _P, _I, _I, _P, _L, _P],
+    "siu3r_blend_background_dp": [_P, _P, _P, _I, _L, _P],
+    "siu3r_raster_project_dp": [C.POINTER(RasterCam), _I, _P, _P, _P, _L, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "siu3r_lift_ids": [_P, _I, _I, _I, _I, _I, _F, _I, C.c_uint32, _P, _P, _P, _P, _P],
     "siu3r_panoptic_stage1": [_P] * 20 + [_I] * 9 + [_F, _F, _F, C.c_uint32, _P],
     "siu3r_panoptic_qcl": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],

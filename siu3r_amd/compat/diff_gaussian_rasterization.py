@@ -61,14 +61,11 @@ class GaussianRasterizer:
             raise Exception("pose gradients (theta, rho) are training-only")
         s = self.raster_settings
         cam = make_cam(s)
-        if shs is None:  # precomputed colours = SH degree 0 with the DC term that reproduces them: c = 0.28209479 * sh + 0.5
-            # LIMITATION: the SH colour path clamps at zero (max(c, 0)), the upstream package blends precomputed colours unclamped.
-            # The reference only passes shs (use_sh=True, cuda_splatting.py:104-118); negative / feature-valued colors_precomp are refused
-            # instead of being rendered differently from upstream.
-            if bool((colors_precomp < 0).any()):
-                raise Exception("colors_precomp < 0 is not supported by this rasterizer (its colour path clamps at zero); pass shs, or non-negative colours")
-            shs = ((colors_precomp - 0.5) / 0.28209479177387814)[:, None, :]
-            cam.sh_degree = 0
+        if shs is None:
+            # precomputed colours: blended as given, like the upstream package (no SH evaluation, no clamp: feature-valued or negative
+            # colours keep their sign) -- siu3r_raster_cam.sh_degree = -1, colours [G, 1, 3]
+            shs = colors_precomp.reshape(-1, 1, 3)
+            cam.sh_degree = -1
         o = raster.rasterize_k2(cam, means3D, cov3D_precomp, shs, opacities.reshape(-1))
         return o["image"], o["radii"][:, 0].contiguous(), o["depth"][None], o["opacity"][None], o["n_touched"]
 

@@ -234,13 +234,20 @@ __global__ __launch_bounds__(256) void project_kernel(const Cam* __restrict__ ca
     rp[0] = make_float4(mx, my, tz, 0.f);
     rp[1] = make_float4(ca, cb, cc, opacity);
     // positive floats order like their bit patterns; culled Gaussians sort behind every visible one
-    keys[o] = valid ? __float_as_uint(tz) : 0xffffffffu;
+    // (0xffffffff is reserved for "culled": the sort drops exactly those keys and trusts stats[ST_GV] = the number of valid flags, so
+    // the two must agree by construction -- a valid Gaussian whose depth has that bit pattern, a NaN payload, is clamped below it)
+    keys[o] = valid ? min(__float_as_uint(tz), 0xfffffffeu) : 0xffffffffu;
     if (valid && c.mode == 1 && colors && channels == 3) {
       // gsplat family with three precomputed colour channels (the viewer's view-dependent RGB): the colour travels in the record, so
       // that the fused sort-free composite (no per-tile lists in HBM) serves this path too
       rp[2] = make_float4(colors[3 * g], colors[3 * g + 1], colors[3 * g + 2], 0.f);
     }
-    if (valid && c.mode == 0) {
+    if (valid && c.mode == 0 && c.sh_degree < 0) {
+      // precomputed colours (the package's `colors_precomp`, cuda_splatting.py:112 use_sh = False): [G, 3], blended as given -- no SH
+      // evaluation, no +0.5, no clamp at zero (feature-valued colours keep their sign)
+      rp[2] = make_float4(colors[3 * g], colors[3 * g + 1], colors[3 * g + 2], 0.f);
+    }
+    if (valid && c.mode == 0 && c.sh_degree >= 0) {
       const float dx = m0 - c.campos[0], dy = m1 - c.campos[1], dz = m2 - c.campos[2];
       const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
       const float x = dx * inv, y = dy * inv, z = dz * inv;
@@ -1057,8 +1064,14 @@ __global__ void quat_scale_cov6_kernel(int64_t G, const float* quats, const floa
 // loads and read back lane by lane: a lane reading its own 300-byte block straight from global memory touches 64 cache lines per load
 // instruction (the kernel then ran at 1.6 TB/s; the algorithm reads every byte once).
 template <int DEG>
-__global__ __launch_bounds__(256) void sh_eval_kernel(int64_t G, int ncoef, const float* means, float cx, float cy, float cz, const float* sh, float* rgb) {
+__global__ __launch_bounds__(256) void sh_eval_kernel(int64_t G, int ncoef, const float* means, float cx, float cy, float cz, const float* sh, float* rgb,
+                                                      const float* campos_dev) {
   extern __shared__ __attribute__((aligned(16))) float s_sh[];
+  if (campos_dev) {  // camera position handed over in device memory (no host round trip of the pose)
+    cx = campos_dev[0];
+    cy = campos_dev[1];
+    cz = campos_dev[2];
+  }
   const int nf = ncoef * 3;
   {
     const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
@@ -1124,6 +1137,161 @@ __global__ void blend_bg_kernel(int64_t n, int C, float* colors, const float* al
   colors[i] = colors[i] + (1.0f - alpha[p]) * b;
 }
 
+// ---- K3 composite, second form: ALL channels of a tile in one workgroup, weights evaluated once, blended sparsely -------------------
+// The 32-channel kernel above re-walks the tile's list (and re-evaluates every alpha) once per channel chunk and spends 32 FMAs per
+// (lane, entry) whether or not the lane's pixel is touched: with q x 21 = 168 logit channels of a pixel-aligned scene a tile lists ~900
+// Gaussians of which ~70 reach any given pixel, so 92 % of those FMAs multiply by zero and the alphas are computed six times.
+// Here a wave owns an 8 x 8 pixel quadrant and alternates between two lane roles per batch of NB = 32 list entries:
+//   phase 1, lane = pixel : the batch's entries whose alpha >= alpha_min footprint can reach the quadrant (a conservative extent test
+//                           done once per entry at load time) are evaluated exactly as before -- same expressions, same order: alpha,
+//                           transmittance chain, early termination -- and each lane leaves its blending weights w = alpha * T in LDS
+//                           together with a 32-bit mask of the entries that contributed to ITS pixel;
+//   phase 2, lane = channel: for every pixel of the quadrant (static loop, the pixel's accumulators are registers) the wave walks that
+//                           pixel's mask in list order and does acc[c] = fma(f[j][c], w, acc[c]) for the 64 * CPL channels of the
+//                           chunk: the feature row of an entry is read from LDS lane-contiguously, the weight travels as a scalar
+//                           (v_readlane of the pixel's weight vector).
+// Work is proportional to the (pixel, Gaussian) pairs that actually blend; per pixel and channel the FMAs are the oracle's, in the
+// oracle's order, so the maps are bit-identical to the 32-channel kernel's (tests/test_raster_gpu.py).
+template <int CPL>
+__global__ __launch_bounds__(256, 2) void composite_feat2_kernel(const Cam* __restrict__ cams, Geo geo, const int32_t* __restrict__ tile_start,
+                                                                 const int32_t* __restrict__ ids, int64_t cap_d, const float* __restrict__ rec,
+                                                                 const float* __restrict__ feats, int channels, int64_t G, float* __restrict__ out,
+                                                                 float* __restrict__ out_alpha) {
+  constexpr int NB = 32, CW = 64 * CPL;
+  __shared__ float s_xy[NB][2];
+  __shared__ __attribute__((aligned(16))) float s_co[NB][4];
+  __shared__ unsigned s_qm[4];
+  __shared__ __attribute__((aligned(16))) float s_f[NB][CW];
+  __shared__ float s_w[4][64][NB + 1];
+  const int v = blockIdx.z;
+  const Cam& c = cams[v];
+  const int tile = blockIdx.x, tx = tile % geo.gw, ty = tile / geo.gw;
+  const int ch0 = blockIdx.y * CW, nch = min(CW, channels - ch0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
+  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+  const int width = c.width, height = c.height;
+  const bool inside = px < width && py < height;
+  const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
+  const int32_t* ts = tile_start + (int64_t)v * (geo.T + 2);
+  const int32_t* idp = ids + (int64_t)v * cap_d;
+  const int64_t vg = (int64_t)v * G;
+  const int beg = ts[tile], end = ts[tile + 1];
+  const float alpha_min = c.alpha_min, alpha_max = c.alpha_max, t_min = c.t_min;
+  const bool vec4 = (channels & 3) == 0 && (((uintptr_t)feats) & 15) == 0;
+  float T = 1.0f, O = 0.f;
+  float acc[64][CPL];
+#pragma unroll
+  for (int p = 0; p < 64; ++p)
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) acc[p][k] = 0.f;
+  bool done = !inside;
+  for (int base = beg; base < end; base += NB) {
+    if (__syncthreads_count(done) == 256) break;  // (also orders the previous batch's LDS reads before this batch's writes)
+    const int cnt = min(NB, end - base);
+    if (threadIdx.x < NB) {  // wave 0, lanes 0..31: the batch's records + which quadrants each entry can reach
+      unsigned bits = 0;
+      if (threadIdx.x < cnt) {
+        const float4* rp = (const float4*)(rec + 12 * (vg + idp[base + threadIdx.x]));
+        const float4 r0 = rp[0], r1 = rp[1];
+        *(float2*)s_xy[threadIdx.x] = make_float2(r0.x, r0.y);
+        *(float4*)s_co[threadIdx.x] = r1;
+        // alpha >= alpha_min  <=>  sigma <= L = ln(opacity / alpha_min); on that ellipse |dx| <= sqrt(2 L c / det), |dy| <= sqrt(2 L a / det).
+        // Conservative (margins far above the rounding of exp_det and of this bound): an entry dropped here can never pass the
+        // per-pixel test below, an entry kept needlessly only costs time.
+        const float det = r1.x * r1.z - r1.y * r1.y;
+        const float L = logf(r1.w / alpha_min) * 1.001f + 0.001f;
+        bits = 0xfu;
+        if (L < 0.f) bits = 0;
+        else if (det > 0.f && L == L) {
+          const float ex = sqrtf(2.0f * L * r1.z / det) + 0.01f, ey = sqrtf(2.0f * L * r1.x / det) + 0.01f;
+          if (ex == ex && ey == ey) {
+            const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
+            const bool xl = r0.x - ex <= tx0 + 7.5f && r0.x + ex >= tx0 + 0.5f, xr = r0.x - ex <= tx0 + 15.5f && r0.x + ex >= tx0 + 8.5f;
+            const bool yt = r0.y - ey <= ty0 + 7.5f && r0.y + ey >= ty0 + 0.5f, yb = r0.y - ey <= ty0 + 15.5f && r0.y + ey >= ty0 + 8.5f;
+            bits = (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned long long m = __ballot((bits >> q) & 1u);
+        if (lane == 0) s_qm[q] = (unsigned)m;
+      }
+    }
+    if (vec4) {
+      for (int e = threadIdx.x; e < cnt * (CW / 4); e += 256) {
+        const int j = e / (CW / 4), c4 = (e - j * (CW / 4)) * 4;
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 < nch) f = *(const float4*)(feats + (size_t)idp[base + j] * channels + ch0 + c4);  // (nch % 4 == 0 here)
+        *(float4*)&s_f[j][c4] = f;
+      }
+    } else {
+      for (int e = threadIdx.x; e < cnt * CW; e += 256) {
+        const int j = e / CW, k = e - j * CW;
+        s_f[j][k] = k < nch ? feats[(size_t)idp[base + j] * channels + ch0 + k] : 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- phase 1: lane = pixel
+    unsigned pm = 0;
+    if (__ballot(!done) != 0ull) {
+      unsigned qm = (unsigned)__builtin_amdgcn_readfirstlane((int)s_qm[wave]);
+      for (; qm; qm &= qm - 1u) {
+        const int j = __builtin_ctz(qm);
+        if (done) continue;
+        const float dx = s_xy[j][0] - pxf, dy = s_xy[j][1] - pyf;
+        const float4 co = *(const float4*)s_co[j];
+        const float sigma = conic_sigma(co.x, co.y, co.z, dx, dy);
+        if (sigma < 0.0f) continue;
+        const float a = fminf(alpha_max, co.w * exp_det(-sigma));
+        if (a < alpha_min) continue;
+        const float nT = __builtin_fmaf(-T, a, T);
+        if (nT <= t_min) {
+          done = true;
+          continue;
+        }
+        const float w = a * T;
+        s_w[wave][lane][j] = w;
+        pm |= 1u << j;
+        O += w;
+        T = nT;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- phase 2: lane = channel (the wave's own LDS writes above are complete before its reads below: DS operations of a wave
+    // execute in order)
+    if (__ballot(pm != 0u) != 0ull) {
+#pragma unroll
+      for (int p = 0; p < 64; ++p) {
+        unsigned m = (unsigned)__builtin_amdgcn_readlane((int)pm, p);
+        if (m) {
+          const float wv = s_w[wave][p][lane & 31];
+          do {
+            const int j = __builtin_ctz(m);
+            m &= m - 1u;
+            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv), j));
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) acc[p][k] = __builtin_fmaf(s_f[j][lane + 64 * k], w, acc[p][k]);
+          } while (m);
+        }
+      }
+    }
+  }
+  const size_t hw = (size_t)width * height;
+#pragma unroll
+  for (int p = 0; p < 64; ++p) {
+    const int ox = qx0 + (p & 7), oy = qy0 + (p >> 3);
+    if (ox < width && oy < height) {
+      float* o = out + ((size_t)v * hw + (size_t)oy * width + ox) * channels + ch0;
+#pragma unroll
+      for (int k = 0; k < CPL; ++k)
+        if (lane + 64 * k < nch) o[lane + 64 * k] = acc[p][k];
+    }
+  }
+  if (inside && blockIdx.y == 0 && out_alpha) out_alpha[(size_t)v * hw + (size_t)py * width + px] = O;
+}
+
 // ---- C ABI -------------------------------------------------------------------------------------------------------
 extern "C" int siu3r_raster_geometry(int width, int height, int64_t G, int32_t* out8) {
   SIU3R_CHECK(out8 && width > 0 && height > 0 && G >= 0, "raster_geometry: bad arguments");
@@ -1135,9 +1303,44 @@ extern "C" int siu3r_raster_geometry(int width, int height, int64_t G, int32_t* 
   return 0;
 }
 
+// gsplat family, pose handed over in DEVICE memory: the per-view world->camera matrices [V,4,4] and pixel-unit intrinsics [V,3,3] (row-major, as
+// gsplat.rasterization receives them) overwrite those fields of the uploaded camera blocks -- the host never reads the pose back
+__global__ void cam_pose_kernel(Cam* cams, int V, const float* viewmats, const float* Ks) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  for (int i = 0; i < 16; ++i) cams[v].w2c[i] = viewmats[16 * v + i];
+  cams[v].fx = Ks[9 * v + 0];
+  cams[v].fy = Ks[9 * v + 4];
+  cams[v].cx = Ks[9 * v + 2];
+  cams[v].cy = Ks[9 * v + 5];
+}
+
+static int project_impl(const siu3r_raster_cam* cams_host, int V, void* cams_dev, int64_t G, const float* means, const float* cov,
+                        int cov_stride, const float* opacities, const float* colors, int channels, int sh_planar, float* rec,
+                        int32_t* radii, int32_t* rect, int32_t* tiles_touched, uint32_t* keys, uint64_t* stats, void* stream,
+                        const float* viewmats_dev, const float* Ks_dev);
+
 extern "C" int siu3r_raster_project(const siu3r_raster_cam* cams_host, int V, void* cams_dev, int64_t G, const float* means, const float* cov,
                                     int cov_stride, const float* opacities, const float* colors, int channels, int sh_planar, float* rec,
                                     int32_t* radii, int32_t* rect, int32_t* tiles_touched, uint32_t* keys, uint64_t* stats, void* stream) {
+  return project_impl(cams_host, V, cams_dev, G, means, cov, cov_stride, opacities, colors, channels, sh_planar, rec, radii, rect, tiles_touched, keys, stats,
+                      stream, nullptr, nullptr);
+}
+
+extern "C" int siu3r_raster_project_dp(const siu3r_raster_cam* cams_host, int V, void* cams_dev, const float* viewmats_dev, const float* Ks_dev, int64_t G,
+                                       const float* means, const float* cov, int cov_stride, const float* opacities, const float* colors, int channels,
+                                       int sh_planar, float* rec, int32_t* radii, int32_t* rect, int32_t* tiles_touched, uint32_t* keys,
+                                       uint64_t* stats, void* stream) {
+  SIU3R_CHECK(viewmats_dev && Ks_dev, "raster_project_dp: null pose pointer");
+  SIU3R_CHECK(cams_host && cams_host[0].mode == 1, "raster_project_dp: device-side poses belong to the gsplat family (mode 1)");
+  return project_impl(cams_host, V, cams_dev, G, means, cov, cov_stride, opacities, colors, channels, sh_planar, rec, radii, rect, tiles_touched, keys, stats,
+                      stream, viewmats_dev, Ks_dev);
+}
+
+static int project_impl(const siu3r_raster_cam* cams_host, int V, void* cams_dev, int64_t G, const float* means, const float* cov,
+                        int cov_stride, const float* opacities, const float* colors, int channels, int sh_planar, float* rec,
+                        int32_t* radii, int32_t* rect, int32_t* tiles_touched, uint32_t* keys, uint64_t* stats, void* stream,
+                        const float* viewmats_dev, const float* Ks_dev) {
   if (int rc = check_views(cams_host, V, "raster_project")) return rc;
   SIU3R_CHECK(cams_dev && stats, "raster_project: null pointer");
   SIU3R_CHECK(G >= 0 && G < (1ll << 31), "raster_project: G = %ld out of range", (long)G);
@@ -1147,13 +1350,16 @@ extern "C" int siu3r_raster_project(const siu3r_raster_cam* cams_host, int V, vo
   SIU3R_CHECK(!sh_planar || channels == 25, "raster_project: the planar SH layout [G,3,25] needs 25 coefficients (got %d)", channels);
   SIU3R_CHECK(((uintptr_t)rec & 15) == 0, "raster_project: rec must be 16-byte aligned");
   for (int v = 0; v < V; ++v)
-    SIU3R_CHECK(cams_host[v].mode == 1 || G == 0 || channels >= (cams_host[v].sh_degree + 1) * (cams_host[v].sh_degree + 1), "raster_project: too few SH coefficients");
+    SIU3R_CHECK(cams_host[v].mode == 1 || G == 0 || (cams_host[v].sh_degree < 0 ? (channels == 1 && !sh_planar && cams_host[v].sh_degree == cams_host[0].sh_degree)
+                                                                                 : channels >= (cams_host[v].sh_degree + 1) * (cams_host[v].sh_degree + 1)),
+                "raster_project: too few SH coefficients (or sh_degree < 0 = precomputed [G,3] colours: channels must be 1, for every view of the call)");
   hipStream_t s = (hipStream_t)stream;
   if (hipMemcpyAsync(cams_dev, cams_host, sizeof(Cam) * V, hipMemcpyHostToDevice, s) != hipSuccess ||
       hipMemsetAsync(stats, 0, sizeof(uint64_t) * ST_N * V, s) != hipSuccess) {
     siu3r_set_error("raster_project: camera upload / stats reset failed");
     return 2;
   }
+  if (viewmats_dev) hipLaunchKernelGGL(cam_pose_kernel, dim3((V + 63) / 64), dim3(64), 0, s, (Cam*)cams_dev, V, viewmats_dev, Ks_dev);
   // SH floats the views of the call may read (the block is loaded once per Gaussian, at the first view that sees it)
   int nf_chunk = 0;
   for (int v = 0; v < V; ++v) {
@@ -1259,10 +1465,26 @@ extern "C" int siu3r_raster_composite_feat(const siu3r_raster_cam* cams_host, in
   if (int rc = check_views(cams_host, V, "raster_composite_feat")) return rc;
   SIU3R_CHECK(cams_dev && tile_start && ids && rec && feats && out && channels > 0, "raster_composite_feat: bad arguments");
   const Geo geo = make_geo(cams_host[0].width, cams_host[0].height);
-  const int nchunk = (channels + CHUNK - 1) / CHUNK;
-  SIU3R_CHECK(nchunk <= 65535 && V <= 65535, "raster_composite_feat: too many channel chunks / views");
-  hipLaunchKernelGGL(composite_feat_kernel, dim3(geo.T, nchunk, V), dim3(256), 0, (hipStream_t)stream, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, rec, feats,
-                     channels, G, out, out_alpha);
+  const char* form_env = getenv("SIU3R_FEAT_FORM");  // 1 = the 32-channel kernel (A/B; the tests cross-check the two forms bit for bit)
+  const int form = form_env ? atoi(form_env) : 2;
+  if (form == 1) {
+    const int nchunk = (channels + CHUNK - 1) / CHUNK;
+    SIU3R_CHECK(nchunk <= 65535 && V <= 65535, "raster_composite_feat: too many channel chunks / views");
+    hipLaunchKernelGGL(composite_feat_kernel, dim3(geo.T, nchunk, V), dim3(256), 0, (hipStream_t)stream, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, rec,
+                       feats, channels, G, out, out_alpha);
+  } else {
+    // all channels of a tile in one workgroup, 64 * CPL of them per chunk: CPL = 1 (<= 64 channels), 2 (<= 128), else 3 (192 per chunk)
+    const int cpl = channels <= 64 ? 1 : (channels <= 128 ? 2 : 3);
+    const int nchunk = (channels + 64 * cpl - 1) / (64 * cpl);
+    SIU3R_CHECK(nchunk <= 65535 && V <= 65535, "raster_composite_feat: too many channel chunks / views");
+    const dim3 grid(geo.T, nchunk, V);
+    if (cpl == 1)
+      hipLaunchKernelGGL(composite_feat2_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, rec, feats, channels, G, out, out_alpha);
+    else if (cpl == 2)
+      hipLaunchKernelGGL(composite_feat2_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, rec, feats, channels, G, out, out_alpha);
+    else
+      hipLaunchKernelGGL(composite_feat2_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, rec, feats, channels, G, out, out_alpha);
+  }
   SIU3R_LAUNCH_CHECK("siu3r_raster_composite_feat");
   return 0;
 }
@@ -1282,14 +1504,14 @@ extern "C" int siu3r_quat_scale_to_cov6(const float* quats_wxyz, const float* sc
   return 0;
 }
 
-extern "C" int siu3r_sh_eval(const float* means, const float* campos3_host, const float* sh, int ncoef, int degree, float* rgb, int64_t G,
-                             void* stream) {
-  SIU3R_CHECK(G == 0 || (means && campos3_host && sh && rgb), "sh_eval: null pointer");
+static int sh_eval_impl(const float* means, const float* campos3_host, const float* campos3_dev, const float* sh, int ncoef, int degree, float* rgb, int64_t G,
+                        void* stream) {
+  SIU3R_CHECK(G == 0 || (means && (campos3_host || campos3_dev) && sh && rgb), "sh_eval: null pointer");
   SIU3R_CHECK(degree >= 0 && degree <= 4 && ncoef >= (degree + 1) * (degree + 1), "sh_eval: degree %d needs %d coefficients, got %d", degree,
               (degree + 1) * (degree + 1), ncoef);
   if (G == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  const float cx = campos3_host[0], cy = campos3_host[1], cz = campos3_host[2];
+  const float cx = campos3_host ? campos3_host[0] : 0.f, cy = campos3_host ? campos3_host[1] : 0.f, cz = campos3_host ? campos3_host[2] : 0.f;
   SIU3R_CHECK(ncoef <= 49, "sh_eval: at most 49 coefficients (got %d)", ncoef);
   const size_t lds = (size_t)256 * ncoef * 3 * sizeof(float);  // <= 147 KiB
   static bool attr_set = false;
@@ -1303,14 +1525,26 @@ extern "C" int siu3r_sh_eval(const float* means, const float* campos3_host, cons
     attr_set = true;
   }
   switch (degree) {
-    case 0: hipLaunchKernelGGL(sh_eval_kernel<0>, g1(G), dim3(256), lds, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
-    case 1: hipLaunchKernelGGL(sh_eval_kernel<1>, g1(G), dim3(256), lds, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
-    case 2: hipLaunchKernelGGL(sh_eval_kernel<2>, g1(G), dim3(256), lds, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
-    case 3: hipLaunchKernelGGL(sh_eval_kernel<3>, g1(G), dim3(256), lds, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
-    default: hipLaunchKernelGGL(sh_eval_kernel<4>, g1(G), dim3(256), lds, s, G, ncoef, means, cx, cy, cz, sh, rgb); break;
+    case 0: hipLaunchKernelGGL(sh_eval_kernel<0>, g1(G), dim3(256), lds, s, G, ncoef, means, cx, cy, cz, sh, rgb, campos3_dev); break;
+    case 1: hipLaunchKernelGGL(sh_eval_kernel<1>, g1(G), dim3(256), lds, s, G, ncoef, means, cx, cy, cz, sh, rgb, campos3_dev); break;
+    case 2: hipLaunchKernelGGL(sh_eval_kernel<2>, g1(G), dim3(256), lds, s, G, ncoef, means, cx, cy, cz, sh, rgb, campos3_dev); break;
+    case 3: hipLaunchKernelGGL(sh_eval_kernel<3>, g1(G), dim3(256), lds, s, G, ncoef, means, cx, cy, cz, sh, rgb, campos3_dev); break;
+    default: hipLaunchKernelGGL(sh_eval_kernel<4>, g1(G), dim3(256), lds, s, G, ncoef, means, cx, cy, cz, sh, rgb, campos3_dev); break;
   }
   SIU3R_LAUNCH_CHECK("siu3r_sh_eval");
   return 0;
+}
+
+extern "C" int siu3r_sh_eval(const float* means, const float* campos3_host, const float* sh, int ncoef, int degree, float* rgb, int64_t G,
+                             void* stream) {
+  SIU3R_CHECK(G == 0 || campos3_host, "sh_eval: null camera position");
+  return sh_eval_impl(means, campos3_host, nullptr, sh, ncoef, degree, rgb, G, stream);
+}
+
+extern "C" int siu3r_sh_eval_dp(const float* means, const float* campos3_dev, const float* sh, int ncoef, int degree, float* rgb, int64_t G,
+                                void* stream) {
+  SIU3R_CHECK(G == 0 || campos3_dev, "sh_eval_dp: null camera position");
+  return sh_eval_impl(means, nullptr, campos3_dev, sh, ncoef, degree, rgb, G, stream);
 }
 
 extern "C" int siu3r_blend_background(float* colors, const float* alpha, const float* bg_host, int channels, int64_t pixels, void* stream) {
@@ -1320,5 +1554,14 @@ extern "C" int siu3r_blend_background(float* colors, const float* alpha, const f
     hipLaunchKernelGGL(blend_bg_kernel, g1(pixels * channels), dim3(256), 0, (hipStream_t)stream, pixels * channels, channels, colors, alpha, bg_host[0],
                        channels > 1 ? bg_host[1] : 0.f, channels > 2 ? bg_host[2] : 0.f, (const float*)nullptr);
   SIU3R_LAUNCH_CHECK("siu3r_blend_background");
+  return 0;
+}
+
+extern "C" int siu3r_blend_background_dp(float* colors, const float* alpha, const float* bg_dev, int channels, int64_t pixels, void* stream) {
+  SIU3R_CHECK(pixels == 0 || (colors && alpha && bg_dev), "blend_background_dp: null pointer");
+  SIU3R_CHECK(channels >= 1, "blend_background_dp: channels = %d", channels);
+  if (pixels > 0)
+    hipLaunchKernelGGL(blend_bg_kernel, g1(pixels * channels), dim3(256), 0, (hipStream_t)stream, pixels * channels, channels, colors, alpha, 0.f, 0.f, 0.f, bg_dev);
+  SIU3R_LAUNCH_CHECK("siu3r_blend_background_dp");
   return 0;
 }

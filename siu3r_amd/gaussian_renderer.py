@@ -129,36 +129,70 @@ def release_prepared_splats():
     _PREPARED.clear()
 
 
+def _drop_prepared(token):
+    if _PREPARED.get("token") is token:
+        _PREPARED.clear()
+
+
 def rasterize_splats(splats: dict, camtoworlds: torch.Tensor, Ks: torch.Tensor, width: int, height: int, sh_degree: int = 4,
                      radius_clip: float = 0.1, near_plane: float = 0.01, far_plane: float = 1e10, backgrounds=(1.0, 1.0, 1.0)):
     """The reference viewer's render call (viewer.py:301-336 + 376-401): gsplat.rasterization semantics with
     quats (w,x,y,z) / log-scales / logit-opacities / SH coefficients `sh0` [G,1,3] + `shN` [G,K-1,3] as loaded from the
-    exported PLY, pixel-unit intrinsics, white background, radius_clip = 0.1 px.  camtoworlds [C,4,4], Ks [C,3,3].
+    exported PLY, pixel-unit intrinsics, white background, radius_clip = 0.1 px.  camtoworlds [C,4,4], Ks [C,3,3]; when they are
+    device tensors (the viewer uploads its camera state, viewer.py:391-392) the pose never comes back to the host.
     Returns (render_colors [C,H,W,3], render_alphas [C,H,W,1], info)."""
+    import weakref
+
     from . import raster
 
     # view-independent preparation (covariances from quats / scales, activations, the concatenated coefficient block): computed once per
-    # splat set -- a viewer renders many frames of one scene (the block alone is 600 MB for 2 M Gaussians).  The one-entry cache is keyed
-    # by storage AND version counter of every source tensor (an in-place edit -- scene editing, an optimizer step, copy_ -- bumps
-    # `_version` and invalidates it) and lives in this module: the caller's dict is not touched.
+    # splat set -- a viewer renders many frames of one scene (the block alone is 600 MB for 2 M Gaussians).  The one-entry cache holds
+    # WEAK references to the source tensors and is valid only while every one of them is the very same live object at the same version
+    # counter (an in-place edit bumps `_version`; a new scene whose tensors reuse the old addresses is a different object); it is dropped
+    # as soon as one of the sources dies, so that it neither serves a stale scene nor pins the prepared tensors after the splats are gone.
     names = ("means", "quats", "scales", "opacities", "sh0", "shN")
-    key = tuple((splats[k].data_ptr(), splats[k]._version, tuple(splats[k].shape)) if k in splats and splats[k] is not None else None for k in names)
+    src = [splats.get(k) for k in names]
     prep = _PREPARED.get("entry")
-    if prep is None or prep[0] != key:
+    valid = prep is not None and all((r is None and t is None) or (r is not None and t is not None and r() is t and ver == t._version)
+                                     for (r, ver), t in zip(prep[0], src))
+    if not valid:
         means = splats["means"].float()
         cov6 = raster.quat_scale_to_cov6(splats["quats"], torch.exp(splats["scales"].float()))
         opac = torch.sigmoid(splats["opacities"].float())
-        coeffs = torch.cat([splats["sh0"], splats["shN"]], 1).float() if "shN" in splats and splats["shN"] is not None else splats["sh0"].float()
-        prep = _PREPARED["entry"] = (key, means, cov6, opac, coeffs)
+        coeffs = torch.cat([splats["sh0"], splats["shN"]], 1).float() if splats.get("shN") is not None else splats["sh0"].float()
+        token = object()
+        refs = []
+        for t in src:
+            if t is None:
+                refs.append((None, 0))
+            else:
+                refs.append((weakref.ref(t), t._version))
+                weakref.finalize(t, _drop_prepared, token)
+        _PREPARED.clear()
+        prep = _PREPARED["entry"] = (refs, means, cov6, opac, coeffs)
+        _PREPARED["token"] = token
     _, means, cov6, opac, coeffs = prep
     assert coeffs.shape[1] >= (sh_degree + 1) ** 2
     cols, alphas, visible, pairs = [], [], [], []
-    for c2w, K in zip(camtoworlds.cpu().float(), Ks.cpu().float()):  # colours are view-dependent (SH): one call per camera
-        w2c = torch.linalg.inv(c2w)
-        cam = raster.make_cam_k3(w2c, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), width, height, near_plane, far_plane,
-                                 radius_clip=radius_clip)
-        rgb = raster.sh_eval(means, c2w[:3, 3].tolist(), coeffs, sh_degree)
-        o = raster.rasterize_views_k3_rgb([cam], means, cov6, opac, rgb)  # three channels: the fused composite, no tile lists in HBM
+    on_dev = camtoworlds.is_cuda and Ks.is_cuda
+    if on_dev:
+        c2w_d = camtoworlds.detach().float()
+        vm_d, Ks_d = torch.linalg.inv(c2w_d), Ks.detach().float()
+        eye = torch.eye(4)
+    else:
+        c2w_h, Ks_h = camtoworlds.detach().cpu().float(), Ks.detach().cpu().float()
+    for i in range(camtoworlds.shape[0]):  # colours are view-dependent (SH): one call per camera
+        if on_dev:
+            cam = raster.make_cam_k3(eye, 1.0, 1.0, 0.0, 0.0, width, height, near_plane, far_plane, radius_clip=radius_clip)
+            rgb = raster.sh_eval(means, c2w_d[i, :3, 3], coeffs, sh_degree)
+            pose = (vm_d[i:i + 1], Ks_d[i:i + 1])
+        else:
+            K = Ks_h[i]
+            cam = raster.make_cam_k3(torch.linalg.inv(c2w_h[i]), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), width, height, near_plane,
+                                     far_plane, radius_clip=radius_clip)
+            rgb = raster.sh_eval(means, c2w_h[i, :3, 3].tolist(), coeffs, sh_degree)
+            pose = None
+        o = raster.rasterize_views_k3_rgb([cam], means, cov6, opac, rgb, pose_dev=pose)  # three channels: the fused composite, no tile lists in HBM
         o = dict(colors=o["colors"][0], alphas=o["alphas"][0], state=o["state"])
         raster.blend_background_(o["colors"], o["alphas"], backgrounds)
         cols.append(o["colors"])

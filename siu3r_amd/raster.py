@@ -27,6 +27,7 @@ def _set(arr, values):
 
 
 def make_cam_k2(w2c, full_proj, tanfovx, tanfovy, campos, bg, width, height, sh_degree=4, sh_band4=False, nt_post_blend=True) -> RasterCam:
+    """sh_degree -1: the colours handed to the rasterizer are precomputed [G,1,3] values, blended as given (no SH, no clamp)"""
     c = RasterCam()
     c.mode, c.width, c.height = 0, int(width), int(height)
     _set(c.w2c, w2c.reshape(-1).tolist())
@@ -178,8 +179,20 @@ def _cov_stride(cov: torch.Tensor) -> int:
     raise RuntimeError(f"covariances must be [G,6] or [G,3,3], got {tuple(cov.shape)}")
 
 
+def _pose_dev(pose_dev, V, dev):
+    """(viewmats [V,4,4], Ks [V,3,3]) device tensors -> contiguous fp32 on `dev` (layout plumbing only; nothing is read back)"""
+    vm, Ks = pose_dev
+    vm = vm.detach().to(device=dev, dtype=torch.float32).contiguous()
+    Ks = Ks.detach().to(device=dev, dtype=torch.float32).contiguous()
+    if tuple(vm.shape) != (V, 4, 4) or tuple(Ks.shape) != (V, 3, 3):
+        raise RuntimeError(f"device-side poses must be viewmats [V,4,4] and Ks [V,3,3] with V = {V}, got {tuple(vm.shape)} / {tuple(Ks.shape)}")
+    return vm, Ks
+
+
 def _project_sort_bin(cams: Sequence[RasterCam], means, cov, opac, colors, channels, entry_capacity=None, check_overflow=True,
-                      sh_planar=False) -> _State:
+                      sh_planar=False, pose_dev=None) -> _State:
+    """pose_dev: None, or (viewmats [V,4,4] world->camera, Ks [V,3,3] pixel units) as DEVICE tensors (gsplat family): the kernels take the
+    pose from them (siu3r_raster_project_dp) and `cams` only carries frame size, planes and thresholds."""
     V, G, dev = len(cams), means.shape[0], means.device
     arr = _cam_array(cams)
     geo = geometry(cams[0].width, cams[0].height, G)
@@ -191,9 +204,15 @@ def _project_sort_bin(cams: Sequence[RasterCam], means, cov, opac, colors, chann
                 stats=torch.empty((V, 4), dtype=torch.int64, device=dev), defer=not check_overflow, cap_d_hint=None)
     st["tiles_touched"] = st["tiles_touched_all"][0]
     lib = _lib.lib()
-    check(lib.siu3r_raster_project(arr, V, _p(st["cams_dev"]), G, _p(means), _p(cov), _cov_stride(cov), _p(opac), _p(colors), channels,
-                                   int(bool(sh_planar)), _p(st["rec"]), _p(st["radii"]), _p(st["rect"]), _p(st["tiles_touched_all"]),
-                                   _p(st["keys"]), _p(st["stats"]), _stream()))
+    if pose_dev is None:
+        check(lib.siu3r_raster_project(arr, V, _p(st["cams_dev"]), G, _p(means), _p(cov), _cov_stride(cov), _p(opac), _p(colors), channels,
+                                       int(bool(sh_planar)), _p(st["rec"]), _p(st["radii"]), _p(st["rect"]), _p(st["tiles_touched_all"]),
+                                       _p(st["keys"]), _p(st["stats"]), _stream()))
+    else:
+        vm, Ks = st["pose_dev"] = _pose_dev(pose_dev, V, dev)  # (kept with the state: the launches below read them asynchronously)
+        check(lib.siu3r_raster_project_dp(arr, V, _p(st["cams_dev"]), _p(vm), _p(Ks), G, _p(means), _p(cov), _cov_stride(cov), _p(opac), _p(colors),
+                                          channels, int(bool(sh_planar)), _p(st["rec"]), _p(st["radii"]), _p(st["rect"]),
+                                          _p(st["tiles_touched_all"]), _p(st["keys"]), _p(st["stats"]), _stream()))
     rs_hist, rs_tot = i32(V, 256, geo["nchunks_sort"]), i32(V, 256)
     check(lib.siu3r_raster_sort(V, G, _p(st["keys"]), _p(st["keys_b"]), _p(st["sorted_ids"]), _p(st["ids_b"]), _p(rs_hist), _p(rs_tot), _p(st["stats"]), _stream()))
     bin_hist, bin_tot = i32(V, geo["NB"], geo["nchunks_bin"]), i32(V, geo["NB"])
@@ -300,16 +319,19 @@ def rasterize_k2(cam: RasterCam, means, cov6, shs, opacities, **kw) -> Dict[str,
 
 
 def rasterize_views_k3(cams: Sequence[RasterCam], means, cov6, opacities, feats, entry_capacity=None, pair_capacity=None,
-                       check_overflow=True) -> Dict[str, torch.Tensor]:
+                       check_overflow=True, pose_dev=None) -> Dict[str, torch.Tensor]:
     """feats [G,C] -> colors [V,H,W,C], alphas [V,H,W] (+ state).  gsplat semantics: the per-tile lists are materialised once
     and shared by every 32-channel chunk."""
     _gpu(means, cov6, opacities, feats)
+    if check_overflow == "deferred":
+        raise ValueError('check_overflow="deferred" is only safe on the RGB composites (an overflowing view is NaN-poisoned there); the '
+                         "N-channel composite has no such marker: pass True (check now) or False (and call state.verify())")
     means, cov6, opacities, feats = (t.contiguous().float() for t in (means, cov6, opacities, feats))
     V, G, dev = len(cams), means.shape[0], means.device
     H, W, Cc = cams[0].height, cams[0].width, feats.shape[1]
 
     def run(cap):
-        st = _project_sort_bin(cams, means, cov6, opacities, None, 0, cap, check_overflow)
+        st = _project_sort_bin(cams, means, cov6, opacities, None, 0, cap, check_overflow, pose_dev=pose_dev)
         st["cap_d_hint"] = int(pair_capacity) if pair_capacity else default_pair_capacity(G)
         out = torch.empty((V, H, W, Cc), dtype=torch.float32, device=dev)
         alpha = torch.empty((V, H, W), dtype=torch.float32, device=dev)
@@ -320,7 +342,8 @@ def rasterize_views_k3(cams: Sequence[RasterCam], means, cov6, opacities, feats,
     return _with_retry(run, entry_capacity, check_overflow)
 
 
-def rasterize_views_k3_rgb(cams: Sequence[RasterCam], means, cov6, opacities, rgb, entry_capacity=None, check_overflow=True) -> Dict[str, torch.Tensor]:
+def rasterize_views_k3_rgb(cams: Sequence[RasterCam], means, cov6, opacities, rgb, entry_capacity=None, check_overflow=True,
+                           pose_dev=None) -> Dict[str, torch.Tensor]:
     """gsplat semantics with THREE precomputed colour channels (rgb [G,3]) -> colors [V,H,W,3], alphas [V,H,W] (+ state), through the
     fused sort-free composite: the colour travels in the per-Gaussian record and no per-tile list is written to HBM (the N-channel
     path materialises the lists because every 32-channel chunk re-walks them)."""
@@ -331,7 +354,7 @@ def rasterize_views_k3_rgb(cams: Sequence[RasterCam], means, cov6, opacities, rg
     H, W = cams[0].height, cams[0].width
 
     def run(cap):
-        st = _project_sort_bin(cams, means, cov6, opacities, rgb, 3, cap, check_overflow)
+        st = _project_sort_bin(cams, means, cov6, opacities, rgb, 3, cap, check_overflow, pose_dev=pose_dev)
         out = torch.empty((V, H, W, 3), dtype=torch.float32, device=dev)
         alpha = torch.empty((V, H, W), dtype=torch.float32, device=dev)
         check(_lib.lib().siu3r_raster_composite_rgb(st["cams"], V, _p(st["cams_dev"]), G, _p(st["bin_start"]), _p(st["entries"]), st["cap_e"],
@@ -363,19 +386,30 @@ def quat_scale_to_cov6(quats_wxyz: torch.Tensor, scales: torch.Tensor) -> torch.
 
 
 def sh_eval(means: torch.Tensor, campos, sh: torch.Tensor, degree: int) -> torch.Tensor:
-    """means [G,3], campos (3 floats, host), sh [G,ncoef,3] -> rgb [G,3] = max(SH . coeffs + 0.5, 0)."""
+    """means [G,3], campos (3 floats on the host, or a DEVICE tensor of 3 floats: no read-back), sh [G,ncoef,3] -> rgb [G,3] =
+    max(SH . coeffs + 0.5, 0)."""
     _gpu(means, sh)
     means, sh = means.contiguous().float(), sh.contiguous().float()
-    cam = (C.c_float * 3)(*[float(v) for v in campos])
     out = torch.empty((means.shape[0], 3), dtype=torch.float32, device=means.device)
+    if isinstance(campos, torch.Tensor) and campos.is_cuda:
+        cp = campos.detach().float().contiguous()
+        assert cp.numel() == 3
+        check(_lib.lib().siu3r_sh_eval_dp(_p(means), _p(cp), _p(sh), sh.shape[1], int(degree), _p(out), means.shape[0], _stream()))
+        return out
+    cam = (C.c_float * 3)(*[float(v) for v in campos])
     check(_lib.lib().siu3r_sh_eval(_p(means), C.cast(cam, C.c_void_p), _p(sh), sh.shape[1], int(degree), _p(out), means.shape[0], _stream()))
     return out
 
 
 def blend_background_(colors: torch.Tensor, alphas: torch.Tensor, bg) -> torch.Tensor:
-    """colors [H,W,C<=3] += (1 - alphas[H,W]) * bg, in place."""
+    """colors [H,W,C] += (1 - alphas[H,W]) * bg, in place.  bg: C <= 3 floats on the host, or a DEVICE tensor of C floats (any C, no read-back)."""
     _gpu(colors, alphas)
     assert colors.is_contiguous() and alphas.is_contiguous() and colors.dtype == torch.float32
+    if isinstance(bg, torch.Tensor) and bg.is_cuda:
+        b = bg.detach().float().contiguous()
+        assert b.numel() == colors.shape[-1], (tuple(b.shape), tuple(colors.shape))
+        check(_lib.lib().siu3r_blend_background_dp(_p(colors), _p(alphas), _p(b), colors.shape[-1], alphas.numel(), _stream()))
+        return colors
     b = (C.c_float * 3)(*([float(v) for v in bg] + [0.0] * (3 - len(bg))))
     check(_lib.lib().siu3r_blend_background(_p(colors), _p(alphas), C.cast(b, C.c_void_p), colors.shape[-1], alphas.numel(), _stream()))
     return colors

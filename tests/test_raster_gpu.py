@@ -88,6 +88,39 @@ def test_k3_channels(channels):
     assert err <= 2e-6 and erra <= 2e-6
 
 
+@pytest.mark.parametrize("channels", [168, 3 * 64 + 8, 130, 63, 21])
+def test_k3_all_channel_composite_equals_the_chunked_one(channels, monkeypatch):
+    """The sparse all-channel list composite (composite_feat2_kernel: weights once per (pixel, entry), blended per pixel in list order,
+    lanes = channels) against the 32-channel-chunk kernel it replaces (SIU3R_FEAT_FORM=1) -- the same FMAs in the same order, hence
+    bit-identical maps -- and against the C oracle, on a ragged frame with several views in one call: q x 21 = 168 logit channels (one
+    192-channel chunk), 200 (two chunks), 130 (three channels per lane, a partly filled chunk), 63 (not a multiple of 4: scalar feature
+    loads) and 21."""
+    from oracle import raster_oracle as RO
+    from siu3r_amd import raster
+
+    H, W, G = 152, 200, 9000
+    means, cov, opac, _ = random_scene(G, seed=15, depth=(0.5, 9.0), scale=(0.01, 0.12))
+    opac[:300] = 0.002                      # below alpha_min: never blend (the extent test drops them at load time)
+    opac[300:600] = 0.999                   # clamp at alpha_max, early termination behind them
+    feats = torch.randn(G, channels, generator=torch.Generator().manual_seed(19))
+    cams = [_k3_cam(H, W, seed=s_, near=1.0, far=9.0) for s_ in (2, 4, 6)]
+    cov6 = raster.cov6_from_cov3x3(cov)
+    args = (cams, means.cuda(), cov6.cuda(), opac.cuda(), feats.cuda())
+    monkeypatch.setenv("SIU3R_FEAT_FORM", "1")
+    old = raster.rasterize_views_k3(*args)
+    monkeypatch.setenv("SIU3R_FEAT_FORM", "2")
+    new = raster.rasterize_views_k3(*args)
+    monkeypatch.delenv("SIU3R_FEAT_FORM")
+    dflt = raster.rasterize_views_k3(*args)
+    assert torch.equal(new["colors"], old["colors"]) and torch.equal(new["alphas"], old["alphas"]), float((new["colors"] - old["colors"]).abs().max())
+    assert torch.equal(dflt["colors"], new["colors"])  # the default is the new form
+    for v in (0, 2):
+        ref = RO.forward(cams[v], means.numpy(), cov6.numpy(), opac.numpy(), feats.numpy(), want_lists=False)
+        assert ref["D"] > 3000
+        assert float(np.abs(new["colors"][v].cpu().numpy() - ref["image"]).max()) <= 5e-6 * max(1.0, float(np.abs(ref["image"]).max()))
+        assert float(np.abs(new["alphas"][v].cpu().numpy() - ref["alpha"]).max()) <= 2e-6
+
+
 def test_empty_and_all_culled():
     from siu3r_amd import raster
 
