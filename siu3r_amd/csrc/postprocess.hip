@@ -11,6 +11,7 @@
 //   pp_accept  : sequential acceptance (area/orig > 0.8), segment ids, stuff fusing       (1 thread / item)
 //   pp_write   : segmentation / semantic / instance maps from the per-query table
 //   pp_qcl     : query_class_logits[(t,y,x), j, c] = class_prob[k_j, c] * mask_prob[t, k_j, y, x]
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -101,7 +102,10 @@ __device__ __forceinline__ float sample256(const float* p256, int64_t base, int 
   return (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
 }
 
-// grid: (ceil(T*H*W/256), B)
+__device__ unsigned long long g_pp_dbg[4];  // probes only: [0] label pixels that differ between two back-to-back argmax passes, [1] NaN reads
+
+// grid: (ceil(T*H*W/256), B).  SYS: system-scope loads of the volume (the shipped form, see sample256); false: plain loads (SIU3R_PP_DBG probes)
+template <bool SYS>
 __global__ __launch_bounds__(256) void pp_argmax_kernel(const float* p256, const float* scores, const int32_t* kept_idx,
                                                         const int32_t* n_keep, int32_t* lab_map, int32_t* area,
                                                         int32_t* orig, int T, int H, int W, int MS, int Q,
@@ -127,7 +131,8 @@ __global__ __launch_bounds__(256) void pp_argmax_kernel(const float* p256, const
     int bk = 0;
     for (int k = 0; k < nk; ++k) {
       const int q = kept_idx[b * Q + k];
-      const float wv = sample256<true>(p256, base, MS, Q, q, y0, y1, x0, x1, ly, lx) * scores[b * Q + q];
+      const float wv = sample256<SYS>(p256, base, MS, Q, q, y0, y1, x0, x1, ly, lx) * scores[b * Q + q];
+      if (!SYS && wv != wv) atomicAdd(&g_pp_dbg[1], 1ull);  // (probe variant only: a NaN-filled volume read before its writer's values)
       if (wv > best) {  // strict: first maximum wins, like torch.argmax
         best = wv;
         bk = k;
@@ -246,6 +251,17 @@ __global__ __launch_bounds__(256) void pp_qcl_kernel(const float* p256, const fl
 
 inline dim3 g1(int64_t n, int blk = 256) { return dim3((unsigned)cdiv64(n, blk)); }
 
+// ---- probes of the round-4 stale read (SIU3R_PP_DBG, tools/label_flake_probe.py): never active in the product path
+__global__ void pp_dbg_fill_kernel(float* p, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = __int_as_float(0x7fc00000);
+}
+__global__ void pp_dbg_diff_kernel(const int32_t* a, const int32_t* b, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && a[i] != b[i]) atomicAdd(&g_pp_dbg[0], 1ull);
+}
+
 }  // namespace
 
 extern "C" int siu3r_panoptic_stage1(const float* class_logits, const float* mask_logits_cl, float* probs, float* scores,
@@ -261,9 +277,33 @@ extern "C" int siu3r_panoptic_stage1(const float* class_logits, const float* mas
               "panoptic_stage1: mask volume / pixel count must stay below 2^31");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(pp_class_kernel, dim3(B), dim3(64), 0, s, class_logits, probs, scores, labels, kept_idx, n_keep, Q, C, threshold, area, orig);
-  hipLaunchKernelGGL(pp_mask256_kernel, g1((int64_t)B * T * mask_size * mask_size * Q), dim3(256), 0, s, mask_logits_cl, p256, B * T, IH, IW, mask_size, Q);
+  // SIU3R_PP_DBG (probes only; bit 0: plain loads in the argmax, bit 1: a stream synchronisation between the volume's writer and the
+  // argmax, bit 2: the volume is NaN-filled before its writer runs, bit 3: the argmax runs twice back to back -- first into `seg` as
+  // scratch -- and the label pixels on which the passes disagree are counted and reported on stderr)
+  const char* dbg_env = getenv("SIU3R_PP_DBG");
+  const int dbg = dbg_env ? atoi(dbg_env) : 0;
+  const int64_t nvol = (int64_t)B * T * mask_size * mask_size * Q;
+  if (dbg & 4) hipLaunchKernelGGL(pp_dbg_fill_kernel, dim3(4096), dim3(256), 0, s, p256, nvol);
+  hipLaunchKernelGGL(pp_mask256_kernel, g1(nvol), dim3(256), 0, s, mask_logits_cl, p256, B * T, IH, IW, mask_size, Q);
   const int64_t npix = (int64_t)T * H * W;
-  hipLaunchKernelGGL(pp_argmax_kernel, dim3((unsigned)cdiv64(npix, 256), B), dim3(256), 0, s, p256, scores, kept_idx, n_keep, lab_map, area, orig, T, H, W, mask_size, Q, mask_threshold);
+  const dim3 ag((unsigned)cdiv64(npix, 256), B);
+  if (dbg & 2) (void)hipStreamSynchronize(s);
+  if (dbg & 8) {
+    hipLaunchKernelGGL(pp_argmax_kernel<false>, ag, dim3(256), 0, s, p256, scores, kept_idx, n_keep, seg, area, orig, T, H, W, mask_size, Q, mask_threshold);
+    hipLaunchKernelGGL(pp_class_kernel, dim3(B), dim3(64), 0, s, class_logits, probs, scores, labels, kept_idx, n_keep, Q, C, threshold, area, orig);  // (counters back to zero)
+  }
+  if (dbg & 1)
+    hipLaunchKernelGGL(pp_argmax_kernel<false>, ag, dim3(256), 0, s, p256, scores, kept_idx, n_keep, lab_map, area, orig, T, H, W, mask_size, Q, mask_threshold);
+  else
+    hipLaunchKernelGGL(pp_argmax_kernel<true>, ag, dim3(256), 0, s, p256, scores, kept_idx, n_keep, lab_map, area, orig, T, H, W, mask_size, Q, mask_threshold);
+  if (dbg & 8) hipLaunchKernelGGL(pp_dbg_diff_kernel, g1(npix * B), dim3(256), 0, s, seg, lab_map, npix * B);
+  if (dbg & 12) {
+    unsigned long long h[4] = {0, 0, 0, 0}, z[4] = {0, 0, 0, 0};
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pp_dbg), sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pp_dbg), z, sizeof(z));
+    if (h[0] || h[1]) fprintf(stderr, "SIU3R_PP_DBG=%d: two back-to-back argmax passes disagree on %llu label pixels; %llu NaN reads of the volume\n", dbg, h[0], h[1]);
+  }
   hipLaunchKernelGGL(pp_accept_kernel, g1(B, 64), dim3(64), 0, s, area, orig, kept_idx, n_keep, labels, scores, seg_id, seg_label, seg_fused, seg_score, acc_list, n_acc, Q, overlap, fuse_mask, B);
   hipLaunchKernelGGL(pp_write_kernel, dim3((unsigned)cdiv64(npix, 256), B), dim3(256), 0, s, lab_map, seg_id, seg_label, n_keep, seg, sem, ins, npix, Q);
   SIU3R_LAUNCH_CHECK("siu3r_panoptic_stage1");

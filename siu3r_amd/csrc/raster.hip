@@ -1137,36 +1137,49 @@ __global__ void blend_bg_kernel(int64_t n, int C, float* colors, const float* al
   colors[i] = colors[i] + (1.0f - alpha[p]) * b;
 }
 
-// ---- K3 composite, second form: ALL channels of a tile in one workgroup, weights evaluated once, blended sparsely -------------------
-// The 32-channel kernel above re-walks the tile's list (and re-evaluates every alpha) once per channel chunk and spends 32 FMAs per
-// (lane, entry) whether or not the lane's pixel is touched: with q x 21 = 168 logit channels of a pixel-aligned scene a tile lists ~900
-// Gaussians of which ~70 reach any given pixel, so 92 % of those FMAs multiply by zero and the alphas are computed six times.
-// Here a wave owns an 8 x 8 pixel quadrant and alternates between two lane roles per batch of NB = 32 list entries:
-//   phase 1, lane = pixel : the batch's entries whose alpha >= alpha_min footprint can reach the quadrant (a conservative extent test
-//                           done once per entry at load time) are evaluated exactly as before -- same expressions, same order: alpha,
-//                           transmittance chain, early termination -- and each lane leaves its blending weights w = alpha * T in LDS
-//                           together with a 32-bit mask of the entries that contributed to ITS pixel;
-//   phase 2, lane = channel: for every pixel of the quadrant (static loop, the pixel's accumulators are registers) the wave walks that
-//                           pixel's mask in list order and does acc[c] = fma(f[j][c], w, acc[c]) for the 64 * CPL channels of the
-//                           chunk: the feature row of an entry is read from LDS lane-contiguously, the weight travels as a scalar
-//                           (v_readlane of the pixel's weight vector).
-// Work is proportional to the (pixel, Gaussian) pairs that actually blend; per pixel and channel the FMAs are the oracle's, in the
-// oracle's order, so the maps are bit-identical to the 32-channel kernel's (tests/test_raster_gpu.py).
-template <int CPL>
-__global__ __launch_bounds__(256, 2) void composite_feat2_kernel(const Cam* __restrict__ cams, Geo geo, const int32_t* __restrict__ tile_start,
+// ---- K3 composite, matrix-core form: the blend as rank-2 updates ---------------------------------------------------------------------------
+// (Round 5 also built and measured two other all-channel forms, both bit-identical and both slower: lanes = channels with per-pixel
+// sparse pair lists in LDS -- bound by ~95 bookkeeping instructions per pixel and batch -- and lanes = pixels with the feature row through
+// scalar loads as SGPR operands of packed FMAs -- bound by the scalar-cache round trip per 16 channels: 1.66 / 2.2 ms per 168-channel
+// frame against 1.93 for the 32-channel kernel and 0.69 here)
+// out[pixel][channel] += w[pixel] * f[channel] per list entry is an outer product; two consecutive entries of a quadrant's list make one
+// v_mfma_f32_32x32x2_f32 per (32-pixel, 32-channel) block: A[i][k] = the blending weight of pixel i for entry k, B[k][j] = channel j of
+// entry k's feature row.  The f32-input MFMA is exact f32 and accumulates like an fmaf chain in k order (the guide: bitwise), i.e. it
+// performs the oracle's FMAs in the oracle's order -- a pixel an entry does not reach takes part with w = 0, which leaves its sums
+// untouched.  What the matrix pipe buys here is not FLOPs (its f32 rate is the packed-VALU rate) but OPERAND DELIVERY: the feature row
+// enters as the B operand, one LDS read of 32 consecutive floats per block and entry pair, instead of being broadcast to 64 lanes value by
+// value (one LDS serves four SIMDs: the 32 broadcast reads per entry and chunk are what bound the 32-channel kernel), and the VALU is
+// free for the next pair's alpha / transmittance step.  lane = pixel of the wave's 8 x 8 quadrant for that step (once per entry, for all
+// channels; lists cut to the quadrant by the extent test at load time); v_permlane32_swap turns two weight registers into the two A
+// operands (pixels 0-31 / 32-63 of the quadrant, k = entry).  Accumulators: 2 x NP blocks of 16 registers.
+#ifndef SIU3R_FEAT_DBG
+#define SIU3R_FEAT_DBG 0  // tools/ab_raster.sh probes: 3 = counters instead of the result, 6 = no output stores, 7 = no MFMAs
+#endif
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+template <int NP>
+__global__ __launch_bounds__(256, 2) void composite_feat4_kernel(const Cam* __restrict__ cams, Geo geo, const int32_t* __restrict__ tile_start,
                                                                  const int32_t* __restrict__ ids, int64_t cap_d, const float* __restrict__ rec,
-                                                                 const float* __restrict__ feats, int channels, int64_t G, float* __restrict__ out,
+                                                                 const float* __restrict__ feats, int channels, int64_t G, int V, float* __restrict__ out,
                                                                  float* __restrict__ out_alpha) {
-  constexpr int NB = 32, CW = 64 * CPL;
-  __shared__ float s_xy[NB][2];
-  __shared__ __attribute__((aligned(16))) float s_co[NB][4];
-  __shared__ unsigned s_qm[4];
-  __shared__ __attribute__((aligned(16))) float s_f[NB][CW];
-  __shared__ float s_w[4][64][NB + 1];
+  // Staging: batches of NB = 32 list entries, DOUBLE-BUFFERED in LDS and filled by LDS-DMA (buffer_load ... lds: global -> LDS without
+  // passing through registers) one batch ahead; the Gaussian ids travel two batches ahead (a register of wave 0, then LDS), because
+  // record and feature addresses depend on them.  While batch b is blended, batch b + 1's records (32 B each) and feature rows
+  // (64 * NP pieces of 16 B ... per entry) are in flight and batch b + 2's ids are being fetched: no wave waits for HBM inside the loop
+  // except at the one vmcnt(0) per batch, by which time the data has had a whole batch to arrive (the counters of the synchronous
+  // version: 69 % of all wave cycles parked in s_waitcnt / barriers, matrix pipe 18 % busy).
+  constexpr int NB = 32, CW = 32 * NP;
+  __shared__ int s_id[3][NB];
+  __shared__ __attribute__((aligned(16))) float s_rec[2][NB][8];  // {mx, my, depth, 0 | conic a, b, c, opacity}
+  __shared__ __attribute__((aligned(16))) float s_f[2][NB][CW];
   const int v = blockIdx.z;
   const Cam& c = cams[v];
   const int tile = blockIdx.x, tx = tile % geo.gw, ty = tile / geo.gw;
-  const int ch0 = blockIdx.y * CW, nch = min(CW, channels - ch0);
+  // chunk blockIdx.y covers CW channels from ch0; the last chunk of a wide matrix is shifted back to end at the last channel, and so
+  // is the last 32-channel block of a chunk (32 <= nch <= CW, the launcher's rule): every window lies inside the feature row; channels
+  // two windows share are computed twice, identically
+  const int ch0 = min((int)blockIdx.y * CW, max(0, channels - CW)), nch = min(CW, channels - ch0);
+  const int last_off = nch - 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
   const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
@@ -1175,120 +1188,179 @@ __global__ __launch_bounds__(256, 2) void composite_feat2_kernel(const Cam* __re
   const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
   const int32_t* ts = tile_start + (int64_t)v * (geo.T + 2);
   const int32_t* idp = ids + (int64_t)v * cap_d;
-  const int64_t vg = (int64_t)v * G;
   const int beg = ts[tile], end = ts[tile + 1];
   const float alpha_min = c.alpha_min, alpha_max = c.alpha_max, t_min = c.t_min;
-  const bool vec4 = (channels & 3) == 0 && (((uintptr_t)feats) & 15) == 0;
   float T = 1.0f, O = 0.f;
-  float acc[64][CPL];
+  f32x16 acc[2][NP];
 #pragma unroll
-  for (int p = 0; p < 64; ++p)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) acc[p][k] = 0.f;
+    for (int n = 0; n < NP; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][n][r] = 0.f;
   bool done = !inside;
-  for (int base = beg; base < end; base += NB) {
-    if (__syncthreads_count(done) == 256) break;  // (also orders the previous batch's LDS reads before this batch's writes)
-    const int cnt = min(NB, end - base);
-    if (threadIdx.x < NB) {  // wave 0, lanes 0..31: the batch's records + which quadrants each entry can reach
-      unsigned bits = 0;
-      if (threadIdx.x < cnt) {
-        const float4* rp = (const float4*)(rec + 12 * (vg + idp[base + threadIdx.x]));
-        const float4 r0 = rp[0], r1 = rp[1];
-        *(float2*)s_xy[threadIdx.x] = make_float2(r0.x, r0.y);
-        *(float4*)s_co[threadIdx.x] = r1;
+#if SIU3R_FEAT_DBG == 3
+  int dbg_pairs = 0, dbg_mfma = 0, dbg_lanes = 0;
+#endif
+  // buffer resources (32-bit byte offsets; the launcher checks that both arrays stay below 4 GiB): an out-of-range offset reads zeros
+  const __amdgpu_buffer_rsrc_t r_rec = __builtin_amdgcn_make_buffer_rsrc((void*)rec, (short)0, (int)((int64_t)V * G * 48), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_feat = __builtin_amdgcn_make_buffer_rsrc((void*)feats, (short)0, (int)((int64_t)G * channels * 4), 0x00020000);
+  const unsigned vg48 = (unsigned)((int64_t)v * G * 48);
+
+  // issue the DMAs of the batch whose ids are in s_id[ring]: records by wave 0 (lane = 2 * entry + half), feature rows by everybody
+  // (piece e = entry * (CW / 4) + 16-byte column); a wave instruction fills 64 consecutive 16-byte slots of the destination
+  auto issue = [&](int ring, int buf) {
+    if (wave == 0) {
+      const int j = lane >> 1;
+      const unsigned off = vg48 + (unsigned)s_id[ring][j] * 48u + (unsigned)(lane & 1) * 16u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rec, (lds_ptr_t)&s_rec[buf][0][0], 16, off, 0, 0, 0);
+    }
+    constexpr int PCS = NB * (CW / 4);  // 16-byte pieces per batch (a multiple of 256: NB * CW / 4 = 256 * NP)
+#pragma unroll
+    for (int k = 0; k < PCS / 256; ++k) {
+      const int e = k * 256 + threadIdx.x;
+      const int j = e / (CW / 4), cw = (e - j * (CW / 4)) * 4;
+      const int co = (cw >> 5) == NP - 1 ? last_off + (cw & 31) : cw;
+      const unsigned off = ((unsigned)s_id[ring][j] * (unsigned)channels + (unsigned)(ch0 + co)) * 4u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_feat, (lds_ptr_t)((char*)&s_f[buf][0][0] + (k * 256 + wave * 64) * 16), 16, off, 0, 0, 0);
+    }
+  };
+
+  const float (*recb)[8] = s_rec[0];  // the records of the batch being blended
+  auto weight = [&](int j) -> float {  // the blending weight of entry j for this lane's pixel (0: does not blend); advances T, O, done
+    if (done) return 0.f;
+    const float dx = recb[j][0] - pxf, dy = recb[j][1] - pyf;
+    const float4 co = *(const float4*)&recb[j][4];
+    const float sigma = conic_sigma(co.x, co.y, co.z, dx, dy);
+    if (sigma < 0.0f) return 0.f;
+    const float a = fminf(alpha_max, co.w * exp_det(-sigma));
+    if (a < alpha_min) return 0.f;
+    const float nT = __builtin_fmaf(-T, a, T);
+    if (nT <= t_min) {
+      done = true;
+      return 0.f;
+    }
+    const float w = a * T;
+    O += w;
+    T = nT;
+    return w;
+  };
+
+  // prologue: ids of batch 0 -> LDS, ids of batch 1 -> wave 0's register, DMAs of batch 0
+  int idreg = 0;
+  if (threadIdx.x < NB) {
+    s_id[0][threadIdx.x] = beg + (int)threadIdx.x < end ? idp[beg + threadIdx.x] : 0;
+    idreg = beg + NB + (int)threadIdx.x < end ? idp[beg + NB + threadIdx.x] : 0;
+  }
+  __syncthreads();
+  if (beg < end) issue(0, 0);
+  int nb = 0;
+  for (int base = beg; base < end; base += NB, ++nb) {
+    // batch nb's DMAs (issued one batch ago) and the ids of batch nb + 1 (loaded one batch ago) have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x < NB) s_id[(nb + 1) % 3][threadIdx.x] = idreg;
+    if (__syncthreads_count(done) == 256) break;  // (also: everybody is past batch nb - 1's LDS reads, batch nb's data is visible to all)
+    const int cnt = min(NB, end - base), buf = nb & 1;
+    recb = s_rec[buf];
+    if (threadIdx.x < NB) idreg = base + 2 * NB + (int)threadIdx.x < end ? idp[base + 2 * NB + threadIdx.x] : 0;
+    if (base + NB < end) issue((nb + 1) % 3, buf ^ 1);
+    // which entries of batch nb can reach THIS wave's quadrant: lanes 0..31 test one entry each (no second barrier, no serial section)
+    unsigned qm;
+    {
+      bool reach = false;
+      if (lane < cnt) {
+        const float4 r0 = *(const float4*)&s_rec[buf][lane][0], r1 = *(const float4*)&s_rec[buf][lane][4];
         // alpha >= alpha_min  <=>  sigma <= L = ln(opacity / alpha_min); on that ellipse |dx| <= sqrt(2 L c / det), |dy| <= sqrt(2 L a / det).
         // Conservative (margins far above the rounding of exp_det and of this bound): an entry dropped here can never pass the
-        // per-pixel test below, an entry kept needlessly only costs time.
+        // per-pixel test, an entry kept needlessly only costs time.
         const float det = r1.x * r1.z - r1.y * r1.y;
         const float L = logf(r1.w / alpha_min) * 1.001f + 0.001f;
-        bits = 0xfu;
-        if (L < 0.f) bits = 0;
-        else if (det > 0.f && L == L) {
+        reach = !(L < 0.f);
+        if (reach && det > 0.f && L == L) {
           const float ex = sqrtf(2.0f * L * r1.z / det) + 0.01f, ey = sqrtf(2.0f * L * r1.x / det) + 0.01f;
-          if (ex == ex && ey == ey) {
-            const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
-            const bool xl = r0.x - ex <= tx0 + 7.5f && r0.x + ex >= tx0 + 0.5f, xr = r0.x - ex <= tx0 + 15.5f && r0.x + ex >= tx0 + 8.5f;
-            const bool yt = r0.y - ey <= ty0 + 7.5f && r0.y + ey >= ty0 + 0.5f, yb = r0.y - ey <= ty0 + 15.5f && r0.y + ey >= ty0 + 8.5f;
-            bits = (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
-          }
+          if (ex == ex && ey == ey)
+            reach = r0.x - ex <= (float)qx0 + 7.5f && r0.x + ex >= (float)qx0 + 0.5f && r0.y - ey <= (float)qy0 + 7.5f && r0.y + ey >= (float)qy0 + 0.5f;
         }
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const unsigned long long m = __ballot((bits >> q) & 1u);
-        if (lane == 0) s_qm[q] = (unsigned)m;
-      }
+      qm = (unsigned)__ballot(reach);  // (cnt <= 32: lanes 32..63 vote false)
     }
-    if (vec4) {
-      for (int e = threadIdx.x; e < cnt * (CW / 4); e += 256) {
-        const int j = e / (CW / 4), c4 = (e - j * (CW / 4)) * 4;
-        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c4 < nch) f = *(const float4*)(feats + (size_t)idp[base + j] * channels + ch0 + c4);  // (nch % 4 == 0 here)
-        *(float4*)&s_f[j][c4] = f;
+    const float (*sfb)[CW] = s_f[buf];
+    if (__ballot(!done) == 0ull) continue;  // the whole quadrant is saturated: only the barrier is left for this wave
+    while (qm) {
+      const int j0 = __builtin_ctz(qm);
+      qm &= qm - 1u;
+      const float w0 = weight(j0);
+      int j1 = j0;
+      float w1 = 0.f;
+      if (qm) {
+        j1 = __builtin_ctz(qm);
+        qm &= qm - 1u;
+        w1 = weight(j1);
       }
-    } else {
-      for (int e = threadIdx.x; e < cnt * CW; e += 256) {
-        const int j = e / CW, k = e - j * CW;
-        s_f[j][k] = k < nch ? feats[(size_t)idp[base + j] * channels + ch0 + k] : 0.f;
-      }
-    }
-    __syncthreads();
-    // ---- phase 1: lane = pixel
-    unsigned pm = 0;
-    if (__ballot(!done) != 0ull) {
-      unsigned qm = (unsigned)__builtin_amdgcn_readfirstlane((int)s_qm[wave]);
-      for (; qm; qm &= qm - 1u) {
-        const int j = __builtin_ctz(qm);
-        if (done) continue;
-        const float dx = s_xy[j][0] - pxf, dy = s_xy[j][1] - pyf;
-        const float4 co = *(const float4*)s_co[j];
-        const float sigma = conic_sigma(co.x, co.y, co.z, dx, dy);
-        if (sigma < 0.0f) continue;
-        const float a = fminf(alpha_max, co.w * exp_det(-sigma));
-        if (a < alpha_min) continue;
-        const float nT = __builtin_fmaf(-T, a, T);
-        if (nT <= t_min) {
-          done = true;
-          continue;
-        }
-        const float w = a * T;
-        s_w[wave][lane][j] = w;
-        pm |= 1u << j;
-        O += w;
-        T = nT;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- phase 2: lane = channel (the wave's own LDS writes above are complete before its reads below: DS operations of a wave
-    // execute in order)
-    if (__ballot(pm != 0u) != 0ull) {
+#if SIU3R_FEAT_DBG == 3
+      dbg_pairs += 1;
+#endif
+      if (__ballot(w0 != 0.f || w1 != 0.f) == 0ull) continue;
+#if SIU3R_FEAT_DBG == 3
+      dbg_mfma += 1;
+      dbg_lanes += __popcll(__ballot(w0 != 0.f)) + __popcll(__ballot(w1 != 0.f));
+#endif
+      // A operands: lanes 0-31 carry k = 0 (entry j0), lanes 32-63 k = 1 (entry j1); block 0 = pixels 0-31 of the quadrant, block 1 = 32-63
+      // (hipcc uses only the FIRST result of a two-operand v_permlane32_swap correctly here -- the second A operand came out as the first
+      // in the ISA -- so each operand takes "the value lane ^ 32 holds" through the single-operand form, which is right whichever
+      // registers the allocator picks: see attention.hip)
+      const bool lo = lane < 32;
+      auto other_half = [&](float x) {
+        const unsigned u = __builtin_bit_cast(unsigned, x);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        return __builtin_bit_cast(float, lo ? sw[1] : sw[0]);
+      };
+      const float w1_other = other_half(w1), w0_other = other_half(w0);
+      const float a_lo = lo ? w0 : w1_other;   // block 0 (pixels 0-31): k = 0 -> w0 of pixel lane, k = 1 -> w1 of pixel lane - 32
+      const float a_hi = lo ? w0_other : w1;   // block 1 (pixels 32-63): k = 0 -> w0 of pixel lane + 32, k = 1 -> w1 of pixel lane
+      const float* frow = &sfb[lane < 32 ? j0 : j1][lane & 31];
+#if SIU3R_FEAT_DBG == 7
+      acc[0][0][0] += a_lo * frow[0] + a_hi;  // (ablation: no MFMAs, the stores stay)
+#else
+      float b[NP];  // all B operands of the pair first: the MFMA burst below then runs without an LDS round trip between its groups
 #pragma unroll
-      for (int p = 0; p < 64; ++p) {
-        unsigned m = (unsigned)__builtin_amdgcn_readlane((int)pm, p);
-        if (m) {
-          const float wv = s_w[wave][p][lane & 31];
-          do {
-            const int j = __builtin_ctz(m);
-            m &= m - 1u;
-            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv), j));
+      for (int n = 0; n < NP; ++n) b[n] = frow[32 * n];
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) acc[p][k] = __builtin_fmaf(s_f[j][lane + 64 * k], w, acc[p][k]);
-          } while (m);
-        }
+      for (int n = 0; n < NP; ++n) {
+        acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, b[n], acc[0][n], 0, 0, 0);
+        acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, b[n], acc[1][n], 0, 0, 0);
       }
+#endif
     }
   }
+#if SIU3R_FEAT_DBG == 3
+  if (lane == 0 && out_alpha && blockIdx.y == 0) {  // (probe build: counters instead of the first alphas; tools/mb_feat.py prints them)
+    atomicAdd(&out_alpha[0], (float)dbg_pairs);
+    atomicAdd(&out_alpha[1], (float)dbg_mfma);
+    atomicAdd(&out_alpha[2], (float)dbg_lanes);
+    atomicAdd(&out_alpha[3], (float)(end - beg) * 0.25f);
+  }
+  return;
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (an early exit leaves the next batch's DMAs in flight: they must land before the LDS is released)
+  // C/D layout: column (channel) = lane & 31, row (pixel of the 32-pixel block) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const size_t hw = (size_t)width * height;
 #pragma unroll
-  for (int p = 0; p < 64; ++p) {
-    const int ox = qx0 + (p & 7), oy = qy0 + (p >> 3);
-    if (ox < width && oy < height) {
-      float* o = out + ((size_t)v * hw + (size_t)oy * width + ox) * channels + ch0;
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int k = 0; k < CPL; ++k)
-        if (lane + 64 * k < nch) o[lane + 64 * k] = acc[p][k];
+    for (int r = 0; r < 16; ++r) {
+      const int p = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int ox = qx0 + (p & 7), oy = qy0 + (p >> 3);
+#if SIU3R_FEAT_DBG == 6
+      if (ox < width && oy < height && T == 123.456f) {  // (ablation: the MFMAs stay alive, the stores never execute)
+#else
+      if (ox < width && oy < height) {
+#endif
+        float* o = out + ((size_t)v * hw + (size_t)oy * width + ox) * channels + ch0 + (lane & 31);
+#pragma unroll
+        for (int n = 0; n < NP; ++n) o[n == NP - 1 ? last_off : 32 * n] = acc[a][n][r];
+      }
     }
-  }
   if (inside && blockIdx.y == 0 && out_alpha) out_alpha[(size_t)v * hw + (size_t)py * width + px] = O;
 }
 
@@ -1465,25 +1537,33 @@ extern "C" int siu3r_raster_composite_feat(const siu3r_raster_cam* cams_host, in
   if (int rc = check_views(cams_host, V, "raster_composite_feat")) return rc;
   SIU3R_CHECK(cams_dev && tile_start && ids && rec && feats && out && channels > 0, "raster_composite_feat: bad arguments");
   const Geo geo = make_geo(cams_host[0].width, cams_host[0].height);
-  const char* form_env = getenv("SIU3R_FEAT_FORM");  // 1 = the 32-channel kernel (A/B; the tests cross-check the two forms bit for bit)
-  const int form = form_env ? atoi(form_env) : 2;
-  if (form == 1) {
+  const char* form_env = getenv("SIU3R_FEAT_FORM");  // 1 = the 32-channel kernel everywhere (A/B; the tests cross-check the two forms bit for bit)
+  const int form = form_env ? atoi(form_env) : 4;
+  // (the matrix-core form addresses records and features through buffer resources: 32-bit byte offsets)
+  const bool fits32 = (int64_t)V * G * 48 < (1ll << 31) * 2 - 64 && (int64_t)G * channels * 4 < (1ll << 31) * 2 - 64 && (channels & 3) == 0 && (((uintptr_t)feats) & 15) == 0;
+  if (form == 1 || channels < 32 || !fits32) {
     const int nchunk = (channels + CHUNK - 1) / CHUNK;
     SIU3R_CHECK(nchunk <= 65535 && V <= 65535, "raster_composite_feat: too many channel chunks / views");
     hipLaunchKernelGGL(composite_feat_kernel, dim3(geo.T, nchunk, V), dim3(256), 0, (hipStream_t)stream, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, rec,
                        feats, channels, G, out, out_alpha);
   } else {
-    // all channels of a tile in one workgroup, 64 * CPL of them per chunk: CPL = 1 (<= 64 channels), 2 (<= 128), else 3 (192 per chunk)
-    const int cpl = channels <= 64 ? 1 : (channels <= 128 ? 2 : 3);
-    const int nchunk = (channels + 64 * cpl - 1) / (64 * cpl);
+    // rank-2 updates on the matrix cores, 32 * NP channels per chunk (NP = 1 .. 6)
+    const char* np_env = getenv("SIU3R_FEAT_NP");  // (A/B: blocks per chunk)
+    const int np_max = np_env ? max(1, min(6, atoi(np_env))) : 6;
+    const int np = channels >= 32 * np_max ? np_max : (channels + 31) / 32;
+    const int nchunk = (channels + 32 * np - 1) / (32 * np);
     SIU3R_CHECK(nchunk <= 65535 && V <= 65535, "raster_composite_feat: too many channel chunks / views");
     const dim3 grid(geo.T, nchunk, V);
-    if (cpl == 1)
-      hipLaunchKernelGGL(composite_feat2_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, rec, feats, channels, G, out, out_alpha);
-    else if (cpl == 2)
-      hipLaunchKernelGGL(composite_feat2_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, rec, feats, channels, G, out, out_alpha);
-    else
-      hipLaunchKernelGGL(composite_feat2_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, rec, feats, channels, G, out, out_alpha);
+#define SIU3R_F4(N) hipLaunchKernelGGL(composite_feat4_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, rec, feats, channels, G, V, out, out_alpha)
+    switch (np) {
+      case 1: SIU3R_F4(1); break;
+      case 2: SIU3R_F4(2); break;
+      case 3: SIU3R_F4(3); break;
+      case 4: SIU3R_F4(4); break;
+      case 5: SIU3R_F4(5); break;
+      default: SIU3R_F4(6); break;
+    }
+#undef SIU3R_F4
   }
   SIU3R_LAUNCH_CHECK("siu3r_raster_composite_feat");
   return 0;

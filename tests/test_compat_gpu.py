@@ -165,7 +165,7 @@ def test_gsplat_rasterization_with_the_viewers_argument_lists():
     assert np.array_equal(info["radii"][0].cpu().numpy(), ref["radii"])
     # the repo's own viewer entry point with device-side cameras: the same launches
     c3, a3, _ = rasterize_splats(splats, camtoworlds, Ks, W, H, sh_degree=degree, radius_clip=0.1)
-    assert torch.equal(c3, render_colors) and torch.equal(a3, render_alphas)
+    assert float((c3 - render_colors).abs().max()) <= 1e-6 and torch.equal(a3, render_alphas)  # (camera centre: c2w[:3, 3] here, inverse(viewmat)[:3, 3] there)
     # --- viewer.py:338-373 `rasterize_qc_logits`
     nq, ncls = 3, 21
     qc = torch.randn(G, nq, ncls, generator=g).cuda()

@@ -88,13 +88,17 @@ def test_k3_channels(channels):
     assert err <= 2e-6 and erra <= 2e-6
 
 
-@pytest.mark.parametrize("channels", [168, 3 * 64 + 8, 130, 63, 21])
+FORMS = ("4",)
+
+
+@pytest.mark.parametrize("channels", [168, 3 * 64 + 8, 130, 63, 32, 21])
 def test_k3_all_channel_composite_equals_the_chunked_one(channels, monkeypatch):
-    """The sparse all-channel list composite (composite_feat2_kernel: weights once per (pixel, entry), blended per pixel in list order,
-    lanes = channels) against the 32-channel-chunk kernel it replaces (SIU3R_FEAT_FORM=1) -- the same FMAs in the same order, hence
-    bit-identical maps -- and against the C oracle, on a ragged frame with several views in one call: q x 21 = 168 logit channels (one
-    192-channel chunk), 200 (two chunks), 130 (three channels per lane, a partly filled chunk), 63 (not a multiple of 4: scalar feature
-    loads) and 21."""
+    """The matrix-core list composite (composite_feat4_kernel: alpha / transmittance once per (pixel, entry) for all channels, lists cut to
+    the wave's 8 x 8 quadrant, the blend as rank-2 v_mfma_f32_32x32x2_f32 updates -- exact f32, accumulating like the oracle's fmaf chain --
+    with records and feature rows double-buffered in LDS by LDS-DMA) against the 32-channel-chunk kernel it replaces (SIU3R_FEAT_FORM=1):
+    bit-identical maps; and against the C oracle, on a ragged frame with several views in one call: q x 21 = 168 logit channels (6 blocks,
+    the last one a shifted window), 200 (two chunks, the second shifted back), 130, 63 (not a multiple of 4: the 32-channel kernel
+    serves it), 32 and 21 (below one block: the 32-channel kernel)."""
     from oracle import raster_oracle as RO
     from siu3r_amd import raster
 
@@ -108,12 +112,13 @@ def test_k3_all_channel_composite_equals_the_chunked_one(channels, monkeypatch):
     args = (cams, means.cuda(), cov6.cuda(), opac.cuda(), feats.cuda())
     monkeypatch.setenv("SIU3R_FEAT_FORM", "1")
     old = raster.rasterize_views_k3(*args)
-    monkeypatch.setenv("SIU3R_FEAT_FORM", "2")
-    new = raster.rasterize_views_k3(*args)
+    for form in FORMS:
+        monkeypatch.setenv("SIU3R_FEAT_FORM", form)
+        new = raster.rasterize_views_k3(*args)
+        assert torch.equal(new["colors"], old["colors"]) and torch.equal(new["alphas"], old["alphas"]), (form, float((new["colors"] - old["colors"]).abs().max()))
     monkeypatch.delenv("SIU3R_FEAT_FORM")
     dflt = raster.rasterize_views_k3(*args)
-    assert torch.equal(new["colors"], old["colors"]) and torch.equal(new["alphas"], old["alphas"]), float((new["colors"] - old["colors"]).abs().max())
-    assert torch.equal(dflt["colors"], new["colors"])  # the default is the new form
+    assert torch.equal(dflt["colors"], new["colors"])  # the default is the last (shipped) form
     for v in (0, 2):
         ref = RO.forward(cams[v], means.numpy(), cov6.numpy(), opac.numpy(), feats.numpy(), want_lists=False)
         assert ref["D"] > 3000
