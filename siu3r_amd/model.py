@@ -863,6 +863,7 @@ class VideoMask2FormerForVideoSegmentation:
         # own mask logits (sigmoid < 0.5, video_seg_decoder.py:1461-1478): tests feed the oracle's masks to show that a logit difference
         # above 1e-3 is a flipped borderline mask pixel and nothing else.  Eager mode only.
         self.forced_attn_masks = None
+        self.record_attn_masks = None  # parity diagnostics (tests): a list that receives the nine boolean masks the layers attend through
         self.heads = 8
 
     # ---- pixel decoder (video_seg_decoder.py:2072-2196), feats NHWC [N2, h_l, w_l, 1024], strides 4,8,16,32
@@ -1026,6 +1027,8 @@ class VideoMask2FormerForVideoSegmentation:
                 fm = self.forced_attn_masks[idx].to(ctx.dev, torch.uint8)
                 am = torch.zeros((B, Q, ((fm.shape[-1] + 63) // 64) * 64), dtype=torch.uint8, device=ctx.dev)
                 am[..., :fm.shape[-1]] = fm
+            if self.record_attn_masks is not None:
+                self.record_attn_masks.append(am.clone())
             a = ops.attention(q, k, v, heads=8, head_dim=d, scale=d ** -0.5, mask=am, split3=ctx.split)
             a = ops.linear(a, ctx.w.linear(p + ".cross_attn.out_proj"), out_dtype=torch.float32, residual=hs)
             hs, hsb = ctx.ln2(p + ".cross_attn_layer_norm", a, 1e-5)

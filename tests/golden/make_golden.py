@@ -97,11 +97,14 @@ def model_fixture(size, sd):
 
 
 def multi_fixture(sd, size=128, V=3):
-    """SIU3RMultiViewModel (src/models/model_multi.py) on V = 3 views: the asset pair + the first image mirrored."""
+    """SIU3RMultiViewModel (src/models/model_multi.py) on V views made of the asset pair (golden_utils.multi_views: V = 3 is the pair + the
+    first image mirrored; V = 8 adds the other mirrors and the transposes).  Fields and logits as strided samples + dense windows + norms;
+    the integer outputs of the panoptic branch as strided samples + whole-map histograms, like the two-view fixtures."""
+    from golden_utils import multi_views
+
     model = R.build_reference_model((size, size), multi=True)
     model.load_state_dict(sd, strict=False)  # backbone.mask_token (unused at inference) is not in the key spec
-    pair = load_pair(size)[0]
-    img = torch.stack((pair[0], pair[1], pair[0].flip(-1)))[None]
+    img = multi_views(load_pair(size)[0], V)
     K = torch.tensor([[318 / 256, 0, 0.5], [0, 318 / 256, 0.5], [0, 0, 1]])[None, None].repeat(1, V, 1, 1)
     with torch.no_grad():
         g, seg, masks, infos, qs = model(img, K, enable_query_class_logit_lift=True)
@@ -115,11 +118,21 @@ def multi_fixture(sd, size=128, V=3):
     out["class_queries_logits.full"] = seg.class_queries_logits.numpy()
     out["semantic_labels.sum"] = np.asarray(int(g.semantic_labels.sum()))
     out["instance_labels.sum"] = np.asarray(int(g.instance_labels.sum()))
+    out["seg_mask.dtype"] = np.asarray(str(masks[0].dtype))
+    out["seg_mask.sample"] = masks[0].reshape(-1)[::ISTRIDE].numpy()
+    out["seg_mask.hist"] = torch.bincount(masks[0].reshape(-1).long().clamp_min(0), minlength=8).numpy()
+    out["semantic_labels.sample"] = g.semantic_labels.reshape(-1)[::ISTRIDE].numpy()
+    out["instance_labels.sample"] = g.instance_labels.reshape(-1)[::ISTRIDE].numpy()
+    out["semantic_labels.hist"] = torch.bincount(g.semantic_labels.reshape(-1).long(), minlength=22).numpy()
+    qcl = g.seg_query_class_logits[0]
+    out["qcl.shape"] = np.asarray(qcl.shape)
+    out["qcl.sample"] = qcl.reshape(-1)[::STRIDE].numpy()
+    out["qcl.l2"] = np.asarray(float(qcl.double().norm()))
     np.savez_compressed(os.path.join(HERE, f"model_multi_v{V}_{size}.npz"), **out)
     with open(os.path.join(HERE, f"model_multi_v{V}_{size}.json"), "w") as fh:
-        json.dump(dict(seg_infos=infos, query_scores=qs, input="asset pair + image1 mirrored, /255, bilinear to size", views=V,
+        json.dump(dict(seg_infos=infos, query_scores=qs, input="golden_utils.multi_views of the asset pair, /255, bilinear to size", views=V,
                        intrinsics="fx=fy=318/256, c=0.5", weights="oracle.weights.make_weights(0)", stride=STRIDE), fh)
-    print("multi-view fixture done")
+    print("multi-view fixture done", V, size, [len(i) for i in infos])
 
 
 def panoptic_fixture():
@@ -206,5 +219,8 @@ if __name__ == "__main__":
         lifting_fixture()
     sd = OW.make_weights(0)
     multi_fixture(sd)
+    multi_fixture(sd, size=256, V=8)   # BASELINE configs[4]'s network half (8 views), at 256^2: 20 s of reference CPU time
+    if "multi" in sys.argv[1:]:        # `make_golden.py models multi`: only the multi-view fixtures
+        sys.exit(0)
     for size in (256, 512):
         model_fixture(size, sd)

@@ -36,10 +36,16 @@ def default_K(B=1, V=2):
     return torch.tensor([[318 / 256, 0, 0.5], [0, 318 / 256, 0.5], [0, 0, 1]])[None, None].repeat(B, V, 1, 1)
 
 
-def fixture_images_multi(size=128):
-    """V = 3 fixture input: the asset pair and the first image mirrored (tests/golden/make_golden.py::multi_fixture)."""
-    pair = fixture_images(size)[0]
-    return torch.stack((pair[0], pair[1], pair[0].flip(-1)))[None]
+def multi_views(pair, V):
+    """V <= 8 views made of the asset pair only (no new image data): the pair, then its horizontal mirrors, vertical mirrors, transposes"""
+    views = [pair[0], pair[1], pair[0].flip(-1), pair[1].flip(-1), pair[0].flip(-2), pair[1].flip(-2), pair[0].transpose(-1, -2), pair[1].transpose(-1, -2)]
+    assert 2 <= V <= len(views)
+    return torch.stack(views[:V])[None]
+
+
+def fixture_images_multi(size=128, V=3):
+    """multi-view fixture input (tests/golden/make_golden.py::multi_fixture): V = 3 is the asset pair and the first image mirrored"""
+    return multi_views(fixture_images(size)[0], V)
 
 
 def load_multi_fixture(V=3, size=128):
@@ -47,7 +53,20 @@ def load_multi_fixture(V=3, size=128):
     return z, json.load(open(os.path.join(GOLDEN, f"model_multi_v{V}_{size}.json")))
 
 
-def compare_summary(name, t: torch.Tensor, z, tol):
+REL_FLOOR = 1e-3  # element-wise relative error: |err| / max(|ref|, REL_FLOOR * absmax(ref))
+
+
+def elementwise_rel(got: torch.Tensor, want: torch.Tensor, absmax: float):
+    """(worst, fraction above 1e-3) of the ELEMENT-WISE relative error |got - want| / max(|want|, 1e-3 * absmax): the north-star's "1e-3 rel"
+    read per element, with a floor at a thousandth of the tensor's range so that entries that are zero up to rounding do not divide by
+    nothing (the max-normalised figure next to it divides every element by absmax)."""
+    g, w = got.double().reshape(-1), want.double().reshape(-1)
+    rel = (g - w).abs() / torch.clamp(w.abs(), min=REL_FLOOR * absmax + 1e-300)
+    return float(rel.max()) if rel.numel() else 0.0, float((rel > 1e-3).double().mean()) if rel.numel() else 0.0
+
+
+def compare_summary(name, t: torch.Tensor, z, tol, rel_tol=None):
+    """rel_tol: bound on the element-wise relative error (elementwise_rel) of the samples and of the dense window; None = reported only"""
     f = t.detach().float().cpu().reshape(-1)
     want = torch.from_numpy(z[f"{name}.sample"])
     got = f[::STRIDE]
@@ -55,8 +74,10 @@ def compare_summary(name, t: torch.Tensor, z, tol):
     scale = float(z[f"{name}.absmax"]) + 1e-30
     err = float((got - want).abs().max()) / scale
     l2 = abs(float(f.double().norm()) - float(z[f"{name}.l2"])) / (float(z[f"{name}.l2"]) + 1e-30)
-    print(f"[golden] {name:24s} sample max-normalised err {err:.3e}  |l2 rel diff| {l2:.3e}")
+    rel, frac = elementwise_rel(got, want, scale)
+    print(f"[golden] {name:24s} sample max-normalised err {err:.3e}  |l2 rel diff| {l2:.3e}  element-wise rel worst {rel:.3e} (> 1e-3 on {frac:.2%} of the elements)")
     assert err <= tol and l2 <= tol, (name, err, l2)
+    assert rel_tol is None or rel <= rel_tol, (name, "element-wise relative error", rel, rel_tol)
     if f"{name}.window" in z.files:
         # one contiguous window (64 Ki elements) compared densely: max-normalised error and the relative L2 norm OF THE DIFFERENCE
         o, n = window_of(f.numel())
@@ -64,8 +85,11 @@ def compare_summary(name, t: torch.Tensor, z, tol):
         assert w_want.numel() == n, (name, w_want.numel(), n)
         werr = float((w_got - w_want).abs().max()) / scale
         wl2 = float((w_got - w_want).norm() / (w_want.norm() + 1e-30))
-        print(f"[golden] {name:24s} dense window [{o}:{o + n}] max-normalised err {werr:.3e}  rel l2 of the difference {wl2:.3e}")
+        wrel, wfrac = elementwise_rel(w_got, w_want, scale)
+        print(f"[golden] {name:24s} dense window [{o}:{o + n}] max-normalised err {werr:.3e}  rel l2 of the difference {wl2:.3e}  "
+              f"element-wise rel worst {wrel:.3e} (> 1e-3 on {wfrac:.2%})")
         assert werr <= tol and wl2 <= tol, (name, werr, wl2)
+        assert rel_tol is None or wrel <= rel_tol, (name, "element-wise relative error (window)", wrel, rel_tol)
         err = max(err, werr)
     return err
 

@@ -169,11 +169,44 @@ def test_batch_of_eight_label_maps_are_run_to_run_identical():
         for it in range(16):
             o = model(img, K, enable_query_class_logit_lift=True)
             torch.cuda.synchronize()
-            cur = (o[0].instance_labels.clone(), o[0].semantic_labels.clone(), torch.stack(list(o[2])).clone(), o[1].masks_queries_logits.clone())
+            cur = (o[0].instance_labels.clone(), o[0].semantic_labels.clone(), torch.stack(list(o[2])).clone(), o[1].masks_queries_logits.clone(),
+                   o[1].class_queries_logits.clone(), *(getattr(o[0], f).clone() for f in GAUSSIAN_FIELDS))  # (round 5: all six Gaussian fields too)
             if ref is None:
                 ref = cur
             elif not all(torch.equal(a, b) for a, b in zip(cur, ref)):
                 bad.append((it, [int((a != b).sum()) for a, b in zip(cur, ref)]))
     assert not bad, bad
+    del model
+    torch.cuda.empty_cache()
+
+
+GAUSSIAN_FIELDS = ("means", "covariances", "harmonics", "opacities", "scales", "rotations")
+
+
+def test_two_hundred_single_pair_forwards_are_identical():
+    """Round 5 companion of the batch-of-eight test: every cross-stream hand-off of the forward (six streams, per-chain HIP graphs, the
+    panoptic device stage behind Mask2Former, the eager tail) exercised 200 times at B = 1 @256^2: label maps, segmentation, both logit
+    tensors and all six Gaussian fields bit-identical to the first forward.  (The round-4 stale read showed up at B = 8 only; with plain
+    loads in the argmax kernel -- SIU3R_PP_DBG=1 -- round 5 measured 0 differing forwards in 222 at B = 8, and a torch-free repro of the
+    writer -> reader hand-off beside seven streams of graph replays, tools/probes/stale_probe.hip, 0 stale reads in 2400 iterations.)"""
+    from golden_utils import default_K, fixture_images
+    from siu3r_amd.model import SIU3RModel
+
+    S = 256
+    img, K = fixture_images(S).cuda(), default_K().cuda()
+    model = SIU3RModel(_weights(), image_size=(S, S), precision="bf16x3")
+    ref, bad = None, []
+    with torch.no_grad():
+        for it in range(200):
+            o = model(img, K, enable_query_class_logit_lift=True)
+            if it % 8 == 0:
+                torch.cuda.synchronize()  # (mostly back to back: the next forward is enqueued while this one's tail runs)
+            cur = (o[0].instance_labels, o[0].semantic_labels, torch.stack(list(o[2])), o[1].masks_queries_logits, o[1].class_queries_logits,
+                   *(getattr(o[0], f) for f in GAUSSIAN_FIELDS))
+            if ref is None:
+                ref = tuple(t.clone() for t in cur)
+            elif not all(torch.equal(a, b) for a, b in zip(cur, ref)):
+                bad.append((it, [int((a != b).sum()) for a, b in zip(cur, ref)]))
+    assert not bad, bad[:8]
     del model
     torch.cuda.empty_cache()

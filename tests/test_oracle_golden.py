@@ -94,16 +94,23 @@ def test_model_forward_against_reference_vectors(size):
     compare_integer_outputs(out["semantic_labels"], out["instance_labels"], out["seg_masks"][0], qcl_gm, z, 2e-5, min_agree=0.9999)
 
 
-def test_multiview_forward_against_reference_vectors():
-    """SIU3RMultiViewModel.forward of the reference (V = 3, 128^2) vs oracle.model_forward_multi."""
-    z, meta = load_multi_fixture()
+@pytest.mark.parametrize("V,size", [(3, 128), (8, 256)], ids=["v3_128", "v8_256"])
+def test_multiview_forward_against_reference_vectors(V, size):
+    """SIU3RMultiViewModel.forward of the reference vs oracle.model_forward_multi: V = 3 at 128^2, and V = 8 at 256^2 -- the network half
+    of BASELINE configs[4] (8 views), pinned to the reference's own model_multi.py (20 s of its CPU time at 256^2; the 512^2 run takes
+    74 s and 19.5 TFLOP).  Fields and logits (samples, dense windows, norms), the segment table, and the integer outputs of the panoptic
+    branch: strided samples + whole-map histograms of the id maps, samples of the query x class logit volume."""
+    z, meta = load_multi_fixture(V, size)
     with torch.no_grad():
-        out = O.model_forward_multi(_weights(), fixture_images_multi(128), default_K(1, 3), keep_intermediates=False)
+        out = O.model_forward_multi(_weights(), fixture_images_multi(size, V), default_K(1, V), keep_intermediates=False)
     for f in FIELDS + ("class_queries_logits", "masks_queries_logits"):
         compare_summary(f, out[f], z, 2e-4)
-    assert abs(int(out["semantic_labels"].sum()) - int(z["semantic_labels.sum"])) <= 64 and abs(int(out["instance_labels"].sum()) - int(z["instance_labels.sum"])) <= 64
     segments_match(out["seg_infos"], meta["seg_infos"], 3e-6)
     assert np.allclose(out["query_scores"][0], meta["query_scores"][0], atol=3e-6) and len(meta["seg_infos"][0]) >= 3
+    qcl = out["query_class_logits"][0]
+    qcl_gm = qcl.permute(0, 3, 4, 1, 2).reshape(-1, qcl.shape[1], qcl.shape[2])  # 'n q c h w -> (n h w) q c' (model.py:261-263)
+    # (two fp32 evaluation orders of the mask logits: a handful of border pixels may change owner, as in the two-view fixtures)
+    compare_integer_outputs(out["semantic_labels"], out["instance_labels"], out["seg_masks"][0], qcl_gm, z, 2e-5, min_agree=0.9999)
 
 
 def test_sh_basis_forms_agree():
