@@ -253,9 +253,23 @@ def main():
     print(json.dumps(result))
 
 
-def _profile_kernel_stats():
-    """newest committed rocprofv3 --kernel-trace --stats summary of this command: {kernel name: (calls, average ns)}"""
+def _profile_kernel_stats(which="step_kernels.txt"):
+    """newest committed rocprofv3 summary of this command, steady state: {kernel name: (launches per step, average ns per launch)} from
+    profiles/rNN_step_kernels.txt (the difference of a 25-step and a 5-step `rocprofv3 --kernel-trace --stats` profile: 20 replayed steps,
+    no warm-up / capture / weight-packing launches in it; the chains run CONCURRENTLY there, kernels share the chip) or
+    rNN_eager_step_kernels.txt (the same for eager single-stream steps: every kernel alone, the regime of this file's HIP-event leg);
+    falls back to rNN_bench_kernel_stats.csv (every launch of the whole command)"""
     import csv
+    import re
+    path = _latest_profile(which)
+    if os.path.exists(path):
+        rows = {}
+        for line in open(path):
+            m = re.match(r"\s*([0-9.]+) us/step\s+([0-9.]+) launches/step\s+(.*)$", line)
+            if m and float(m.group(2)) > 0:
+                rows[m.group(3).strip()] = (float(m.group(2)), float(m.group(1)) * 1e3 / float(m.group(2)))
+        if rows:
+            return "profiles/" + os.path.basename(path), rows
     path = _latest_profile("bench_kernel_stats.csv")
     if not os.path.exists(path):
         return None, {}
@@ -328,17 +342,30 @@ def gemm_roofline(model, step, precision, B, H, W, passes=3):
     variants = lambda pred: {k: {"launches": v["launches"], "ms": v["ms"], "avg_launch_us": v["ms"] * 1e3 / v["launches"],
                                  "avg_launch_us_min_max_over_passes": [v["ms_min"] * 1e3 / v["launches"], v["ms_max"] * 1e3 / v["launches"]],
                                  "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]) if pred(k)}
-    # consistency: (i) the kernels of one serial step cannot take longer than the step; (ii) the committed rocprofv3 summary of the
-    # same command must agree on the dominant kernel's average launch duration
+    # consistency: (i) the kernels of one serial step cannot take longer than the step; (ii) the committed rocprofv3 summary of the SAME
+    # regime (eager, one stream: profiles/rNN_eager_step_kernels.txt) must agree on the dominant kernel's average launch duration; and,
+    # for the record, (iii) the same kernel inside the replayed multi-stream step (profiles/rNN_step_kernels.txt): there its launches share
+    # the chip with the other chains and take longer -- `in_step` is that figure, from the committed profile, not measured in this run
     gemm_ms = sum(v["ms"] for v in summ.values())
     avg_us = d["ms"] * 1e3 / d["launches"]
-    prof_name, prof = _profile_kernel_stats()
-    prow = [(c, ns) for n, (c, ns) in prof.items() if _family(n.replace("void ", "")) == name and (("<true" in n) == (precision == "bf16x3"))]
-    prof_avg_us = sum(c * ns for c, ns in prow) / max(1, sum(c for c, _ in prow)) / 1e3 if prow else None
+
+    def prof_avg(which):
+        pn, prof = _profile_kernel_stats(which)
+        prow = [(c, ns) for n, (c, ns) in prof.items() if _family(n.replace("void ", "")) == name and (("<true" in n) == (precision == "bf16x3"))]
+        return pn, (sum(c * ns for c, ns in prow) / max(1e-9, sum(c for c, _ in prow)) / 1e3 if prow else None)
+
+    prof_name, prof_avg_us = prof_avg("eager_step_kernels.txt")
+    same_regime = prof_name is not None and prof_name.endswith("eager_step_kernels.txt")
+    step_name, step_avg_us = prof_avg("step_kernels.txt")
     check = {"dominant_ms_le_eager_step": bool(d["ms"] <= eager_step_ms), "gemm_ms_le_eager_step": bool(gemm_ms <= eager_step_ms),
-             "eager_single_stream_step_ms": eager_step_ms, "profile": prof_name, "profile_avg_launch_us": prof_avg_us,
-             "ratio_to_profile": (avg_us / prof_avg_us) if prof_avg_us else None,
-             "agrees_with_profile_within_10pct": bool(abs(avg_us / prof_avg_us - 1.0) <= 0.10) if prof_avg_us else None}
+             "eager_single_stream_step_ms": eager_step_ms, "profile": prof_name, "profile_is_same_regime": same_regime,
+             "profile_avg_launch_us": prof_avg_us, "ratio_to_profile": (avg_us / prof_avg_us) if prof_avg_us else None,
+             "agrees_with_profile_within_10pct": bool(abs(avg_us / prof_avg_us - 1.0) <= 0.10) if (prof_avg_us and same_regime) else None}
+    in_step = None
+    if step_avg_us and step_name.endswith("step_kernels.txt") and not step_name.endswith("eager_step_kernels.txt"):
+        in_step = {"source": step_name + " (replayed multi-stream step under rocprofv3 --kernel-trace: the chains run beside each other)", "live": False,
+                   "avg_launch_us": step_avg_us, "achieved": d["flops"] / d["launches"] / (step_avg_us * 1e-6) / 1e12,
+                   "frac": d["flops"] / d["launches"] / (step_avg_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
     if not check["gemm_ms_le_eager_step"] or check["agrees_with_profile_within_10pct"] is False:
         print(f"bench.py: roofline consistency check: {check}", file=sys.stderr)
     return {
@@ -355,6 +382,7 @@ def gemm_roofline(model, step, precision, B, H, W, passes=3):
         "gemm_time_ms_per_step": gemm_ms,
         "gemm_tflops_all_kernels": sum(v["flops"] for v in summ.values()) / (gemm_ms * 1e-3) / 1e12,
         "consistency": check,
+        "in_step": in_step,
         "instantiations": variants(lambda k: _family(k) == name),
         "other_gemm_kernels": variants(lambda k: _family(k) != name),
     }
@@ -494,8 +522,9 @@ def logit_leg(means, cov, opac, ext, Kt, H, W, nv, q=8, classes=21):
     ach = bytes_alg / (ms_frame * 1e-3) / 1e9
     return {"ms_per_frame": ms_frame, "views": nv, "resolution": [H, W], "gaussians": G, "channels": Cc, "kept_queries": q, "visible_mean": sum(Gv) / nv,
             "tile_pairs_mean": sum(Dp) / nv, "scene": "siu3r_amd.synthetic.pixel_aligned_scene(seed=0) with seeded normal features [G, q*21]",
-            "semantics": "K3 (gsplat.rasterization family): N-channel features, per-tile lists materialised once, 32 channels per composite pass; "
-                         "overflow counters read after every call (one device synchronisation per call, as the evaluation loop runs it)",
+            "semantics": "K3 (gsplat.rasterization family): N-channel features, per-tile lists materialised once, all channels composited in one pass as "
+                         "rank-2 v_mfma_f32_32x32x2_f32 updates (exact f32, bit-identical to the 32-channel-chunk kernel); overflow counters read after "
+                         "every call (one device synchronisation per call, as the evaluation loop runs it)",
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_view": bytes_alg, "formula": "(44+4C) G + 36 G_v + (76+4C) D + (4C+4) P", "traffic": None}}
 

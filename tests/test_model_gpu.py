@@ -555,9 +555,10 @@ def test_parity_sweep(case):
     assert max(fields.values()) <= 1e-3, fields
     assert max(logits.values()) <= 5e-3, logits
     assert agree >= 0.995
-    if max(logits.values()) > 1e-3:
-        # above the north-star bar: then it must be a flipped pixel of a thresholded attention mask and nothing else -- with the
-        # oracle's nine boolean masks forced into the HIP run (eager) the same logits are within 1e-3
+    if max(logits.values()) > 2e-4:
+        # well above the 3e-5 the logits otherwise show (and in some rounds / on some shapes above the 1e-3 bar: 1-3e-3 in 3 of 7 cases in
+        # round 4, 9.5e-4 at 224^2 in round 5): then it must be a flipped pixel of a thresholded attention mask and nothing else -- with
+        # the oracle's nine boolean masks forced into the HIP run (eager) the same logits are within 1e-3 (in fact back at the 3e-5 level)
         model.use_graph = False
         model.mask2former.forced_attn_masks = ref["attn_masks"]
         with torch.no_grad():

@@ -23,6 +23,21 @@ print(f"one bf16x3 step (profiled: streams serialised): {sum(r[1] for r in rows)
 for us, c, n in rows:
     print(f"{us:9.1f} us/step {c:7.1f} launches/step  {n[:170]}")
 PY
+# the same table for EAGER SINGLE-STREAM steps (no graphs, no concurrent chains: every kernel alone on the chip, back to back) -- the regime
+# bench.py's roofline leg times with HIP events; its per-kernel averages are what that leg's numbers must agree with
+ROCPROF_HEAD=1 SIU3R_NO_GRAPH=1 SIU3R_NO_STREAMS=1 bash tools/rocprof_cmd.sh ${tag}_e5 python bench.py $Bq --steps 5 > /dev/null
+ROCPROF_HEAD=1 SIU3R_NO_GRAPH=1 SIU3R_NO_STREAMS=1 bash tools/rocprof_cmd.sh ${tag}_e25 python bench.py $Bq --steps 25 > /dev/null
+python - $tag <<'PY' > $O/${tag}_eager_step_kernels.txt
+import csv, sys
+tag = sys.argv[1]
+ld = lambda f: {r["Name"]: (int(r["Calls"]), int(r["TotalDurationNs"])) for r in csv.DictReader(open(f))}
+a, b = ld(f"gpurun_out/{tag}_e5_kernel_stats.csv"), ld(f"gpurun_out/{tag}_e25_kernel_stats.csv")
+rows = sorted(((t - a.get(n, (0, 0))[1]) / 20e3, (c - a.get(n, (0, 0))[0]) / 20, n) for n, (c, t) in b.items() if c - a.get(n, (0, 0))[0] > 0)[::-1]
+print(f"one bf16x3 step, EAGER on ONE stream (SIU3R_NO_GRAPH=1 SIU3R_NO_STREAMS=1; rocprofv3 --kernel-trace --stats, 25-step minus 5-step profile): "
+      f"{sum(r[1] for r in rows):.0f} launches, {sum(r[0] for r in rows) / 1e3:.2f} ms of kernel time")
+for us, c, n in rows:
+    print(f"{us:9.1f} us/step {c:7.1f} launches/step  {n[:170]}")
+PY
 bash tools/pmc_round.sh $tag > $O/${tag}_pmc_round.log 2>&1
 ROCPROF_HEAD=12 bash tools/rocprof_cmd.sh ${tag}_raster_stress python tools/mb_raster.py stress > $O/${tag}_raster_stress.log 2>&1
 ROCPROF_HEAD=12 bash tools/rocprof_cmd.sh ${tag}_raster_pair python tools/mb_raster.py pair 6 > $O/${tag}_raster_pair.log 2>&1
@@ -32,6 +47,8 @@ timeout 200 python tools/timeline.py bf16x3 1 > $O/${tag}_timeline_bf16x3.txt 2>
 timeout 200 python tools/timeline.py bf16 1 > $O/${tag}_timeline_bf16.txt 2>&1
 timeout 200 python tools/stage_times.py bf16x3 > $O/${tag}_stage_times.txt 2>&1
 timeout 200 python tools/mb_presplit.py > $O/${tag}_mb_presplit.txt 2>&1   # the encoder block's GEMMs with fp32 and with pre-split operands
+timeout 200 python tools/mb_feat.py 168 84 40 > $O/${tag}_mb_feat.txt 2>&1   # N-channel list composite: 32-channel-chunk kernel vs matrix-core form
+bash tools/pmc_feat.sh > $O/${tag}_pmc_feat.txt 2>&1
 ( for e in SIU3R_NO_PRESPLIT SIU3R_NO_DEC_QKVX SIU3R_NO_CONV_PLANES SIU3R_NO_KV_PLANES NONE; do   # same-box A/B of the round's switches
     env $e=1 python bench.py --gpus 1 --steps 20 --warmup 5 --no-second-mode --no-roofline --no-render --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$e=1', round(d['value'], 2), 'pairs/s', round(d['ms_per_step'], 3), 'ms')"
   done ) > $O/${tag}_switches.txt 2>&1
