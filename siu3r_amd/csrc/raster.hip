@@ -1540,7 +1540,7 @@ extern "C" int siu3r_raster_composite_feat(const siu3r_raster_cam* cams_host, in
   const char* form_env = getenv("SIU3R_FEAT_FORM");  // 1 = the 32-channel kernel everywhere (A/B; the tests cross-check the two forms bit for bit)
   const int form = form_env ? atoi(form_env) : 4;
   // (the matrix-core form addresses records and features through buffer resources: 32-bit byte offsets)
-  const bool fits32 = (int64_t)V * G * 48 < (1ll << 31) * 2 - 64 && (int64_t)G * channels * 4 < (1ll << 31) * 2 - 64 && (channels & 3) == 0 && (((uintptr_t)feats) & 15) == 0;
+  const bool fits32 = (int64_t)V * G * 48 < (1ll << 31) * 2 - 64 && (int64_t)G * channels * 4 < (1ll << 31) * 2 - 64 && (((uintptr_t)feats) & 3) == 0;  // (rows need not be 16-byte aligned: q x 21 channels rarely are)
   if (form == 1 || channels < 32 || !fits32) {
     const int nchunk = (channels + CHUNK - 1) / CHUNK;
     SIU3R_CHECK(nchunk <= 65535 && V <= 65535, "raster_composite_feat: too many channel chunks / views");

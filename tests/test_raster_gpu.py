@@ -91,14 +91,14 @@ def test_k3_channels(channels):
 FORMS = ("4",)
 
 
-@pytest.mark.parametrize("channels", [168, 3 * 64 + 8, 130, 63, 32, 21])
+@pytest.mark.parametrize("channels", [168, 3 * 64 + 8, 130, 105, 63, 32, 21])
 def test_k3_all_channel_composite_equals_the_chunked_one(channels, monkeypatch):
     """The matrix-core list composite (composite_feat4_kernel: alpha / transmittance once per (pixel, entry) for all channels, lists cut to
     the wave's 8 x 8 quadrant, the blend as rank-2 v_mfma_f32_32x32x2_f32 updates -- exact f32, accumulating like the oracle's fmaf chain --
     with records and feature rows double-buffered in LDS by LDS-DMA) against the 32-channel-chunk kernel it replaces (SIU3R_FEAT_FORM=1):
     bit-identical maps; and against the C oracle, on a ragged frame with several views in one call: q x 21 = 168 logit channels (6 blocks,
-    the last one a shifted window), 200 (two chunks, the second shifted back), 130, 63 (not a multiple of 4: the 32-channel kernel
-    serves it), 32 and 21 (below one block: the 32-channel kernel)."""
+    the last one a shifted window), 200 (two chunks, the second shifted back), 130, 105 and 63 (q x 21 with odd q: feature rows that are only
+    4-byte aligned), 32 and 21 (below one block: the 32-channel kernel serves it)."""
     from oracle import raster_oracle as RO
     from siu3r_amd import raster
 
