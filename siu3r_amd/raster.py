@@ -95,7 +95,11 @@ def _remember(kind: str, G: int, V: int, W: int, H: int, needed: int):
 
 
 class RasterOverflow(RuntimeError):
-    pass
+    """call_id: sequence number of the deferred call whose views overflowed (None for the synchronous paths)"""
+
+    def __init__(self, msg, call_id=None):
+        super().__init__(msg)
+        self.call_id = call_id
 
 
 class _State(dict):
@@ -229,9 +233,13 @@ def _project_sort_bin(cams: Sequence[RasterCam], means, cov, opac, colors, chann
 # asynchronous copy of the counters into pinned memory instead and looks at it when the NEXT deferred call starts (by then the copy has
 # long landed) or when check_pending() is called; an overflowing view cannot pass unnoticed meanwhile: the composite kernel fills it
 # with NaN.  On detection the needed capacity is remembered (later calls of that scene size are sized right) and RasterOverflow names
-# the call, which the caller repeats (evaluate.py does; SplattingCUDA.check_pending is the explicit barrier).
+# the call that overflowed -- its sequence number (`RasterOverflow.call_id`, returned as out["call_id"] by the deferred call) and its
+# scene size -- so that the caller knows WHICH result to discard and repeat; the exception may surface at the start of a LATER deferred
+# call (which has not run yet) or at check_pending().  Callers in this repository: bench.py's render legs (check_pending() after the
+# timed calls); evaluate.py renders with the synchronous check (check_overflow=True: transparent repeat).
 _PENDING: "collections.deque" = collections.deque()
 _PINNED_FREE: list = []
+_CALL_SEQ = [0]
 
 
 def _defer_check(st: "_State"):
@@ -241,7 +249,9 @@ def _defer_check(st: "_State"):
     host.copy_(stats, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
-    _PENDING.append((ev, host, dict.__getitem__(st, "cap_e"), (dict.__getitem__(st, "G"), dict.__getitem__(st, "V"), dict.__getitem__(st, "W"), dict.__getitem__(st, "H"))))
+    _CALL_SEQ[0] += 1
+    _PENDING.append((ev, host, dict.__getitem__(st, "cap_e"), (dict.__getitem__(st, "G"), dict.__getitem__(st, "V"), dict.__getitem__(st, "W"), dict.__getitem__(st, "H")), _CALL_SEQ[0]))
+    return _CALL_SEQ[0]
 
 
 def check_pending(block: bool = True):
@@ -249,7 +259,7 @@ def check_pending(block: bool = True):
     arrived).  Raises RasterOverflow for the first call that overflowed its entry buffers (its views were rendered as NaN)."""
     bad = None
     while _PENDING:
-        ev, host, cap_e, key = _PENDING[0]
+        ev, host, cap_e, key, seq = _PENDING[0]
         if not block and not ev.query():
             break
         ev.synchronize()
@@ -259,10 +269,10 @@ def check_pending(block: bool = True):
             _PINNED_FREE.append(host)
         if e_max > cap_e:
             _remember("entries", *key, e_max)
-            bad = bad or (e_max, cap_e, key)
+            bad = bad or (e_max, cap_e, key, seq)
     if bad:
-        raise RasterOverflow(f"a deferred rasterizer call (G, V, W, H = {bad[2]}) overflowed its coarse-bin entries: E = {bad[0]} > entry_capacity {bad[1]}; "
-                             "its views were rendered as NaN.  The needed capacity is remembered: repeat the call")
+        raise RasterOverflow(f"deferred rasterizer call #{bad[3]} (G, V, W, H = {bad[2]}) overflowed its coarse-bin entries: E = {bad[0]} > entry_capacity "
+                             f"{bad[1]}; its views were rendered as NaN.  The needed capacity is remembered: repeat that call", call_id=bad[3])
 
 
 def _with_retry(run, entry_capacity, check_overflow):
@@ -273,7 +283,7 @@ def _with_retry(run, entry_capacity, check_overflow):
     if check_overflow == "deferred":
         check_pending(block=False)
         out = run(entry_capacity)
-        _defer_check(out["state"])
+        out["call_id"] = _defer_check(out["state"])
         return out
     out = run(entry_capacity)
     if not check_overflow:

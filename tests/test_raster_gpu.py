@@ -255,18 +255,23 @@ def test_deferred_overflow_check_poisons_and_reports():
     assert len(raster._PENDING) == 1
     torch.cuda.synchronize()
     assert torch.isnan(bad["image"]).all() and torch.isnan(bad["depth"]).all() and torch.isnan(bad["opacity"]).all()
-    with pytest.raises(raster.RasterOverflow, match="deferred"):
+    with pytest.raises(raster.RasterOverflow, match="deferred") as exc:
         raster.check_pending()
+    assert exc.value.call_id == bad["call_id"] != ok["call_id"]  # the exception names the call whose result is to be discarded
     assert not raster._PENDING
     again = raster.rasterize_views_k2(k2, *a, check_overflow="deferred")  # the remembered capacity covers the scene now
     raster.check_pending()
     assert again["state"]["cap_e"] >= E and torch.equal(again["image"], full["image"]) and torch.equal(again["depth"], full["depth"])
-    # the next deferred call is the implicit check point of the previous one
-    raster.rasterize_views_k2(k2, *a, entry_capacity=E // 3, check_overflow="deferred")
+    # the next deferred call is the implicit check point of the previous one (the exception carries the PREVIOUS call's id)
+    prev = raster.rasterize_views_k2(k2, *a, entry_capacity=E // 3, check_overflow="deferred")
     torch.cuda.synchronize()
-    with pytest.raises(raster.RasterOverflow):
+    with pytest.raises(raster.RasterOverflow) as exc:
         raster.rasterize_views_k2(k2, *a, check_overflow="deferred")
+    assert exc.value.call_id == prev["call_id"]
     raster.check_pending()
+    # the N-channel composite has no NaN marker: a deferred check is refused there
+    with pytest.raises(ValueError, match="deferred"):
+        raster.rasterize_views_k3([_k3_cam(H, W, 2)], a[0], a[1], a[3], torch.rand(G, 40).cuda(), check_overflow="deferred")
 
 
 def test_views_batched_equals_view_by_view():
