@@ -187,7 +187,7 @@ def test_two_hundred_single_pair_forwards_are_identical():
     """Round 5 companion of the batch-of-eight test: every cross-stream hand-off of the forward (six streams, per-chain HIP graphs, the
     panoptic device stage behind Mask2Former, the eager tail) exercised 200 times at B = 1 @256^2: label maps, segmentation, both logit
     tensors and all six Gaussian fields bit-identical to the first forward.  (The round-4 stale read showed up at B = 8 only; with plain
-    loads in the argmax kernel -- SIU3R_PP_DBG=1 -- round 5 measured 0 differing forwards in 222 at B = 8, and a torch-free repro of the
+    loads in the argmax kernel -- SIU3R_PP_DBG=1 -- round 5 measured 0 differing forwards in 372 at B = 8, and a torch-free repro of the
     writer -> reader hand-off beside seven streams of graph replays, tools/probes/stale_probe.hip, 0 stale reads in 2400 iterations.)"""
     from golden_utils import default_K, fixture_images
     from siu3r_amd.model import SIU3RModel
