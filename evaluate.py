@@ -104,14 +104,20 @@ def main():
         my_scenes += write_batch(out_dir, batch, res)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    E.accumulate_dir(out_dir, acc, scenes=my_scenes)  # this rank's shard, read back from the files it wrote (PNG truncation included)
-    gathered = D.all_gather_stats(torch.from_numpy(acc.to_vector()), device=dev)  # the path's single collective
+    map_recs = {}
+    E.accumulate_dir(out_dir, acc, scenes=my_scenes, map_records=map_recs)  # this rank's shard, read back from the files it wrote (PNG truncation included)
+    gathered = D.all_gather_stats(torch.from_numpy(acc.to_vector()), device=dev)  # the additive statistics: ONE fixed-length all-gather
+    all_recs = D.all_gather_objects(map_recs)  # mean average precision is not additive: per-scene match records (a few KB each)
     if rank == 0:
         result = M.MetricAccumulator.from_vectors(gathered.numpy()).compute()
+        for mode in ("context", "target"):
+            recs = [r for per_rank in all_recs for r in per_rank.get(mode, [])]
+            if recs:
+                result[f"{mode}_map"] = M.mean_average_precision(recs)  # (evaluator.py:388-399: the whole torchmetrics result dict)
         with open(out_dir / "results.json", "w") as fh:
             json.dump(result, fh, indent=4)
         print(json.dumps({"pairs": n, "world": world, "pairs_per_s_rank0": len(mine) / max(elapsed, 1e-9),
-                          **{k: v for k, v in result.items() if not k.endswith("per_class")}}))
+                          **{k: (v["map"] if k.endswith("_map") else v) for k, v in result.items() if not k.endswith("per_class")}}))
     D.barrier()
 
 

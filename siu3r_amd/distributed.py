@@ -77,3 +77,15 @@ def max_over_ranks(x: float, device=None) -> float:
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
+
+
+def all_gather_objects(obj) -> list:
+    """Variable-length companion of the statistics gather, for the one metric that is not additive (mean average precision: per-scene
+    match records, a few KB per scene): every rank's object, in rank order, on every rank.  Pickled by torch.distributed
+    (`all_gather_object`); a single process returns [obj]."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+

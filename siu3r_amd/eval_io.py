@@ -132,8 +132,11 @@ def load_segmentation_dir(pred_dir: Path, gt_dir: Path):
     return cat(ps), cat(pi), cat(gs), cat(gi)
 
 
-def accumulate_dir(path, acc: Optional[M.MetricAccumulator] = None, scenes: Optional[Sequence[str]] = None, write_scene_scores: bool = True) -> M.MetricAccumulator:
-    """Fold the scene directories under `path` (all, or the named subset: a rank's shard) into additive statistics."""
+def accumulate_dir(path, acc: Optional[M.MetricAccumulator] = None, scenes: Optional[Sequence[str]] = None, write_scene_scores: bool = True,
+                   map_records: Optional[Dict[str, list]] = None) -> M.MetricAccumulator:
+    """Fold the scene directories under `path` (all, or the named subset: a rank's shard) into additive statistics.  map_records: a dict
+    that receives, per mode ("context" / "target"), one COCO match record per scene for the mean average precision (metrics.map_scene_records;
+    not additive: the caller gathers the lists and calls metrics.mean_average_precision on rank 0)."""
     from PIL import Image
 
     acc = acc or M.MetricAccumulator()
@@ -161,13 +164,21 @@ def accumulate_dir(path, acc: Optional[M.MetricAccumulator] = None, scenes: Opti
                     json.dump(scores, fh, indent=4)
         for mode in ("context", "target"):
             if (d / f"{mode}_seg_pred").is_dir() and (d / f"{mode}_seg_gt").is_dir() and any((d / f"{mode}_seg_pred").glob("*.png")):
-                acc.add_segmentation(mode, *load_segmentation_dir(d / f"{mode}_seg_pred", d / f"{mode}_seg_gt"))
+                maps = load_segmentation_dir(d / f"{mode}_seg_pred", d / f"{mode}_seg_gt")
+                acc.add_segmentation(mode, *maps)
+                if map_records is not None:
+                    pj = d / f"{mode}_seg_pred" / "pred.json"  # (evaluator.py:175-180: label and score of a predicted id come from here)
+                    preds = json.load(open(pj)) if pj.exists() else None
+                    map_records.setdefault(mode, []).append(M.map_scene_records(*M.map_scene_inputs(*maps, preds)))
     return acc
 
 
 def evaluate_dir(path, write: bool = True) -> Dict[str, object]:
     """single-process counterpart of Evaluator.evaluate (evaluator.py:240-404): results.json with the BASELINE metric's keys."""
-    res = accumulate_dir(path).compute()
+    recs: Dict[str, list] = {}
+    res = accumulate_dir(path, map_records=recs).compute()
+    for mode, r in recs.items():
+        res[f"{mode}_map"] = M.mean_average_precision(r)
     if write:
         with open(Path(path) / "results.json", "w") as fh:
             json.dump(res, fh, indent=4)

@@ -7,12 +7,16 @@ stuffs = [1, 2] (1-based, :32-37), mean IoU from an intersection/union histogram
 additive over images, so here each rank accumulates a fixed-length fp64 vector and ONE all-gather (siu3r_amd/distributed.py)
 reproduces the single-process result.  Image quality adds SSIM (torchmetrics StructuralSimilarityIndexMeasure defaults, :231-233)
 and depth quality adds AbsRel / RMSE after a least-squares scale + shift fit over the valid ground-truth pixels (:229-236,
-:346-366); all three are per-image values the evaluator averages, i.e. additive too.  Not computed: LPIPS (needs the VGG weights,
-absent offline) and mAP (`context_map` / `target_map`: COCO matching over the whole set, not additive).
+:346-366); all three are per-image values the evaluator averages, i.e. additive too.  `context_map` / `target_map` (torchmetrics
+MeanAveragePrecision(iou_type="segm", class_metrics=True), evaluator.py:93-106, 152-226, 388-399) are NOT additive -- COCO matching sorts
+the detections of the whole set by score -- so they travel as small per-scene match records (`map_scene_records`: what COCOeval.evaluateImg
+keeps: scores, matched / ignored flags per IoU threshold, ground-truth ignore flags) in a second, variable-length gather and are
+accumulated on rank 0 (`mean_average_precision`).  Not computed: LPIPS (needs the VGG weights, absent offline).
 torchmetrics (pinned 1.7.3, uv.lock:3373) is not in this image: PSNR / SSIM / PQ restate its algorithms -- PQ: Kirillov et al. 2019
 as torchmetrics.detection.PanopticQuality(allow_unknown_preds_category=True, return_per_class=True) implements it, per-class order
 = sorted things then sorted stuffs -- and are PARITY-UNPINNED against the library; the tests check them against hand-computed
-cases (void / unknown categories, absent classes, mostly-void segments).  Host-side code (numpy)."""
+cases (void / unknown categories, absent classes, mostly-void segments); mAP restates pycocotools' COCOeval (evaluateImg / accumulate /
+summarize, the backend torchmetrics drives) for masks without crowds, equally unpinned, with hand-computed cases.  Host-side code (numpy)."""
 from __future__ import annotations
 
 from typing import Dict, Iterable, Sequence
@@ -234,7 +238,8 @@ class MetricAccumulator:
         return m
 
     def compute(self) -> Dict[str, object]:
-        """the keys of the reference's results.json (evaluator.py:368-399) except `lpips` and `*_map` (module docstring)."""
+        """the additive keys of the reference's results.json (evaluator.py:368-399); `context_map` / `target_map` are added by the caller from
+        the gathered per-scene records (mean_average_precision); `lpips` is not computed (module docstring)."""
         res: Dict[str, object] = {}
         if self.n_images:
             res["psnr"] = self.sum_psnr / self.n_images
@@ -253,3 +258,141 @@ class MetricAccumulator:
                 iou = np.where(union > 0, inter / np.maximum(union, 1), 0.0)
                 res[f"{k}_ious_per_class"], res[f"{k}_miou"] = iou.tolist(), float(np.mean(iou))
         return res
+
+
+# ---- mean average precision (COCO protocol over instance masks) ---------------------------------------------------------------------
+MAP_IOU_THRS = np.linspace(0.5, 0.95, 10)
+MAP_REC_THRS = np.linspace(0.0, 1.0, 101)
+MAP_MAX_DETS = (1, 10, 100)
+MAP_AREAS = ((0.0, 1e10), (0.0, 32.0 ** 2), (32.0 ** 2, 96.0 ** 2), (96.0 ** 2, 1e10))  # all, small, medium, large (pixels)
+
+
+def map_scene_inputs(pred_sem, pred_ins, gt_sem, gt_ins, pred_json=None, stuffs: Sequence[int] = STUFFS):
+    """The evaluator's preparation of one scene (all views concatenated along H) for MeanAveragePrecision, evaluator.py:152-226:
+    ground truth = every instance id != 0 whose category (first pixel's semantic id) is not a stuff class, label 0-based; detections =
+    every predicted instance id != 0, label / score from pred.json (`label_id - 1`, the MEAN score of the infos sharing the id: fused
+    stuff segments) or, without pred.json, the first pixel's semantic id - 1 and score 1.  (An id without an entry in pred.json makes
+    the reference append a mask without label or score, which torchmetrics then rejects; here such an id is skipped.)
+    Returns (det_masks [D,P] bool, det_labels [D], det_scores [D], gt_masks [G,P] bool, gt_labels [G])."""
+    ps, pi, gs, gi = (np.asarray(a).reshape(-1) for a in (pred_sem, pred_ins, gt_sem, gt_ins))
+    gm, gl = [], []
+    for g in np.unique(gi):
+        if g == 0:
+            continue
+        m = gi == g
+        lab = int(gs[m][0]) - 1
+        if lab + 1 in stuffs:
+            continue
+        gm.append(m)
+        gl.append(lab)
+    dm, dl, dsc = [], [], []
+    for d in np.unique(pi):
+        if d == 0:
+            continue
+        m = pi == d
+        if pred_json is None:
+            dm.append(m); dl.append(int(ps[m][0]) - 1); dsc.append(1.0)
+        else:
+            info = [i for i in pred_json if i["id"] == int(d)]
+            if info:
+                dm.append(m); dl.append(int(info[0]["label_id"]) - 1); dsc.append(float(np.mean([i["score"] for i in info])))
+    P = ps.shape[0]
+    st = lambda l: np.stack(l) if l else np.zeros((0, P), bool)
+    return st(dm), np.asarray(dl, np.int64), np.asarray(dsc, np.float64), st(gm), np.asarray(gl, np.int64)
+
+
+def map_scene_records(det_masks, det_labels, det_scores, gt_masks, gt_labels):
+    """COCOeval.evaluateImg for one image (scene) and every category in it, masks without crowds: per category the detections sorted
+    by score (stable, at most 100), and per area range the [T, D] "matched" and "ignored" flags and the ground truth's ignore flags.
+    Small, picklable: this is what travels to rank 0."""
+    recs = {}
+    for c in sorted(set(det_labels.tolist()) | set(gt_labels.tolist())):
+        d_idx = np.flatnonzero(det_labels == c)
+        g_idx = np.flatnonzero(gt_labels == c)
+        d_idx = d_idx[np.argsort(-det_scores[d_idx], kind="mergesort")][:MAP_MAX_DETS[-1]]
+        dm, gm = det_masks[d_idx], gt_masks[g_idx]
+        d_area, g_area = dm.sum(1).astype(np.float64), gm.sum(1).astype(np.float64)
+        if len(d_idx) and len(g_idx):
+            inter = (dm[:, None, :] & gm[None, :, :]).sum(-1).astype(np.float64)
+            iou = inter / (d_area[:, None] + g_area[None, :] - inter)
+        else:
+            iou = np.zeros((len(d_idx), len(g_idx)))
+        per_area = []
+        for lo, hi in MAP_AREAS:
+            g_ig = (g_area < lo) | (g_area > hi)
+            order = np.argsort(g_ig, kind="mergesort")  # ignored ground truth last
+            g_ig_s, iou_s = g_ig[order], iou[:, order]
+            T, D, G = len(MAP_IOU_THRS), len(d_idx), len(g_idx)
+            gtm, dtm, dt_ig = np.zeros((T, G), bool), np.zeros((T, D), bool), np.zeros((T, D), bool)
+            for ti, t in enumerate(MAP_IOU_THRS):
+                for di in range(D):
+                    best, m = min(t, 1 - 1e-10), -1
+                    for gi_ in range(G):
+                        if gtm[ti, gi_]:
+                            continue
+                        if m > -1 and not g_ig_s[m] and g_ig_s[gi_]:
+                            break  # (a regular match is kept rather than traded for an ignored one)
+                        if iou_s[di, gi_] < best:
+                            continue
+                        best, m = iou_s[di, gi_], gi_
+                    if m == -1:
+                        continue
+                    dt_ig[ti, di], dtm[ti, di], gtm[ti, m] = g_ig_s[m], True, True
+            d_out = (d_area < lo) | (d_area > hi)
+            dt_ig = dt_ig | (~dtm & d_out[None, :])
+            per_area.append(dict(dtm=dtm, dt_ig=dt_ig, g_ig=g_ig_s))
+        recs[int(c)] = dict(scores=det_scores[d_idx], areas=per_area)
+    return recs
+
+
+def mean_average_precision(scene_records: Sequence[dict]) -> Dict[str, object]:
+    """COCOeval.accumulate + summarize over the scenes' records, with torchmetrics MeanAveragePrecision's result keys (class_metrics=True):
+    map, map_50, map_75, map_{small,medium,large}, mar_{1,10,100}, mar_{small,medium,large}, map_per_class, mar_100_per_class, classes.
+    -1 where nothing could be evaluated (no ground truth), as the library reports it."""
+    classes = sorted({c for r in scene_records for c in r})
+    T, R, K, A, Mx = len(MAP_IOU_THRS), len(MAP_REC_THRS), len(classes), len(MAP_AREAS), len(MAP_MAX_DETS)
+    precision, recall = -np.ones((T, R, K, A, Mx)), -np.ones((T, K, A, Mx))
+    for ki, c in enumerate(classes):
+        E = [r[c] for r in scene_records if c in r]
+        for ai in range(A):
+            for mi, md in enumerate(MAP_MAX_DETS):
+                sc = np.concatenate([e["scores"][:md] for e in E]) if E else np.zeros(0)
+                inds = np.argsort(-sc, kind="mergesort")
+                dtm = np.concatenate([e["areas"][ai]["dtm"][:, :md] for e in E], axis=1)[:, inds]
+                dtig = np.concatenate([e["areas"][ai]["dt_ig"][:, :md] for e in E], axis=1)[:, inds]
+                gig = np.concatenate([e["areas"][ai]["g_ig"] for e in E])
+                npig = int(np.count_nonzero(~gig))
+                if npig == 0:
+                    continue
+                tp = np.cumsum(dtm & ~dtig, axis=1).astype(np.float64)
+                fp = np.cumsum(~dtm & ~dtig, axis=1).astype(np.float64)
+                for ti in range(T):
+                    nd = tp.shape[1]
+                    rc = tp[ti] / npig
+                    pr = tp[ti] / (fp[ti] + tp[ti] + np.spacing(1))
+                    recall[ti, ki, ai, mi] = rc[-1] if nd else 0.0
+                    pr = pr.tolist()
+                    for i in range(nd - 1, 0, -1):
+                        if pr[i] > pr[i - 1]:
+                            pr[i - 1] = pr[i]
+                    q = np.zeros(R)
+                    pos = np.searchsorted(rc, MAP_REC_THRS, side="left")
+                    for ri, pi_ in enumerate(pos):
+                        if pi_ < nd:
+                            q[ri] = pr[pi_]
+                    precision[ti, :, ki, ai, mi] = q
+
+    def ap(iou=None, area=0, k=slice(None)):
+        p = precision[:, :, k, area, 2] if iou is None else precision[np.isclose(MAP_IOU_THRS, iou), :, k, area, 2]
+        p = p[p > -1]
+        return float(p.mean()) if p.size else -1.0
+
+    def ar(area=0, md=2, k=slice(None)):
+        r = recall[:, k, area, md]
+        r = r[r > -1]
+        return float(r.mean()) if r.size else -1.0
+
+    return dict(map=ap(), map_50=ap(0.5), map_75=ap(0.75), map_small=ap(area=1), map_medium=ap(area=2), map_large=ap(area=3),
+                mar_1=ar(md=0), mar_10=ar(md=1), mar_100=ar(md=2), mar_small=ar(1), mar_medium=ar(2), mar_large=ar(3),
+                map_per_class=[ap(k=ki) for ki in range(K)], mar_100_per_class=[ar(k=ki) for ki in range(K)], classes=[int(c) for c in classes])
+

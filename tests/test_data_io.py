@@ -129,6 +129,13 @@ def test_eval_files_round_trip(tmp_path):
     b = E.accumulate_dir(tmp_path, scenes=["scene0001_00_context5_15"], write_scene_scores=False)
     both = M.MetricAccumulator.from_vectors(np.stack((a.to_vector(), b.to_vector()))).compute()
     assert abs(both["psnr"] - res["psnr"]) < 1e-12 and abs(both["target_pq"] - res["target_pq"]) < 1e-12
+    # mean average precision (evaluator.py:388-399: the torchmetrics result dict under context_map / target_map): not additive -- the
+    # shards' per-scene match records, concatenated, give the whole directory's value
+    assert {"map", "map_50", "mar_100", "map_per_class", "classes"} <= set(res["target_map"]) and "context_map" in res
+    ra, rb = {}, {}
+    E.accumulate_dir(tmp_path, scenes=["scene0000_00_context0_20"], write_scene_scores=False, map_records=ra)
+    E.accumulate_dir(tmp_path, scenes=["scene0001_00_context5_15"], write_scene_scores=False, map_records=rb)
+    assert M.mean_average_precision(ra["target"] + rb["target"]) == res["target_map"]
 
 
 def test_segment_id_encoding_is_the_references():

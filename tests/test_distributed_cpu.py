@@ -59,8 +59,19 @@ def _metric_worker(rank, world, port, q):
         ps = np.where(rng.random((6, 10)) < 0.3, rng.integers(0, 8, (6, 10)), gs)
         acc.add_segmentation("context", ps, gi, gs, gi)
         acc.add_render(rng.random((4, 4, 3)).astype(np.float32), rng.random((4, 4, 3)).astype(np.float32))
-    gathered = D.all_gather_stats(torch.from_numpy(acc.to_vector()))      # the path's single collective
-    q.put((rank, M.MetricAccumulator.from_vectors(gathered.numpy()).compute()))
+    gathered = D.all_gather_stats(torch.from_numpy(acc.to_vector()))      # the additive statistics: one fixed-length all-gather
+    res = M.MetricAccumulator.from_vectors(gathered.numpy()).compute()
+    # mean average precision is not additive: the scenes' match records travel in a second, variable-length gather
+    recs = []
+    for i in range(rank, 5, world):
+        rng = np.random.default_rng(100 + i)
+        gs = rng.integers(0, 8, (6, 10))
+        gi = rng.integers(0, 3, (6, 10))
+        ps = np.where(rng.random((6, 10)) < 0.3, rng.integers(0, 8, (6, 10)), gs)
+        recs.append((i, M.map_scene_records(*M.map_scene_inputs(ps, gi, gs, gi, None))))
+    every = sorted((t for per_rank in D.all_gather_objects(recs) for t in per_rank), key=lambda t: t[0])
+    res["context_map"] = M.mean_average_precision([r for _, r in every])
+    q.put((rank, res))
     dist.destroy_process_group()
 
 
@@ -84,8 +95,12 @@ def test_metric_vector_gather_world2():
         pr = np.where(rng.random((6, 10)) < 0.3, rng.integers(0, 8, (6, 10)), gs)
         whole.add_segmentation("context", pr, gi, gs, gi)
         whole.add_render(rng.random((4, 4, 3)).astype(np.float32), rng.random((4, 4, 3)).astype(np.float32))
+        map_recs = locals().setdefault("map_recs", [])
+        map_recs.append(M.map_scene_records(*M.map_scene_inputs(pr, gi, gs, gi, None)))
     want = whole.compute()
+    want["context_map"] = M.mean_average_precision(map_recs)
     for _, got in res:
+        assert got["context_map"] == want["context_map"] and got["context_map"]["map"] >= 0
         assert set(got) == set(want)
         assert abs(got["psnr"] - want["psnr"]) < 1e-12 and abs(got["context_pq"] - want["context_pq"]) < 1e-12
         assert np.allclose(got["context_ious_per_class"], want["context_ious_per_class"], atol=1e-12)

@@ -162,3 +162,62 @@ def test_depth_errors_scale_shift():
     assert abs(res["absrel"] - a2) < 1e-15 and abs(res["rmse"] - r2) < 1e-15
     merged = M.MetricAccumulator.from_vectors(np.stack((acc.to_vector(), acc.to_vector())))
     assert abs(merged.compute()["rmse"] - r2) < 1e-12 and merged.n_depth == 2
+
+
+def _boxes(H, W, boxes):
+    """id / category maps from a list of (id, category, y0, y1, x0, x1)"""
+    sem, ins = np.zeros((H, W), int), np.zeros((H, W), int)
+    for i, c, y0, y1, x0, x1 in boxes:
+        sem[y0:y1, x0:x1], ins[y0:y1, x0:x1] = c, i
+    return sem, ins
+
+
+def test_mean_average_precision_hand_cases():
+    """COCO protocol over instance masks (torchmetrics MeanAveragePrecision(iou_type="segm", class_metrics=True), evaluator.py:93-106,
+    152-226, 388-399) on cases worked out by hand: one class, two ground-truth chairs of 50 px each; three detections -- score 0.9 exact on
+    chair 1 (IoU 1), score 0.8 covering 31 of chair 2's 50 px (IoU 0.62), score 0.7 somewhere else (false positive).
+      IoU thresholds 0.5, 0.55, 0.6: TP, TP, FP -> recall [0.5, 1, 1], precision [1, 1, 2/3] -> AP 1
+      thresholds 0.65 .. 0.95:       TP, FP, FP -> recall 0.5 throughout, precision [1, 1/2, 1/3]: 1 at the 51 recall points <= 0.5, 0 at
+                                     the other 50 -> AP 51 / 101
+      map = (3 * 1 + 7 * 51/101) / 10, map_50 = 1, map_75 = 51/101; mar_100 = (3 * 1 + 7 * 0.5) / 10; mar_1 (best detection only) = 0.5"""
+    H, W = 20, 40
+    gs, gi = _boxes(H, W, [(1, 5, 0, 5, 0, 10), (2, 5, 10, 15, 0, 10)])
+    ps, pi = _boxes(H, W, [(1, 5, 0, 5, 0, 10), (3, 5, 15, 20, 30, 40)])
+    ps[10:13, 0:10], pi[10:13, 0:10] = 5, 2   # 30 px of chair 2 ...
+    ps[13, 0], pi[13, 0] = 5, 2               # ... and one more: 31 of 50, nothing outside -> IoU 0.62
+    pred_json = [dict(id=1, label_id=5, score=0.9), dict(id=2, label_id=5, score=0.8), dict(id=3, label_id=5, score=0.7)]
+    inp = M.map_scene_inputs(ps, pi, gs, gi, pred_json)
+    assert inp[0].shape[0] == 3 and inp[3].shape[0] == 2 and inp[1].tolist() == [4, 4, 4] and inp[4].tolist() == [4, 4]
+    r = M.mean_average_precision([M.map_scene_records(*inp)])
+    ap_hi = 51 / 101
+    assert abs(r["map"] - (3 + 7 * ap_hi) / 10) < 1e-9 and abs(r["map_50"] - 1) < 1e-9 and abs(r["map_75"] - ap_hi) < 1e-9
+    assert abs(r["mar_100"] - 0.65) < 1e-12 and abs(r["mar_10"] - 0.65) < 1e-12 and abs(r["mar_1"] - 0.5) < 1e-12
+    assert r["classes"] == [4] and abs(r["map_per_class"][0] - r["map"]) < 1e-12
+    # all four instances have 50 px: "small" (< 32^2); no medium / large ground truth -> -1 there, as the library reports it
+    assert abs(r["map_small"] - r["map"]) < 1e-12 and r["map_medium"] == -1.0 and r["map_large"] == -1.0 and r["mar_large"] == -1.0
+
+
+def test_mean_average_precision_is_not_additive_and_handles_stuff_and_absent_classes():
+    """Two scenes: a confident false positive in a scene WITHOUT ground truth of that class ranks above the other scene's true positive:
+    detections sorted over the whole set -> recall [0, 1], precision [0, 1/2] -> AP 0.5 (per-scene APs would be "undefined" and 1: the
+    metric cannot be accumulated as a sum -- hence the per-scene records and the second gather).  Ground-truth stuff segments are not
+    instances (evaluator.py:160-161) while predicted stuff ids stay detections (class without ground truth: -1, left out of the mean);
+    fused stuff ids take the MEAN score of their infos; without pred.json every detection scores 1."""
+    H, W = 48, 48
+    g1s, g1i = _boxes(H, W, [(1, 1, 0, 48, 0, 8)])                              # scene 1: only wall (stuff): no chair ground truth
+    p1s, p1i = _boxes(H, W, [(101, 1, 0, 48, 0, 8), (2, 5, 10, 20, 10, 20)])    # a wall id (fused) and a confident chair that is not there
+    j1 = [dict(id=101, label_id=1, score=0.6), dict(id=101, label_id=1, score=0.8), dict(id=2, label_id=5, score=0.9)]
+    g2s, g2i = _boxes(H, W, [(1, 5, 0, 40, 0, 40)])                              # scene 2: one chair of 1600 px (medium)
+    p2s, p2i = g2s.copy(), g2i.copy()
+    j2 = [dict(id=1, label_id=5, score=0.8)]
+    i1, i2 = M.map_scene_inputs(p1s, p1i, g1s, g1i, j1), M.map_scene_inputs(p2s, p2i, g2s, g2i, j2)
+    assert i1[3].shape[0] == 0 and sorted(i1[1].tolist()) == [0, 4] and abs(float(i1[2][i1[1] == 0][0]) - 0.7) < 1e-12
+    recs = [M.map_scene_records(*i1), M.map_scene_records(*i2)]
+    r = M.mean_average_precision(recs)
+    assert r["classes"] == [0, 4] and r["map_per_class"][0] == -1.0 and abs(r["map_per_class"][1] - 0.5) < 1e-9
+    # area ranges: the false positive is 100 px -- outside "medium" and unmatched, hence ignored there: the medium range sees only the true positive
+    assert abs(r["map"] - 0.5) < 1e-9 and abs(r["map_medium"] - 1.0) < 1e-9 and r["map_small"] == -1.0 and abs(r["mar_100"] - 1.0) < 1e-12
+    assert abs(M.mean_average_precision(recs[1:])["map"] - 1.0) < 1e-9        # the second scene alone: AP 1
+    no_json = M.map_scene_inputs(p2s, p2i, g2s, g2i, None)
+    assert no_json[2].tolist() == [1.0] and no_json[1].tolist() == [4]
+
