@@ -169,7 +169,7 @@ def accumulate_dir(path, acc: Optional[M.MetricAccumulator] = None, scenes: Opti
                 if map_records is not None:
                     pj = d / f"{mode}_seg_pred" / "pred.json"  # (evaluator.py:175-180: label and score of a predicted id come from here)
                     preds = json.load(open(pj)) if pj.exists() else None
-                    map_records.setdefault(mode, []).append(M.map_scene_records(*M.map_scene_inputs(*maps, preds)))
+                    map_records.setdefault(mode, []).append(M.map_scene_records(M.map_scene_inputs(*maps, preds)))
     return acc
 
 

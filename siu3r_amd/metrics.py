@@ -267,56 +267,49 @@ MAP_MAX_DETS = (1, 10, 100)
 MAP_AREAS = ((0.0, 1e10), (0.0, 32.0 ** 2), (32.0 ** 2, 96.0 ** 2), (96.0 ** 2, 1e10))  # all, small, medium, large (pixels)
 
 
-def map_scene_inputs(pred_sem, pred_ins, gt_sem, gt_ins, pred_json=None, stuffs: Sequence[int] = STUFFS):
+def map_scene_inputs(pred_sem, pred_ins, gt_sem, gt_ins, pred_json=None, stuffs: Sequence[int] = STUFFS) -> Dict[str, np.ndarray]:
     """The evaluator's preparation of one scene (all views concatenated along H) for MeanAveragePrecision, evaluator.py:152-226:
     ground truth = every instance id != 0 whose category (first pixel's semantic id) is not a stuff class, label 0-based; detections =
     every predicted instance id != 0, label / score from pred.json (`label_id - 1`, the MEAN score of the infos sharing the id: fused
     stuff segments) or, without pred.json, the first pixel's semantic id - 1 and score 1.  (An id without an entry in pred.json makes
     the reference append a mask without label or score, which torchmetrics then rejects; here such an id is skipped.)
-    Returns (det_masks [D,P] bool, det_labels [D], det_scores [D], gt_masks [G,P] bool, gt_labels [G])."""
+    The masks of an id map are disjoint, so areas and pairwise intersections come from one joint histogram of (predicted id, ground-truth
+    id) instead of D x G mask products.  Returns det_labels / det_scores / det_area [D], gt_labels / gt_area [G], inter [D, G]."""
     ps, pi, gs, gi = (np.asarray(a).reshape(-1) for a in (pred_sem, pred_ins, gt_sem, gt_ins))
-    gm, gl = [], []
-    for g in np.unique(gi):
-        if g == 0:
-            continue
-        m = gi == g
-        lab = int(gs[m][0]) - 1
-        if lab + 1 in stuffs:
-            continue
-        gm.append(m)
-        gl.append(lab)
-    dm, dl, dsc = [], [], []
-    for d in np.unique(pi):
+    g_ids, g_first, g_cnt = np.unique(gi, return_index=True, return_counts=True)
+    d_ids, d_first, d_cnt = np.unique(pi, return_index=True, return_counts=True)
+    g_keep = [k for k, g in enumerate(g_ids) if g != 0 and int(gs[g_first[k]]) not in stuffs]
+    # (the first pixel in scan order is what `gt_semantics[gt_mask][0]` reads; return_index gives exactly that pixel)
+    d_keep, dl, dsc = [], [], []
+    for k, d in enumerate(d_ids):
         if d == 0:
             continue
-        m = pi == d
         if pred_json is None:
-            dm.append(m); dl.append(int(ps[m][0]) - 1); dsc.append(1.0)
+            d_keep.append(k); dl.append(int(ps[d_first[k]]) - 1); dsc.append(1.0)
         else:
             info = [i for i in pred_json if i["id"] == int(d)]
             if info:
-                dm.append(m); dl.append(int(info[0]["label_id"]) - 1); dsc.append(float(np.mean([i["score"] for i in info])))
-    P = ps.shape[0]
-    st = lambda l: np.stack(l) if l else np.zeros((0, P), bool)
-    return st(dm), np.asarray(dl, np.int64), np.asarray(dsc, np.float64), st(gm), np.asarray(gl, np.int64)
+                d_keep.append(k); dl.append(int(info[0]["label_id"]) - 1); dsc.append(float(np.mean([i["score"] for i in info])))
+    joint = np.zeros((len(d_ids), len(g_ids)), np.int64)
+    np.add.at(joint, (np.searchsorted(d_ids, pi), np.searchsorted(g_ids, gi)), 1)
+    return dict(det_labels=np.asarray(dl, np.int64), det_scores=np.asarray(dsc, np.float64), det_area=d_cnt[d_keep].astype(np.float64),
+                gt_labels=np.asarray([int(gs[g_first[k]]) - 1 for k in g_keep], np.int64), gt_area=g_cnt[g_keep].astype(np.float64),
+                inter=joint[np.ix_(d_keep, g_keep)].astype(np.float64))
 
 
-def map_scene_records(det_masks, det_labels, det_scores, gt_masks, gt_labels):
+def map_scene_records(inp: Dict[str, np.ndarray]) -> dict:
     """COCOeval.evaluateImg for one image (scene) and every category in it, masks without crowds: per category the detections sorted
     by score (stable, at most 100), and per area range the [T, D] "matched" and "ignored" flags and the ground truth's ignore flags.
     Small, picklable: this is what travels to rank 0."""
+    det_labels, det_scores, gt_labels = inp["det_labels"], inp["det_scores"], inp["gt_labels"]
     recs = {}
     for c in sorted(set(det_labels.tolist()) | set(gt_labels.tolist())):
         d_idx = np.flatnonzero(det_labels == c)
         g_idx = np.flatnonzero(gt_labels == c)
         d_idx = d_idx[np.argsort(-det_scores[d_idx], kind="mergesort")][:MAP_MAX_DETS[-1]]
-        dm, gm = det_masks[d_idx], gt_masks[g_idx]
-        d_area, g_area = dm.sum(1).astype(np.float64), gm.sum(1).astype(np.float64)
-        if len(d_idx) and len(g_idx):
-            inter = (dm[:, None, :] & gm[None, :, :]).sum(-1).astype(np.float64)
-            iou = inter / (d_area[:, None] + g_area[None, :] - inter)
-        else:
-            iou = np.zeros((len(d_idx), len(g_idx)))
+        d_area, g_area = inp["det_area"][d_idx], inp["gt_area"][g_idx]
+        inter = inp["inter"][np.ix_(d_idx, g_idx)]
+        iou = inter / np.maximum(d_area[:, None] + g_area[None, :] - inter, 1.0)
         per_area = []
         for lo, hi in MAP_AREAS:
             g_ig = (g_area < lo) | (g_area > hi)

@@ -68,7 +68,7 @@ def _metric_worker(rank, world, port, q):
         gs = rng.integers(0, 8, (6, 10))
         gi = rng.integers(0, 3, (6, 10))
         ps = np.where(rng.random((6, 10)) < 0.3, rng.integers(0, 8, (6, 10)), gs)
-        recs.append((i, M.map_scene_records(*M.map_scene_inputs(ps, gi, gs, gi, None))))
+        recs.append((i, M.map_scene_records(M.map_scene_inputs(ps, gi, gs, gi, None))))
     every = sorted((t for per_rank in D.all_gather_objects(recs) for t in per_rank), key=lambda t: t[0])
     res["context_map"] = M.mean_average_precision([r for _, r in every])
     q.put((rank, res))
@@ -96,7 +96,7 @@ def test_metric_vector_gather_world2():
         whole.add_segmentation("context", pr, gi, gs, gi)
         whole.add_render(rng.random((4, 4, 3)).astype(np.float32), rng.random((4, 4, 3)).astype(np.float32))
         map_recs = locals().setdefault("map_recs", [])
-        map_recs.append(M.map_scene_records(*M.map_scene_inputs(pr, gi, gs, gi, None)))
+        map_recs.append(M.map_scene_records(M.map_scene_inputs(pr, gi, gs, gi, None)))
     want = whole.compute()
     want["context_map"] = M.mean_average_precision(map_recs)
     for _, got in res:

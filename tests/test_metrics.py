@@ -187,8 +187,9 @@ def test_mean_average_precision_hand_cases():
     ps[13, 0], pi[13, 0] = 5, 2               # ... and one more: 31 of 50, nothing outside -> IoU 0.62
     pred_json = [dict(id=1, label_id=5, score=0.9), dict(id=2, label_id=5, score=0.8), dict(id=3, label_id=5, score=0.7)]
     inp = M.map_scene_inputs(ps, pi, gs, gi, pred_json)
-    assert inp[0].shape[0] == 3 and inp[3].shape[0] == 2 and inp[1].tolist() == [4, 4, 4] and inp[4].tolist() == [4, 4]
-    r = M.mean_average_precision([M.map_scene_records(*inp)])
+    assert inp["det_labels"].tolist() == [4, 4, 4] and inp["gt_labels"].tolist() == [4, 4] and inp["det_area"].tolist() == [50, 31, 50]
+    assert inp["inter"].tolist() == [[50, 0], [0, 31], [0, 0]]
+    r = M.mean_average_precision([M.map_scene_records(inp)])
     ap_hi = 51 / 101
     assert abs(r["map"] - (3 + 7 * ap_hi) / 10) < 1e-9 and abs(r["map_50"] - 1) < 1e-9 and abs(r["map_75"] - ap_hi) < 1e-9
     assert abs(r["mar_100"] - 0.65) < 1e-12 and abs(r["mar_10"] - 0.65) < 1e-12 and abs(r["mar_1"] - 0.5) < 1e-12
@@ -211,13 +212,13 @@ def test_mean_average_precision_is_not_additive_and_handles_stuff_and_absent_cla
     p2s, p2i = g2s.copy(), g2i.copy()
     j2 = [dict(id=1, label_id=5, score=0.8)]
     i1, i2 = M.map_scene_inputs(p1s, p1i, g1s, g1i, j1), M.map_scene_inputs(p2s, p2i, g2s, g2i, j2)
-    assert i1[3].shape[0] == 0 and sorted(i1[1].tolist()) == [0, 4] and abs(float(i1[2][i1[1] == 0][0]) - 0.7) < 1e-12
-    recs = [M.map_scene_records(*i1), M.map_scene_records(*i2)]
+    assert i1["gt_labels"].shape[0] == 0 and sorted(i1["det_labels"].tolist()) == [0, 4] and abs(float(i1["det_scores"][i1["det_labels"] == 0][0]) - 0.7) < 1e-12
+    recs = [M.map_scene_records(i1), M.map_scene_records(i2)]
     r = M.mean_average_precision(recs)
     assert r["classes"] == [0, 4] and r["map_per_class"][0] == -1.0 and abs(r["map_per_class"][1] - 0.5) < 1e-9
     # area ranges: the false positive is 100 px -- outside "medium" and unmatched, hence ignored there: the medium range sees only the true positive
     assert abs(r["map"] - 0.5) < 1e-9 and abs(r["map_medium"] - 1.0) < 1e-9 and r["map_small"] == -1.0 and abs(r["mar_100"] - 1.0) < 1e-12
     assert abs(M.mean_average_precision(recs[1:])["map"] - 1.0) < 1e-9        # the second scene alone: AP 1
     no_json = M.map_scene_inputs(p2s, p2i, g2s, g2i, None)
-    assert no_json[2].tolist() == [1.0] and no_json[1].tolist() == [4]
+    assert no_json["det_scores"].tolist() == [1.0] and no_json["det_labels"].tolist() == [4]
 
