@@ -1149,7 +1149,7 @@ __global__ void blend_bg_kernel(int64_t n, int C, float* colors, const float* al
 // untouched.  What the matrix pipe buys here is not FLOPs (its f32 rate is the packed-VALU rate) but OPERAND DELIVERY: the feature row
 // enters as the B operand, one LDS read of 32 consecutive floats per block and entry pair, instead of being broadcast to 64 lanes value by
 // value (one LDS serves four SIMDs: the 32 broadcast reads per entry and chunk are what bound the 32-channel kernel), and the VALU is
-// free for the next pair's alpha / transmittance step.  lane = pixel of the wave's 8 x 8 quadrant for that step (once per entry, for all
+// left to the alpha / transmittance steps (the SIMD's other wave runs its own while this wave's MFMAs execute).  lane = pixel of the wave's 8 x 8 quadrant for that step (once per entry, for all
 // channels; lists cut to the quadrant by the extent test at load time); v_permlane32_swap turns two weight registers into the two A
 // operands (pixels 0-31 / 32-63 of the quadrant, k = entry).  Accumulators: 2 x NP blocks of 16 registers.
 #ifndef SIU3R_FEAT_DBG
