@@ -327,6 +327,14 @@ int siu3r_raster_tile_lists(const siu3r_raster_cam* cams_host, int V, const int3
 int siu3r_raster_composite_feat(const siu3r_raster_cam* cams_host, int V, const void* cams_dev, int64_t G, const int32_t* tile_start,
                                 const int32_t* ids, int64_t cap_d, const float* rec, const float* feats, int channels, float* out,
                                 float* out_alpha, void* stream);
+/* the same with a WORKSPACE (device, ws_bytes >= siu3r_raster_composite_feat_ws_bytes(width, height, V, cap_d), 4-byte aligned): for
+ * channels >= 32 the tile lists are first cut per 8 x 8 pixel quadrant (a conservative footprint test; 16 * cap_d + 16 * T bytes per view)
+ * and every wave of the composite walks its own quadrant's list with wave-private LDS staging -- no workgroup barrier in the kernel.
+ * Identical bits to siu3r_raster_composite_feat (which it falls back to without a workspace; SIU3R_FEAT_FORM=4 / 1 force the other forms). */
+int64_t siu3r_raster_composite_feat_ws_bytes(int width, int height, int V, int64_t cap_d);
+int siu3r_raster_composite_feat_ws(const siu3r_raster_cam* cams_host, int V, const void* cams_dev, int64_t G, const int32_t* tile_start,
+                                   const int32_t* ids, int64_t cap_d, const float* rec, const float* feats, int channels, float* out,
+                                   float* out_alpha, void* ws, int64_t ws_bytes, void* stream);
 /* x *= s in place (the reference rescales the scene x10 in place, src/models/gaussian_renderer.py:43-46) */
 int siu3r_scale_inplace(float* x, int64_t n, float s, void* stream);
 /* query-class-logit lifting (reference src/pipeline.py:137-193): rendered [V,H,W,q*C] -> sem_id, ins_id int64 [V,H,W];

@@ -118,6 +118,8 @@ SIGNATURES = {
     "siu3r_raster_composite_rgb": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _P],
     "siu3r_raster_tile_lists": [C.POINTER(RasterCam), _I, _P, _P, _L, _P, _P, _P, _L, _P, _P],
     "siu3r_raster_composite_feat": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _L, _P, _P, _I, _P, _P, _P],
+    "siu3r_raster_composite_feat_ws_bytes": [_I, _I, _I, _L],
+    "siu3r_raster_composite_feat_ws": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _L, _P, _P, _I, _P, _P, _P, _L, _P],
     "siu3r_scale_inplace": [_P, _L, _F, _P],
     "siu3r_quat_scale_to_cov6": [_P, _P, _P, _L, _P],
     "siu3r_sh_eval": [_P, _P, _P, _I, _I, _P, _L, _P],
@@ -129,7 +131,7 @@ SIGNATURES = {
     "siu3r_panoptic_stage1": [_P] * 20 + [_I] * 9 + [_F, _F, _F, C.c_uint32, _P],
     "siu3r_panoptic_qcl": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPES = {"siu3r_last_error": C.c_char_p}
+_RESTYPES = {"siu3r_last_error": C.c_char_p, "siu3r_raster_composite_feat_ws_bytes": C.c_int64}
 
 _lib = None
 

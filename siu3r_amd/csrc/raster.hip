@@ -1364,6 +1364,223 @@ __global__ __launch_bounds__(256, 2) void composite_feat4_kernel(const Cam* __re
   if (inside && blockIdx.y == 0 && out_alpha) out_alpha[(size_t)v * hw + (size_t)py * width + px] = O;
 }
 
+// ---- K3 composite, matrix-core form without a workgroup barrier: per-QUADRANT lists + wave-private staging --------------------------------
+// composite_feat4_kernel stages a tile's list in batches that its four waves share, so every batch ends in a barrier that the wave with
+// the longest quadrant list decides (counters: 54 % of the wave cycles parked).  Here the lists are cut per 8 x 8 quadrant FIRST
+// (ql_build_kernel: the same conservative extent test, order kept; 4 B per (quadrant, entry) pair), and each wave of the composite walks
+// its own quadrant's list with its own LDS ring (3 chunks of 8 entries: records + feature rows by LDS-DMA two chunks ahead, ids three
+// ahead): no __syncthreads in the kernel, a saturated quadrant's wave simply leaves, pairs are formed over the whole quadrant list
+// (one padded half pair per quadrant instead of one per batch).  Same arithmetic: per pixel the fmaf chain over the list in order.
+//
+// quadrant lists: region of tile t = qids[4 * tile_start[t], 4 * tile_start[t + 1]); quadrant q uses the q-th quarter of it, qcnt[t][q] entries.
+__global__ __launch_bounds__(256) void ql_build_kernel(const Cam* __restrict__ cams, Geo geo, const int32_t* __restrict__ tile_start,
+                                                       const int32_t* __restrict__ ids, int64_t cap_d, const float* __restrict__ rec, int64_t G,
+                                                       int32_t* __restrict__ qids, int32_t* __restrict__ qcnt) {
+  __shared__ int s_w[4][4];  // [quadrant][wave] survivors of the current slice
+  const int v = blockIdx.y, tile = blockIdx.x, tx = tile % geo.gw, ty = tile / geo.gw;
+  const Cam& c = cams[v];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int32_t* ts = tile_start + (int64_t)v * (geo.T + 2);
+  const int32_t* idp = ids + (int64_t)v * cap_d;
+  const int beg = ts[tile], end = ts[tile + 1], len = end - beg;
+  int32_t* qo = qids + (int64_t)v * 4 * cap_d + 4 * (int64_t)beg;
+  const float alpha_min = c.alpha_min;
+  const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
+  int run[4] = {0, 0, 0, 0};
+  for (int b = beg; b < end; b += 256) {
+    const int i = b + threadIdx.x;
+    unsigned bits = 0;
+    int id = 0;
+    if (i < end) {
+      id = idp[i];
+      const float4* rp = (const float4*)(rec + 12 * ((int64_t)v * G + id));
+      const float4 r0 = rp[0], r1 = rp[1];
+      // alpha >= alpha_min  <=>  sigma <= L = ln(opacity / alpha_min); on that ellipse |dx| <= sqrt(2 L c / det), |dy| <= sqrt(2 L a / det).
+      // Conservative (margins far above the rounding of exp_det and of this bound): an entry dropped here can never pass the per-pixel
+      // test of the composite, an entry kept needlessly only costs time.
+      const float det = r1.x * r1.z - r1.y * r1.y;
+      const float L = logf(r1.w / alpha_min) * 1.001f + 0.001f;
+      bits = 0xfu;
+      if (L < 0.f) bits = 0;
+      else if (det > 0.f && L == L) {
+        const float ex = sqrtf(2.0f * L * r1.z / det) + 0.01f, ey = sqrtf(2.0f * L * r1.x / det) + 0.01f;
+        if (ex == ex && ey == ey) {
+          const bool xl = r0.x - ex <= tx0 + 7.5f && r0.x + ex >= tx0 + 0.5f, xr = r0.x - ex <= tx0 + 15.5f && r0.x + ex >= tx0 + 8.5f;
+          const bool yt = r0.y - ey <= ty0 + 7.5f && r0.y + ey >= ty0 + 0.5f, yb = r0.y - ey <= ty0 + 15.5f && r0.y + ey >= ty0 + 8.5f;
+          bits = (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
+        }
+      }
+    }
+    unsigned long long m[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      m[q] = __ballot((bits >> q) & 1u);
+      if (lane == 0) s_w[q][wave] = __popcll(m[q]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int off = run[q] + __popcll(m[q] & ((1ull << lane) - 1ull));
+      for (int w = 0; w < wave; ++w) off += s_w[q][w];
+      if ((bits >> q) & 1u) qo[(int64_t)q * len + off] = id;
+      run[q] += s_w[q][0] + s_w[q][1] + s_w[q][2] + s_w[q][3];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) qcnt[((int64_t)v * geo.T + tile) * 4 + threadIdx.x] = run[threadIdx.x];
+}
+
+template <int NP>
+__global__ __launch_bounds__(256, 2) void composite_feat5_kernel(const Cam* __restrict__ cams, Geo geo, const int32_t* __restrict__ tile_start,
+                                                                 const int32_t* __restrict__ qids, const int32_t* __restrict__ qcnt, int64_t cap_d,
+                                                                 const float* __restrict__ rec, const float* __restrict__ feats, int channels, int64_t G,
+                                                                 int V, float* __restrict__ out, float* __restrict__ out_alpha) {
+  constexpr int CH = 8, R = 3, CW = 32 * NP;  // entries per chunk, chunks in the ring, channels per workgroup
+  __shared__ __attribute__((aligned(16))) float s_rec[4][R][CH][8];  // per wave: {mx, my, depth, 0 | conic a, b, c, opacity}
+  __shared__ __attribute__((aligned(16))) float s_f[4][R][CH][CW];   // per wave: feature rows (column cw = channel window of block cw / 32)
+  const int v = blockIdx.z;
+  const Cam& c = cams[v];
+  const int tile = blockIdx.x, tx = tile % geo.gw, ty = tile / geo.gw;
+  const int ch0 = min((int)blockIdx.y * CW, max(0, channels - CW)), nch = min(CW, channels - ch0);
+  const int last_off = nch - 32;  // (shifted last window, as in composite_feat4_kernel)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
+  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+  const int width = c.width, height = c.height;
+  const bool inside = px < width && py < height;
+  const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
+  const int32_t* ts = tile_start + (int64_t)v * (geo.T + 2);
+  const int beg = ts[tile], len = ts[tile + 1] - beg;
+  const int n = __builtin_amdgcn_readfirstlane(qcnt[((int64_t)v * geo.T + tile) * 4 + wave]);
+  const int32_t* ql = qids + (int64_t)v * 4 * cap_d + 4 * (int64_t)beg + (int64_t)wave * len;
+  const float alpha_min = c.alpha_min, alpha_max = c.alpha_max, t_min = c.t_min;
+  float T = 1.0f, O = 0.f;
+  f32x16 acc[2][NP];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int nb = 0; nb < NP; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][nb][r] = 0.f;
+  bool done = !inside;
+  const __amdgpu_buffer_rsrc_t r_rec = __builtin_amdgcn_make_buffer_rsrc((void*)rec, (short)0, (int)((int64_t)V * G * 48), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_feat = __builtin_amdgcn_make_buffer_rsrc((void*)feats, (short)0, (int)((int64_t)G * channels * 4), 0x00020000);
+  const unsigned vg48 = (unsigned)((int64_t)v * G * 48);
+  const int nchunks = (n + CH - 1) / CH;
+
+  // ids of chunk k: lane l < CH holds the id of list entry k * CH + l (0 beyond the list: a valid row whose weights are forced to zero)
+  auto load_ids = [&](int k) -> int { return (lane < CH && k * CH + lane < n) ? ql[k * CH + lane] : 0; };
+  // DMAs of chunk k (ids in `idv`): records = 16 pieces (lane = 2 * entry + half, lanes 0..15 only), feature rows = 8 * (CW / 4) pieces =
+  // NP full wave instructions (piece p = entry * (CW / 4) + 16-byte column)
+  auto issue = [&](int idv, int buf) {
+    const int idr = __shfl(idv, lane >> 1);
+    if (lane < 2 * CH)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rec, (lds_ptr_t)&s_rec[wave][buf][0][0], 16, vg48 + (unsigned)idr * 48u + (unsigned)(lane & 1) * 16u, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int p = k * 64 + lane;
+      const int j = p / (CW / 4), cw = (p - j * (CW / 4)) * 4;
+      const int co = (cw >> 5) == NP - 1 ? last_off + (cw & 31) : cw;
+      const unsigned off = ((unsigned)__shfl(idv, j) * (unsigned)channels + (unsigned)(ch0 + co)) * 4u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_feat, (lds_ptr_t)((char*)&s_f[wave][buf][0][0] + k * 1024), 16, off, 0, 0, 0);
+    }
+  };
+
+  const bool lo = lane < 32;
+  auto other_half = [&](float x) {  // the value lane ^ 32 holds (single-operand v_permlane32_swap: right whichever registers are picked)
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, lo ? sw[1] : sw[0]);
+  };
+
+  // prologue: chunks 0 and 1 on their way, ids of chunk 2 in a register
+  int idv_next = 0;  // ids of the chunk whose DMAs are issued next
+  if (nchunks > 0) {
+    int i0 = load_ids(0), i1 = load_ids(1);
+    idv_next = load_ids(2);
+    issue(i0, 0);
+    if (nchunks > 1) issue(i1, 1);
+  }
+  for (int k = 0; k < nchunks; ++k) {
+    // chunk k's DMAs (issued two iterations ago) and the ids of chunk k + 2 have landed; chunk k + 1's NP + 1 DMAs may still be in flight
+    if (k + 1 < nchunks) {
+      if (NP + 1 == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (NP + 1 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (NP + 1 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (NP + 1 == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (NP + 1 == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (__ballot(!done) == 0ull) break;  // the quadrant is saturated
+    const int buf = k % R;
+    if (k + 2 < nchunks) {
+      const int idv = idv_next;
+      idv_next = load_ids(k + 3);
+      issue(idv, (k + 2) % R);
+    }
+    const float (*rb)[8] = s_rec[wave][buf];
+    const float (*fb)[CW] = s_f[wave][buf];
+#pragma unroll
+    for (int pr = 0; pr < CH / 2; ++pr) {
+      float w[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = 2 * pr + e;
+        float wv = 0.f;
+        if (!done && k * CH + j < n) {
+          const float dx = rb[j][0] - pxf, dy = rb[j][1] - pyf;
+          const float4 co = *(const float4*)&rb[j][4];
+          const float sigma = conic_sigma(co.x, co.y, co.z, dx, dy);
+          if (sigma >= 0.0f) {
+            const float a = fminf(alpha_max, co.w * exp_det(-sigma));
+            if (a >= alpha_min) {
+              const float nT = __builtin_fmaf(-T, a, T);
+              if (nT <= t_min) {
+                done = true;
+              } else {
+                wv = a * T;
+                O += wv;
+                T = nT;
+              }
+            }
+          }
+        }
+        w[e] = wv;
+      }
+      if (__ballot(w[0] != 0.f || w[1] != 0.f) == 0ull) continue;
+      const float w1_other = other_half(w[1]), w0_other = other_half(w[0]);
+      const float a_lo = lo ? w[0] : w1_other, a_hi = lo ? w0_other : w[1];
+      const float* frow = &fb[2 * pr + (lo ? 0 : 1)][lane & 31];
+      float b[NP];
+#pragma unroll
+      for (int nb = 0; nb < NP; ++nb) b[nb] = frow[32 * nb];
+#pragma unroll
+      for (int nb = 0; nb < NP; ++nb) {
+        acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, b[nb], acc[0][nb], 0, 0, 0);
+        acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, b[nb], acc[1][nb], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (an early exit leaves DMAs in flight: they must land before the LDS is released)
+  // C/D layout: column (channel) = lane & 31, row (pixel of the 32-pixel block) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const size_t hw = (size_t)width * height;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int ox = qx0 + (p & 7), oy = qy0 + (p >> 3);
+      if (ox < width && oy < height) {
+        float* o = out + ((size_t)v * hw + (size_t)oy * width + ox) * channels + ch0 + (lane & 31);
+#pragma unroll
+        for (int nb = 0; nb < NP; ++nb) o[nb == NP - 1 ? last_off : 32 * nb] = acc[a][nb][r];
+      }
+    }
+  if (inside && blockIdx.y == 0 && out_alpha) out_alpha[(size_t)v * hw + (size_t)py * width + px] = O;
+}
+
 // ---- C ABI -------------------------------------------------------------------------------------------------------
 extern "C" int siu3r_raster_geometry(int width, int height, int64_t G, int32_t* out8) {
   SIU3R_CHECK(out8 && width > 0 && height > 0 && G >= 0, "raster_geometry: bad arguments");
@@ -1566,6 +1783,47 @@ extern "C" int siu3r_raster_composite_feat(const siu3r_raster_cam* cams_host, in
 #undef SIU3R_F4
   }
   SIU3R_LAUNCH_CHECK("siu3r_raster_composite_feat");
+  return 0;
+}
+
+extern "C" int64_t siu3r_raster_composite_feat_ws_bytes(int width, int height, int V, int64_t cap_d) {
+  const Geo geo = make_geo(width, height);
+  return (int64_t)V * (16 * cap_d + 16 * (int64_t)geo.T);
+}
+
+extern "C" int siu3r_raster_composite_feat_ws(const siu3r_raster_cam* cams_host, int V, const void* cams_dev, int64_t G, const int32_t* tile_start,
+                                              const int32_t* ids, int64_t cap_d, const float* rec, const float* feats, int channels, float* out,
+                                              float* out_alpha, void* ws, int64_t ws_bytes, void* stream) {
+  if (int rc = check_views(cams_host, V, "raster_composite_feat_ws")) return rc;
+  SIU3R_CHECK(cams_dev && tile_start && ids && rec && feats && out && channels > 0, "raster_composite_feat_ws: bad arguments");
+  const Geo geo = make_geo(cams_host[0].width, cams_host[0].height);
+  const char* form_env = getenv("SIU3R_FEAT_FORM");  // 1 = 32-channel kernel, 4 = matrix cores with shared batches, default 5 = per-quadrant lists
+  const int form = form_env ? atoi(form_env) : 5;
+  const bool fits32 = (int64_t)V * G * 48 < (1ll << 31) * 2 - 64 && (int64_t)G * channels * 4 < (1ll << 31) * 2 - 64 && (((uintptr_t)feats) & 3) == 0;
+  const int64_t need = (int64_t)V * (16 * cap_d + 16 * (int64_t)geo.T);
+  if (form != 5 || channels < 32 || !fits32 || !ws || ws_bytes < need || (((uintptr_t)ws) & 3))
+    return siu3r_raster_composite_feat(cams_host, V, cams_dev, G, tile_start, ids, cap_d, rec, feats, channels, out, out_alpha, stream);
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* qids = (int32_t*)ws;
+  int32_t* qcnt = qids + (int64_t)V * 4 * cap_d;
+  hipLaunchKernelGGL(ql_build_kernel, dim3(geo.T, V), dim3(256), 0, s, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, rec, G, qids, qcnt);
+  const char* np_env = getenv("SIU3R_FEAT_NP");  // (A/B: blocks per chunk)
+  const int np_max = np_env ? max(1, min(6, atoi(np_env))) : 6;
+  const int np = channels >= 32 * np_max ? np_max : (channels + 31) / 32;
+  const int nchunk = (channels + 32 * np - 1) / (32 * np);
+  SIU3R_CHECK(nchunk <= 65535 && V <= 65535, "raster_composite_feat_ws: too many channel chunks / views");
+  const dim3 grid(geo.T, nchunk, V);
+#define SIU3R_F5(N) hipLaunchKernelGGL(composite_feat5_kernel<N>, grid, dim3(256), 0, s, (const Cam*)cams_dev, geo, tile_start, qids, qcnt, cap_d, rec, feats, channels, G, V, out, out_alpha)
+  switch (np) {
+    case 1: SIU3R_F5(1); break;
+    case 2: SIU3R_F5(2); break;
+    case 3: SIU3R_F5(3); break;
+    case 4: SIU3R_F5(4); break;
+    case 5: SIU3R_F5(5); break;
+    default: SIU3R_F5(6); break;
+  }
+#undef SIU3R_F5
+  SIU3R_LAUNCH_CHECK("siu3r_raster_composite_feat_ws");
   return 0;
 }
 

@@ -345,8 +345,13 @@ def rasterize_views_k3(cams: Sequence[RasterCam], means, cov6, opacities, feats,
         st["cap_d_hint"] = int(pair_capacity) if pair_capacity else default_pair_capacity(G)
         out = torch.empty((V, H, W, Cc), dtype=torch.float32, device=dev)
         alpha = torch.empty((V, H, W), dtype=torch.float32, device=dev)
-        check(_lib.lib().siu3r_raster_composite_feat(st["cams"], V, _p(st["cams_dev"]), G, _p(st["tile_start_all"]), _p(st["ids_all"]), st["cap_d"],
-                                                     _p(st["rec"]), _p(feats), Cc, _p(out), _p(alpha), _stream()))
+        lib = _lib.lib()
+        tstart, ids_all, cap_d = st["tile_start_all"], st["ids_all"], st["cap_d"]
+        # workspace of the per-quadrant lists (C >= 32: every wave of the composite walks its own 8 x 8 quadrant's list)
+        ws = torch.empty((int(lib.siu3r_raster_composite_feat_ws_bytes(W, H, V, cap_d)) // 4,), dtype=torch.int32, device=dev) if Cc >= 32 else None
+        st["feat_ws"] = ws
+        check(lib.siu3r_raster_composite_feat_ws(st["cams"], V, _p(st["cams_dev"]), G, _p(tstart), _p(ids_all), cap_d, _p(st["rec"]), _p(feats), Cc,
+                                                 _p(out), _p(alpha), _p(ws), 0 if ws is None else ws.numel() * 4, _stream()))
         return dict(colors=out, alphas=alpha, radii=st["radii"], state=st)
 
     return _with_retry(run, entry_capacity, check_overflow)

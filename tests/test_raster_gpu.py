@@ -88,7 +88,7 @@ def test_k3_channels(channels):
     assert err <= 2e-6 and erra <= 2e-6
 
 
-FORMS = ("4",)
+FORMS = ("4", "5")
 
 
 @pytest.mark.parametrize("channels", [168, 3 * 64 + 8, 130, 105, 63, 32, 21])

@@ -35,15 +35,16 @@ def ev_ms(fn, reps=5):
 for C in chans:
     feats = torch.randn(means.shape[0], C, generator=torch.Generator().manual_seed(5)).to(dev)
     outs = {}
-    for form in ("1", "4"):
+    for form in ("1", "4", "5"):
         os.environ["SIU3R_FEAT_FORM"] = form
         run = lambda: raster.rasterize_views_k3(cams, m10, c100, opac, feats)
         o = run()
         st = o["state"]
         ms_call = ev_ms(run) / nv
         out = torch.empty_like(o["colors"]); al = torch.empty_like(o["alphas"])
-        comp = lambda: _lib.check(_lib.lib().siu3r_raster_composite_feat(st["cams"], nv, _p(st["cams_dev"]), means.shape[0], _p(st["tile_start_all"]), _p(st["ids_all"]),
-                                                                         st["cap_d"], _p(st["rec"]), _p(feats), C, _p(out), _p(al), _stream()))
+        ws = st["feat_ws"]
+        comp = lambda: _lib.check(_lib.lib().siu3r_raster_composite_feat_ws(st["cams"], nv, _p(st["cams_dev"]), means.shape[0], _p(st["tile_start_all"]), _p(st["ids_all"]),
+                                                                            st["cap_d"], _p(st["rec"]), _p(feats), C, _p(out), _p(al), _p(ws), 0 if ws is None else ws.numel() * 4, _stream()))
         ms_comp = ev_ms(comp, 10) / nv
         if os.environ.get("MB_FEAT_COUNTERS"):  # probe build (-DSIU3R_FEAT_DBG=3): the kernel leaves counters in the first alphas of view 0
             al.zero_(); comp(); torch.cuda.synchronize()
@@ -55,4 +56,4 @@ for C in chans:
         outs[form] = o["colors"]
         print(f"C={C:4d} form {form}: call {ms_call:.3f} ms/frame ({b / ms_call / 1e6:.0f} GB/s alg. = {b / ms_call / 1e6 / 8000:.3f} of 8 TB/s), composite kernel {ms_comp:.3f} ms/frame; "
               f"D/view {sum(Dp) / nv:.0f}", flush=True)
-    print(f"        forms bit-identical: {torch.equal(outs['1'], outs['4'])}")
+    print(f"        forms bit-identical: {torch.equal(outs['1'], outs['4']) and torch.equal(outs['1'], outs['5'])}")
