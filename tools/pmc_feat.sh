@@ -11,7 +11,7 @@ if not fs:
     print("no csv", open(sys.argv[1] + ".err").read()[-400:]); sys.exit()
 acc = {}
 for r in csv.DictReader(open(fs[0])):
-    if "composite_feat" not in r["Kernel_Name"]: continue
+    if "composite_feat" not in r["Kernel_Name"] and "ql_build" not in r["Kernel_Name"]: continue
     k = (r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])
     a = acc.setdefault(k, [0.0, 0]); a[0] += float(r["Counter_Value"]); a[1] += 1
 for (n, c), (v, k) in sorted(acc.items()):
