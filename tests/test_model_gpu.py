@@ -569,10 +569,11 @@ def test_parity_sweep(case):
         assert max(forced.values()) <= 1e-3, forced
         # ... and WHICH pixels flipped, and on which side: the nine masks the HIP run attended through against the fp32 oracle's, with an
         # fp64 run of the oracle as the referee (the thresholded quantity sigmoid(mask) - 0.5 is within fp32 rounding of zero there)
-        model.record_attn_masks = rec = []
+        model.mask2former.record_attn_masks = rec = []
         with torch.no_grad():
             model(img.cuda(), K.cuda())
-        model.record_attn_masks = None
+        model.mask2former.record_attn_masks = None
+        assert len(rec) == len(ref["attn_masks"]) == 9
         sd64 = {k_: (v_.double() if v_.is_floating_point() else v_) for k_, v_ in sd.items()}
         with torch.no_grad():
             ref64 = (O.model_forward if V == 2 else O.model_forward_multi)(sd64, img.double(), K.double(), keep_intermediates=False)
