@@ -1556,10 +1556,14 @@ __global__ __launch_bounds__(256, 2) void composite_feat5_kernel(const Cam* __re
       float b[NP];
 #pragma unroll
       for (int nb = 0; nb < NP; ++nb) b[nb] = frow[32 * nb];
+      // a 32-pixel block (the quadrant's upper / lower four rows) that neither entry of the pair reaches keeps its sums: its MFMAs are skipped
+      if (__ballot(a_lo != 0.f) != 0ull) {
 #pragma unroll
-      for (int nb = 0; nb < NP; ++nb) {
-        acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, b[nb], acc[0][nb], 0, 0, 0);
-        acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, b[nb], acc[1][nb], 0, 0, 0);
+        for (int nb = 0; nb < NP; ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, b[nb], acc[0][nb], 0, 0, 0);
+      }
+      if (__ballot(a_hi != 0.f) != 0ull) {
+#pragma unroll
+        for (int nb = 0; nb < NP; ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, b[nb], acc[1][nb], 0, 0, 0);
       }
     }
   }
