@@ -65,6 +65,15 @@ __device__ __forceinline__ float conic_sigma(float ca, float cb, float cc, float
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// a c - b^2 of a conic without the cancellation of the naive form (Kahan's 2 x 2 determinant: the rounding error of b * b is recovered with
+// one fma; accurate to a few ulps of the RESULT).  The footprint tests that cut lists per quadrant divide by it: for a long thin splat
+// seen diagonally a c and b^2 agree to 1e-6 and the naive difference is off by tens of per cent -- a box computed too small would drop
+// entries that blend.
+__device__ __forceinline__ float conic_det(float a, float b, float c) {
+  const float w = b * b;
+  const float e = __builtin_fmaf(-b, b, w);
+  return __builtin_fmaf(a, c, -w) + e;
+}
 
 // ---- frame geometry shared by host and device ------------------------------------------------------------------
 constexpr int NB_MAX = 1024;            // coarse bins per view (LDS: 40 B per bin in bin_scatter_kernel)
@@ -758,7 +767,7 @@ __global__ __launch_bounds__(256) void composite_rgb_kernel(const Cam* __restric
           // Padded by 1 % + 0.05 px (the exact per-pixel tests below still decide; the box only has to be conservative)
           int mk = 15;  // NaN / degenerate conics: no culling, the exact tests decide
           const float L = __logf(r1.w / alpha_min);
-          const float det = r1.x * r1.z - r1.y * r1.y;
+          const float det = conic_det(r1.x, r1.y, r1.z);
           if (L <= 0.f) {
             mk = 0;  // opacity below alpha_min: alpha = min(alpha_max, opacity * exp(<= 0)) can never reach it
           } else if (det > 0.f) {
@@ -1273,7 +1282,7 @@ __global__ __launch_bounds__(256, 2) void composite_feat4_kernel(const Cam* __re
         // alpha >= alpha_min  <=>  sigma <= L = ln(opacity / alpha_min); on that ellipse |dx| <= sqrt(2 L c / det), |dy| <= sqrt(2 L a / det).
         // Conservative (margins far above the rounding of exp_det and of this bound): an entry dropped here can never pass the
         // per-pixel test, an entry kept needlessly only costs time.
-        const float det = r1.x * r1.z - r1.y * r1.y;
+        const float det = conic_det(r1.x, r1.y, r1.z);
         const float L = logf(r1.w / alpha_min) * 1.001f + 0.001f;
         reach = !(L < 0.f);
         if (reach && det > 0.f && L == L) {
@@ -1398,7 +1407,7 @@ __global__ __launch_bounds__(256) void ql_build_kernel(const Cam* __restrict__ c
       // alpha >= alpha_min  <=>  sigma <= L = ln(opacity / alpha_min); on that ellipse |dx| <= sqrt(2 L c / det), |dy| <= sqrt(2 L a / det).
       // Conservative (margins far above the rounding of exp_det and of this bound): an entry dropped here can never pass the per-pixel
       // test of the composite, an entry kept needlessly only costs time.
-      const float det = r1.x * r1.z - r1.y * r1.y;
+      const float det = conic_det(r1.x, r1.y, r1.z);
       const float L = logf(r1.w / alpha_min) * 1.001f + 0.001f;
       bits = 0xfu;
       if (L < 0.f) bits = 0;

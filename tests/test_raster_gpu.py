@@ -126,6 +126,33 @@ def test_k3_all_channel_composite_equals_the_chunked_one(channels, monkeypatch):
         assert float(np.abs(new["alphas"][v].cpu().numpy() - ref["alpha"]).max()) <= 2e-6
 
 
+def test_k3_all_channel_composite_on_needles(monkeypatch):
+    """Long thin splats seen diagonally (1 : 3000 axes, hundreds of pixels long): the conic's a c and b^2 agree to many digits, and the
+    per-quadrant footprint test divides by their difference.  The quadrant lists must still keep every entry that blends: maps
+    bit-identical to the kernel that walks the uncut tile lists."""
+    from siu3r_amd import raster
+
+    H, W, G, channels = 152, 200, 1500, 64
+    g = torch.Generator().manual_seed(23)
+    means, cov, opac, _ = random_scene(G, seed=29, depth=(1.0, 6.0))
+    ang = torch.rand(G, generator=g) * 3.14159265
+    d = torch.stack((torch.cos(ang), torch.sin(ang), 0.2 * torch.randn(G, generator=g)), -1)
+    d = d / d.norm(dim=-1, keepdim=True)
+    long = 0.3 + 2.7 * torch.rand(G, generator=g)
+    cov = (long * long)[:, None, None] * d[:, :, None] * d[:, None, :] + 1e-6 * torch.eye(3)
+    opac = 0.3 + 0.69 * torch.rand(G, generator=g)
+    feats = torch.randn(G, channels, generator=g)
+    cams = [_k3_cam(H, W, seed=s_, near=0.5, far=9.0) for s_ in (2, 4)]
+    args = (cams, means.cuda(), raster.cov6_from_cov3x3(cov).cuda(), opac.cuda(), feats.cuda())
+    monkeypatch.setenv("SIU3R_FEAT_FORM", "1")
+    old = raster.rasterize_views_k3(*args)
+    assert float(old["alphas"].mean()) > 0.5 and int(old["state"]["D"]) > 20 * G
+    for form in FORMS:
+        monkeypatch.setenv("SIU3R_FEAT_FORM", form)
+        new = raster.rasterize_views_k3(*args)
+        assert torch.equal(new["colors"], old["colors"]) and torch.equal(new["alphas"], old["alphas"]), (form, float((new["colors"] - old["colors"]).abs().max()))
+
+
 def test_empty_and_all_culled():
     from siu3r_amd import raster
 
