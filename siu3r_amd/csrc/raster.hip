@@ -1765,7 +1765,7 @@ extern "C" int siu3r_raster_composite_feat(const siu3r_raster_cam* cams_host, in
                                            const int32_t* ids, int64_t cap_d, const float* rec, const float* feats, int channels, float* out,
                                            float* out_alpha, void* stream) {
   if (int rc = check_views(cams_host, V, "raster_composite_feat")) return rc;
-  SIU3R_CHECK(cams_dev && tile_start && ids && rec && feats && out && channels > 0, "raster_composite_feat: bad arguments");
+  SIU3R_CHECK(cams_dev && tile_start && (ids || cap_d == 0 || G == 0) && ((rec && feats) || G == 0) && out && channels > 0, "raster_composite_feat: bad arguments");  // (an empty scene has empty lists: nothing is dereferenced)
   const Geo geo = make_geo(cams_host[0].width, cams_host[0].height);
   const char* form_env = getenv("SIU3R_FEAT_FORM");  // 1 = the 32-channel kernel everywhere (A/B; the tests cross-check the two forms bit for bit)
   const int form = form_env ? atoi(form_env) : 4;
@@ -1808,7 +1808,7 @@ extern "C" int siu3r_raster_composite_feat_ws(const siu3r_raster_cam* cams_host,
                                               const int32_t* ids, int64_t cap_d, const float* rec, const float* feats, int channels, float* out,
                                               float* out_alpha, void* ws, int64_t ws_bytes, void* stream) {
   if (int rc = check_views(cams_host, V, "raster_composite_feat_ws")) return rc;
-  SIU3R_CHECK(cams_dev && tile_start && ids && rec && feats && out && channels > 0, "raster_composite_feat_ws: bad arguments");
+  SIU3R_CHECK(cams_dev && tile_start && (ids || cap_d == 0 || G == 0) && ((rec && feats) || G == 0) && out && channels > 0, "raster_composite_feat_ws: bad arguments");
   const Geo geo = make_geo(cams_host[0].width, cams_host[0].height);
   const char* form_env = getenv("SIU3R_FEAT_FORM");  // 1 = 32-channel kernel, 4 = matrix cores with shared batches, default 5 = per-quadrant lists
   const int form = form_env ? atoi(form_env) : 5;

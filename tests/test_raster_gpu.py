@@ -153,6 +153,25 @@ def test_k3_all_channel_composite_on_needles(monkeypatch):
         assert torch.equal(new["colors"], old["colors"]) and torch.equal(new["alphas"], old["alphas"]), (form, float((new["colors"] - old["colors"]).abs().max()))
 
 
+def test_k3_all_channel_composite_empty_and_culled():
+    """The N-channel path with nothing to blend: no Gaussians at all, and all of them behind the camera -- zero maps, zero alphas, no
+    list entries, from the quadrant-list kernels like from the 32-channel one."""
+    from siu3r_amd import raster
+
+    H, W, C = 72, 104, 168
+    cams = [_k3_cam(H, W, seed=s_, near=0.5, far=9.0) for s_ in (1, 3)]
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    out = raster.rasterize_views_k3(cams, z(0, 3), z(0, 6), z(0), z(0, C))
+    assert out["colors"].shape == (2, H, W, C) and float(out["colors"].abs().max()) == 0.0 and float(out["alphas"].abs().max()) == 0.0
+    means, cov, opac, _ = random_scene(300, seed=5)
+    far_away = means.clone()
+    far_away[:, 2] = 1e6   # beyond every camera's far plane, whichever way it looks
+    feats = torch.randn(300, C, generator=torch.Generator().manual_seed(2))
+    out = raster.rasterize_views_k3(cams, far_away.cuda(), raster.cov6_from_cov3x3(cov).cuda(), opac.cuda(), feats.cuda())
+    assert int(out["state"]["D"]) == 0 and float(out["colors"].abs().max()) == 0.0 and float(out["alphas"].abs().max()) == 0.0
+    assert int(out["radii"].abs().sum()) == 0
+
+
 def test_empty_and_all_culled():
     from siu3r_amd import raster
 
