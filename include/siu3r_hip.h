@@ -323,7 +323,8 @@ int siu3r_raster_tile_lists(const siu3r_raster_cam* cams_host, int V, const int3
                             int32_t* tile_count, int32_t* tile_start, int32_t* ids, int64_t cap_d, uint64_t* stats, void* stream);
 /* stage 4 (mode 1): feats [G,channels] -> out [V,H,W,channels] (+ alphas [V,H,W]) over the tile lists.  channels >= 32 (arrays below 4 GiB): all
  * channels in one pass per 192-channel chunk, the blend as rank-2 v_mfma_f32_32x32x2_f32 updates, records and feature rows staged by LDS-DMA;
- * otherwise 32 channels per pass (the two forms give identical bits; SIU3R_FEAT_FORM=1 forces the second).  Feature values must be finite. */
+ * otherwise 32 channels per pass (the two forms give identical bits; SIU3R_FEAT_FORM=1 forces the second).  Feature values must be finite.
+ * An empty scene (G == 0; then rec / feats / ids may be null) renders zero maps. */
 int siu3r_raster_composite_feat(const siu3r_raster_cam* cams_host, int V, const void* cams_dev, int64_t G, const int32_t* tile_start,
                                 const int32_t* ids, int64_t cap_d, const float* rec, const float* feats, int channels, float* out,
                                 float* out_alpha, void* stream);
