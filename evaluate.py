@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="pairs per forward (configs[2]: 8)")
     ap.add_argument("--limit", type=int, default=0, help="evaluate only the first N pairs")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16", "bf16x3"])
+    ap.add_argument("--lpips_weights", default=None, help="file holding the LPIPS (VGG16 + lin) tensors; default: the `lpips.*` keys of --model_path when it "
+                    "is a Pipeline checkpoint (src/pipeline.py:35).  Without either, results.json has no `lpips` key")
     a = ap.parse_args()
 
     from siu3r_amd import distributed as D, eval_io as E, metrics as M, scannet
@@ -90,6 +92,16 @@ def main():
     size = (data.image_size, data.image_size)
     model = SIU3RModel(load_weights(a.model_path), image_size=size, precision=a.precision, device=dev)
     renderer = SplattingCUDA()
+    lp = None
+    lp_file = a.lpips_weights or a.model_path
+    if lp_file:
+        from siu3r_amd.checkpoint import load_lpips_weights
+        from siu3r_amd.lpips import LPIPS
+
+        lw = load_lpips_weights(lp_file)
+        if lw is None and a.lpips_weights:
+            raise RuntimeError(f"{a.lpips_weights}: no LPIPS network found")
+        lp = LPIPS(lw, device=dev) if lw is not None else None
     out_dir = Path(a.output_path)
     out_dir.mkdir(parents=True, exist_ok=True)
     acc, my_scenes, t0 = M.MetricAccumulator(), [], time.perf_counter()
@@ -105,7 +117,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     map_recs = {}
-    E.accumulate_dir(out_dir, acc, scenes=my_scenes, map_records=map_recs)  # this rank's shard, read back from the files it wrote (PNG truncation included)
+    E.accumulate_dir(out_dir, acc, scenes=my_scenes, map_records=map_recs, lpips=lp)  # this rank's shard, read back from the files it wrote (PNG truncation included)
     gathered = D.all_gather_stats(torch.from_numpy(acc.to_vector()), device=dev)  # the additive statistics: ONE fixed-length all-gather
     all_recs = D.all_gather_objects(map_recs)  # mean average precision is not additive: per-scene match records (a few KB each)
     if rank == 0:

@@ -26,7 +26,7 @@ extern "C" {
 #define SIU3R_F64 3
 
 const char* siu3r_last_error(void);
-#define SIU3R_ABI_VERSION 7 /* 7: device-side poses for the gsplat seam (siu3r_raster_project_dp, siu3r_sh_eval_dp, siu3r_blend_background_dp), precomputed K2 colours (sh_degree < 0), all-channel list composite; 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok), siu3r_attn_params.kv_bxor / kv_x3, siu3r_gemm_params.c_x3_col0; 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
+#define SIU3R_ABI_VERSION 8 /* 8: LPIPS (siu3r_maxpool2x2s2, siu3r_lpips_layer); 7: device-side poses for the gsplat seam (siu3r_raster_project_dp, siu3r_sh_eval_dp, siu3r_blend_background_dp), precomputed K2 colours (sh_degree < 0), all-channel list composite; 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok), siu3r_attn_params.kv_bxor / kv_x3, siu3r_gemm_params.c_x3_col0; 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
 int siu3r_abi_version(void);
 
 /* ---- seam 1: curope.rope_2d(tokens, positions, base, fwd)
@@ -221,6 +221,11 @@ int siu3r_affine_add_strided(const void* x, int x_dtype, const void* addend, int
                              int64_t x_batch_stride, int64_t addend_batch_stride, void* stream);
 /* 3x3 stride-2 pad-1 max pool, NHWC (vit_adapter.py:226) */
 int siu3r_maxpool3x3s2(const void* x, void* y, int dtype, int N, int IH, int IW, int C, void* stream);
+/* 2x2 stride-2 max pool (floor), NHWC: the pooling of the VGG16 feature stack under the evaluator's LPIPS (evaluator.py:55-57, 263) */
+int siu3r_maxpool2x2s2(const void* x, void* y, int dtype, int N, int IH, int IW, int C, void* stream);
+/* one feature tap of LPIPS (torchmetrics LearnedPerceptualImagePatchSimilarity("vgg"); third-party, absent from the reference tree):
+ * dist[p] = sum_c w[c] * (f0[p][c] / sqrt(eps + |f0[p]|^2) - f1[p][c] / sqrt(eps + |f1[p]|^2))^2 for f0, f1 [npix, C] fp32, w [C] */
+int siu3r_lpips_layer(const float* f0, const float* f1, const float* w, float* dist, int64_t npix, int C, float eps, void* stream);
 /* depth-wise 3x3 + bias + GELU over the 3 token scales of the adapter ConvFFN (vit_adapter.py:16-59) */
 int siu3r_dwconv3x3_gelu(const void* x, void* y, int dtype, const float* w9c, const float* bias, int B, int H,
                          int W, int C, void* stream);

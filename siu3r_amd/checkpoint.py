@@ -188,3 +188,16 @@ def load_siu3r_state_dict(path, strict: bool = False, verbose: bool = True) -> D
     if strict and (missing or unexpected):
         raise RuntimeError(f"{path}: missing keys {missing[:8]}..., unexpected keys {unexpected[:8]}...")
     return sd
+
+
+def load_lpips_weights(path) -> Optional[Dict[str, torch.Tensor]]:
+    """The LPIPS (VGG16 + lin layers) tensors of a checkpoint file, or None when it holds none.  A Pipeline checkpoint carries them under
+    `lpips.` (src/pipeline.py:35: the metric is a sub-module of the LightningModule); a state dict of the metric alone or of the `lpips`
+    package's network is accepted too (siu3r_amd.lpips.weights_from_state_dict matches the key tails)."""
+    from .lpips import weights_from_state_dict
+
+    ckpt = read_checkpoint_file(path)
+    sd = ckpt.get("state_dict", ckpt) if isinstance(ckpt, dict) else ckpt
+    if not isinstance(sd, dict):
+        return None
+    return weights_from_state_dict({k: v for k, v in sd.items() if isinstance(v, torch.Tensor)})

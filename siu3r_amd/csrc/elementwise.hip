@@ -268,6 +268,62 @@ __global__ void maxpool_kernel(const void* x, void* y, int dtype, int N, int IH,
   store4(y, dtype, idx * 4, m);
 }
 
+// ================================ max-pool 2x2 s2 (NHWC, floor) ==================================
+// VGG16's pooling (the LPIPS feature stack, torchmetrics functional/image/lpips.py: torchvision vgg16().features indices 4, 9, 16, 23)
+__global__ void maxpool2x2_kernel(const void* x, void* y, int dtype, int N, int IH, int IW, int OH, int OW, int C) {
+  const int C4 = C >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * OH * OW * C4) return;
+  const int c = (int)(idx % C4) * 4;
+  int64_t r = idx / C4;
+  const int ox = (int)(r % OW);
+  r /= OW;
+  const int oy = (int)(r % OH);
+  const int n = (int)(r / OH);
+  const int64_t base = (((int64_t)n * IH + 2 * oy) * IW + 2 * ox) * C + c;
+  const f32x4v a = load4(x, dtype, base), b = load4(x, dtype, base + C), d = load4(x, dtype, base + (int64_t)IW * C),
+               e = load4(x, dtype, base + (int64_t)IW * C + C);
+  f32x4v m;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) m.v[j] = fmaxf(fmaxf(a.v[j], b.v[j]), fmaxf(d.v[j], e.v[j]));
+  store4(y, dtype, idx * 4, m);
+}
+
+// ================================ LPIPS layer distance ===========================================
+// One feature tap of the perceptual distance (torchmetrics _LPIPS.forward): per pixel, both feature vectors are scaled to unit length
+// (x / sqrt(eps + sum_c x^2)), the squared difference is weighted by the learned non-negative 1x1 "lin" weights and summed over the
+// channels.  f0, f1 [npix, C] fp32 channel-last, w [C]; dist [npix] (the caller averages over the pixels and adds the five taps).
+// One wave per pixel, two passes over its 2 x C values (the second hits L1 / L2).
+__global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restrict__ f0, const float* __restrict__ f1, const float* __restrict__ w,
+                                                          float* __restrict__ dist, int64_t npix, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= npix) return;
+  const float* a = f0 + pix * C;
+  const float* b = f1 + pix * C;
+  float s0 = 0.f, s1 = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    const float4 x = *(const float4*)(a + c), y = *(const float4*)(b + c);
+    s0 += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+    s1 += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    s0 += __shfl_xor(s0, o);
+    s1 += __shfl_xor(s1, o);
+  }
+  const float n0 = sqrtf(eps + s0), n1 = sqrtf(eps + s1);
+  float acc = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    const float4 x = *(const float4*)(a + c), y = *(const float4*)(b + c), ww = *(const float4*)(w + c);
+    const float d0 = x.x / n0 - y.x / n1, d1 = x.y / n0 - y.y / n1, d2 = x.z / n0 - y.z / n1, d3 = x.w / n0 - y.w / n1;
+    acc += ww.x * (d0 * d0) + ww.y * (d1 * d1) + ww.z * (d2 * d2) + ww.w * (d3 * d3);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) dist[pix] = acc;
+}
+
 // ================================ depth-wise 3x3 + bias + GELU over 3 token scales =============
 // tokens [B, 21n, C]: [0,16n) is a (2H x 2W) map, [16n,20n) (H x W), [20n,21n) (H/2 x W/2)
 __global__ void dwconv_gelu_kernel(const void* x, void* y, int dtype, const float* w9c, const float* bias, int B,
@@ -696,6 +752,22 @@ extern "C" int siu3r_maxpool3x3s2(const void* x, void* y, int dtype, int N, int 
   const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
   hipLaunchKernelGGL(maxpool_kernel, grid1d((int64_t)N * OH * OW * (C / 4)), dim3(256), 0, (hipStream_t)stream, x, y, dtype, N, IH, IW, OH, OW, C);
   SIU3R_LAUNCH_CHECK("siu3r_maxpool3x3s2");
+  return 0;
+}
+
+extern "C" int siu3r_maxpool2x2s2(const void* x, void* y, int dtype, int N, int IH, int IW, int C, void* stream) {
+  SIU3R_CHECK(x && y && C % 4 == 0 && IH >= 2 && IW >= 2, "maxpool2x2s2: bad arguments");
+  const int OH = IH / 2, OW = IW / 2;
+  hipLaunchKernelGGL(maxpool2x2_kernel, grid1d((int64_t)N * OH * OW * (C / 4)), dim3(256), 0, (hipStream_t)stream, x, y, dtype, N, IH, IW, OH, OW, C);
+  SIU3R_LAUNCH_CHECK("siu3r_maxpool2x2s2");
+  return 0;
+}
+
+extern "C" int siu3r_lpips_layer(const float* f0, const float* f1, const float* w, float* dist, int64_t npix, int C, float eps, void* stream) {
+  SIU3R_CHECK(npix == 0 || (f0 && f1 && w && dist), "lpips_layer: null pointer");
+  SIU3R_CHECK(C > 0 && C % 4 == 0 && (((uintptr_t)f0 | (uintptr_t)f1 | (uintptr_t)w) & 15) == 0, "lpips_layer: C = %d must be a multiple of 4, pointers 16-byte aligned", C);
+  if (npix > 0) hipLaunchKernelGGL(lpips_layer_kernel, dim3((unsigned)cdiv64(npix, 4)), dim3(256), 0, (hipStream_t)stream, f0, f1, w, dist, npix, C, eps);
+  SIU3R_LAUNCH_CHECK("siu3r_lpips_layer");
   return 0;
 }
 

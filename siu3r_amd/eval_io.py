@@ -7,7 +7,7 @@ reads back (src/evaluator.py:108-150, 240-404):
         depth/<scene>_<tid>.png, depth_gt/...   int32 millimetres (`(depth * 1000).astype(int32)`, :309-310, mode "I")
         {context,target}_seg_pred/<scene>_pred<vid>.png + pred.json    segment id = 1000 * semantic + instance as R + 256 G + 65536 B
         {context,target}_seg_gt/<scene>_gt<vid>.png                    same encoding, instance = 1 + index in the sorted instance list
-    <save_dir>/results.json                     keys psnr, ssim, absrel, rmse, {context,target}_{pq,pqs_per_class,miou,ious_per_class}
+    <save_dir>/results.json                     keys psnr, ssim, lpips (when LPIPS weights are given), absrel, rmse, {context,target}_{pq,pqs_per_class,miou,ious_per_class}
                                                 (evaluator.py:368-399); per scene render_scores.json / depth_scores.json
 
 so that the reference's tooling can score this build's outputs and vice versa.  The numbers come from siu3r_amd.metrics (additive
@@ -133,10 +133,11 @@ def load_segmentation_dir(pred_dir: Path, gt_dir: Path):
 
 
 def accumulate_dir(path, acc: Optional[M.MetricAccumulator] = None, scenes: Optional[Sequence[str]] = None, write_scene_scores: bool = True,
-                   map_records: Optional[Dict[str, list]] = None) -> M.MetricAccumulator:
+                   map_records: Optional[Dict[str, list]] = None, lpips=None) -> M.MetricAccumulator:
     """Fold the scene directories under `path` (all, or the named subset: a rank's shard) into additive statistics.  map_records: a dict
     that receives, per mode ("context" / "target"), one COCO match record per scene for the mean average precision (metrics.map_scene_records;
-    not additive: the caller gathers the lists and calls metrics.mean_average_precision on rank 0)."""
+    not additive: the caller gathers the lists and calls metrics.mean_average_precision on rank 0).  lpips: a siu3r_amd.lpips.LPIPS (GPU);
+    when given, every rendered image also gets its `lpips` score (evaluator.py:263)."""
     from PIL import Image
 
     acc = acc or M.MetricAccumulator()
@@ -150,7 +151,10 @@ def accumulate_dir(path, acc: Optional[M.MetricAccumulator] = None, scenes: Opti
             scores = []
             for item in sorted((d / "rgb").glob("*.png")):
                 pred, gt = load_image01(item), load_image01(d / "rgb_gt" / item.name)
-                scores.append({"item": item.name, **acc.add_render_u8(pred, gt)})  # the files already hold the truncated uint8 values
+                sc = {"item": item.name, **acc.add_render_u8(pred, gt)}  # the files already hold the truncated uint8 values
+                if lpips is not None and min(pred.shape[:2]) >= 16:
+                    sc.update(acc.add_lpips(float(lpips(pred, gt)[0])))
+                scores.append(sc)
             if write_scene_scores:
                 with open(d / "render_scores.json", "w") as fh:
                     json.dump(scores, fh, indent=4)
@@ -173,10 +177,10 @@ def accumulate_dir(path, acc: Optional[M.MetricAccumulator] = None, scenes: Opti
     return acc
 
 
-def evaluate_dir(path, write: bool = True) -> Dict[str, object]:
+def evaluate_dir(path, write: bool = True, lpips=None) -> Dict[str, object]:
     """single-process counterpart of Evaluator.evaluate (evaluator.py:240-404): results.json with the BASELINE metric's keys."""
     recs: Dict[str, list] = {}
-    res = accumulate_dir(path, map_records=recs).compute()
+    res = accumulate_dir(path, map_records=recs, lpips=lpips).compute()
     for mode, r in recs.items():
         res[f"{mode}_map"] = M.mean_average_precision(r)
     if write:

@@ -11,7 +11,7 @@ and depth quality adds AbsRel / RMSE after a least-squares scale + shift fit ove
 MeanAveragePrecision(iou_type="segm", class_metrics=True), evaluator.py:93-106, 152-226, 388-399) are NOT additive -- COCO matching sorts
 the detections of the whole set by score -- so they travel as small per-scene match records (`map_scene_records`: what COCOeval.evaluateImg
 keeps: scores, matched / ignored flags per IoU threshold, ground-truth ignore flags) in a second, variable-length gather and are
-accumulated on rank 0 (`mean_average_precision`).  Not computed: LPIPS (needs the VGG weights, absent offline).
+accumulated on rank 0 (`mean_average_precision`).  LPIPS: siu3r_amd/lpips.py (GPU; the weights come from the checkpoint, none are shipped), accumulated here as n_lpips / sum_lpips.
 torchmetrics (pinned 1.7.3, uv.lock:3373) is not in this image: PSNR / SSIM / PQ restate its algorithms -- PQ: Kirillov et al. 2019
 as torchmetrics.detection.PanopticQuality(allow_unknown_preds_category=True, return_per_class=True) implements it, per-class order
 = sorted things then sorted stuffs -- and are PARITY-UNPINNED against the library; the tests check them against hand-computed
@@ -180,15 +180,16 @@ def miou_stats(pred_sem, gt_sem, num_classes: int = NUM_CLASSES) -> np.ndarray:
 
 
 class MetricAccumulator:
-    """Additive statistics of one rank.  Vector layout (fp64): [n_images, sum_psnr, n_ssim, sum_ssim, n_depth, sum_absrel, sum_rmse] +
-    context PQ [C,4] + target PQ [C,4] + context mIoU [C,2] + target mIoU [C,2]  ->  7 + 12 C doubles (259 for C = 21: 2 KB per
-    rank in the all-gather)."""
-    HEAD = 7
+    """Additive statistics of one rank.  Vector layout (fp64): [n_images, sum_psnr, n_ssim, sum_ssim, n_depth, sum_absrel, sum_rmse,
+    n_lpips, sum_lpips] + context PQ [C,4] + target PQ [C,4] + context mIoU [C,2] + target mIoU [C,2]  ->  9 + 12 C doubles (261 for
+    C = 21: 2 KB per rank in the all-gather)."""
+    HEAD = 9
 
     def __init__(self, num_classes: int = NUM_CLASSES, things=THINGS, stuffs=STUFFS):
         self.C, self.things, self.stuffs = num_classes, tuple(things), tuple(stuffs)
         self.n_images, self.sum_psnr, self.n_ssim, self.sum_ssim = 0.0, 0.0, 0.0, 0.0
         self.n_depth, self.sum_absrel, self.sum_rmse = 0.0, 0.0, 0.0
+        self.n_lpips, self.sum_lpips = 0.0, 0.0
         self.pq = {k: np.zeros((num_classes, 4)) for k in ("context", "target")}
         self.iou = {k: np.zeros((num_classes, 2)) for k in ("context", "target")}
 
@@ -206,6 +207,12 @@ class MetricAccumulator:
             self.n_ssim += 1
         return sc
 
+    def add_lpips(self, value: float):
+        """one rendered image's LPIPS distance (siu3r_amd.lpips.LPIPS; evaluator.py:263, 268)"""
+        self.sum_lpips += float(value)
+        self.n_lpips += 1
+        return {"lpips": float(value)}
+
     def add_depth(self, depth_m: np.ndarray, depth_gt_m: np.ndarray):
         """one target view's rendered and ground-truth depth in metres (as read back from the millimetre PNGs); views without any
         ground-truth pixel are skipped (the reference would average a NaN)"""
@@ -222,14 +229,14 @@ class MetricAccumulator:
         self.iou[which] += miou_stats(pred_sem, gt_sem, self.C)
 
     def to_vector(self) -> np.ndarray:
-        return np.concatenate(([self.n_images, self.sum_psnr, self.n_ssim, self.sum_ssim, self.n_depth, self.sum_absrel, self.sum_rmse], self.pq["context"].ravel(), self.pq["target"].ravel(),
+        return np.concatenate(([self.n_images, self.sum_psnr, self.n_ssim, self.sum_ssim, self.n_depth, self.sum_absrel, self.sum_rmse, self.n_lpips, self.sum_lpips], self.pq["context"].ravel(), self.pq["target"].ravel(),
                                self.iou["context"].ravel(), self.iou["target"].ravel())).astype(np.float64)
 
     @classmethod
     def from_vectors(cls, vecs: np.ndarray, num_classes: int = NUM_CLASSES, things=THINGS, stuffs=STUFFS) -> "MetricAccumulator":
         v = np.asarray(vecs, np.float64).reshape(-1, cls.HEAD + 12 * num_classes).sum(0)
         m = cls(num_classes, things, stuffs)
-        m.n_images, m.sum_psnr, m.n_ssim, m.sum_ssim, m.n_depth, m.sum_absrel, m.sum_rmse = v[:cls.HEAD]
+        m.n_images, m.sum_psnr, m.n_ssim, m.sum_ssim, m.n_depth, m.sum_absrel, m.sum_rmse, m.n_lpips, m.sum_lpips = v[:cls.HEAD]
         o, C = cls.HEAD, num_classes
         m.pq["context"] = v[o:o + 4 * C].reshape(C, 4); o += 4 * C
         m.pq["target"] = v[o:o + 4 * C].reshape(C, 4); o += 4 * C
@@ -239,12 +246,14 @@ class MetricAccumulator:
 
     def compute(self) -> Dict[str, object]:
         """the additive keys of the reference's results.json (evaluator.py:368-399); `context_map` / `target_map` are added by the caller from
-        the gathered per-scene records (mean_average_precision); `lpips` is not computed (module docstring)."""
+        the gathered per-scene records (mean_average_precision); `lpips` appears when the caller scored images with siu3r_amd.lpips.LPIPS."""
         res: Dict[str, object] = {}
         if self.n_images:
             res["psnr"] = self.sum_psnr / self.n_images
         if self.n_ssim:
             res["ssim"] = self.sum_ssim / self.n_ssim
+        if self.n_lpips:
+            res["lpips"] = self.sum_lpips / self.n_lpips
         if self.n_depth:
             res["absrel"] = self.sum_absrel / self.n_depth
             res["rmse"] = self.sum_rmse / self.n_depth

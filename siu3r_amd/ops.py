@@ -855,6 +855,27 @@ def maxpool3x3s2(x: torch.Tensor):
     return out
 
 
+def maxpool2x2s2(x: torch.Tensor):
+    """NHWC 2 x 2 stride-2 max pool (floor): the pooling of the LPIPS VGG16 stack"""
+    _gpu(x)
+    assert x.is_contiguous()
+    N, IH, IW, Cc = x.shape
+    out = torch.empty((N, IH // 2, IW // 2, Cc), dtype=x.dtype, device=x.device)
+    check(_lib.lib().siu3r_maxpool2x2s2(_p(x), _p(out), _dt(x), N, IH, IW, Cc, _stream()))
+    return out
+
+
+def lpips_layer(f0: torch.Tensor, f1: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    """f0, f1 [..., C] fp32 channel-last feature maps of the two images, w [C] -> per-pixel weighted squared distance of the unit-normalised
+    feature vectors, shape f0.shape[:-1] (siu3r_lpips_layer)."""
+    _gpu(f0, f1, w)
+    assert f0.shape == f1.shape and f0.is_contiguous() and f1.is_contiguous() and w.is_contiguous()
+    assert f0.dtype == f1.dtype == w.dtype == torch.float32 and w.numel() == f0.shape[-1]
+    dist = torch.empty(f0.shape[:-1], dtype=torch.float32, device=f0.device)
+    check(_lib.lib().siu3r_lpips_layer(_p(f0), _p(f1), _p(w), _p(dist), dist.numel(), f0.shape[-1], float(eps), _stream()))
+    return dist
+
+
 def dwconv3x3_gelu(x: torch.Tensor, w9c: torch.Tensor, bias: torch.Tensor, H: int, W: int):
     _gpu(x)
     assert x.is_contiguous()

@@ -30,7 +30,7 @@ D.barrier()
 torch.cuda.synchronize()
 from siu3r_amd.metrics import MetricAccumulator
 acc = MetricAccumulator(num_classes=3)
-vec = torch.as_tensor(acc.to_vector(), dtype=torch.float64)  # the evaluator's per-rank vector (7 + 12 C doubles)
+vec = torch.as_tensor(acc.to_vector(), dtype=torch.float64)  # the evaluator's per-rank vector (9 + 12 C doubles)
 out = [torch.empty_like(vec.to(dev))]
 dist.all_gather(out, vec.to(dev))
 assert torch.equal(out[0].cpu(), vec)

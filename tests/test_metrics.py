@@ -53,7 +53,7 @@ def test_accumulator_is_additive():
         acc.add_segmentation("context", ps2, pi, gs, gi)
         acc.add_segmentation("target", ps, pi, gs, gi)
     merged = M.MetricAccumulator.from_vectors(np.stack((a.to_vector(), b.to_vector())))
-    assert a.to_vector().shape == (7 + 12 * 21,)
+    assert a.to_vector().shape == (9 + 12 * 21,)
     assert merged.compute() == whole.compute()
     assert set(whole.compute()) >= {"psnr", "context_pq", "context_miou", "target_pq", "target_miou"}
 
