@@ -25,11 +25,21 @@ def test_evaluate_driver_on_a_scannet_shaped_tree(tmp_path, precision):
     os.makedirs(data)
     _fake_scannet(str(data))
     out = tmp_path / "val"
+    extra = []
+    if precision == "bf16x3":  # an LPIPS network in a file shaped like the metric's own state dict (seeded stand-in weights: plumbing only)
+        import torch
+
+        from oracle import lpips_oracle as LO
+
+        lp_file = tmp_path / "lpips_state.pt"
+        torch.save({"net." + k.replace("features.", "net.slice1.") if k.startswith("features.") else "net." + k: v for k, v in LO.random_weights(1).items()}, lp_file)
+        extra = ["--lpips_weights", str(lp_file)]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "evaluate.py"), "--data_root", str(data), "--output_path", str(out), "--batch", "2",
-                        "--precision", precision], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--precision", precision, *extra], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["pairs"] == 2 and line["world"] == 1 and np.isfinite(line["psnr"])
+    assert ("lpips" in line) == bool(extra) and (not extra or (np.isfinite(line["lpips"]) and line["lpips"] > 0))
     scenes = sorted(p.name for p in out.iterdir() if p.is_dir())
     assert scenes == ["scene0000_00_context0_20", "scene0001_00_context0_20"]
     d0 = out / scenes[0]
