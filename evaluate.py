@@ -98,7 +98,13 @@ def main():
         from siu3r_amd.checkpoint import load_lpips_weights
         from siu3r_amd.lpips import LPIPS
 
-        lw = load_lpips_weights(lp_file)
+        try:
+            lw = load_lpips_weights(lp_file)
+        except RuntimeError as e:   # an incomplete network: an error when the file was named for it, a note when it is just the model file
+            if a.lpips_weights:
+                raise
+            print(f"evaluate.py: {e}; results.json will have no `lpips` key", file=sys.stderr)
+            lw = None
         if lw is None and a.lpips_weights:
             raise RuntimeError(f"{a.lpips_weights}: no LPIPS network found")
         lp = LPIPS(lw, device=dev) if lw is not None else None

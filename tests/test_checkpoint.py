@@ -65,6 +65,34 @@ def test_lightning_ckpt_loads_without_the_pickled_config_class(tmp_path):
     assert unexpected == [] and len(missing) > 1000 and "backbone.enc_norm.weight" in missing
 
 
+def test_lpips_network_comes_out_of_a_pipeline_checkpoint(tmp_path):
+    """Pipeline keeps its LPIPS metric as a sub-module (src/pipeline.py:35), so a Lightning checkpoint carries the VGG16 + lin tensors under
+    `lpips.net.`: load_lpips_weights finds them through the restricted unpickler; a checkpoint without them gives None, a partial set an error"""
+    from oracle import lpips_oracle as LO
+    from siu3r_amd.lpips import VGG_SLICES
+
+    lw = LO.random_weights(4)
+    state = {"model." + k: v for k, v in _small_sd().items()}
+    for k, sl in enumerate(VGG_SLICES):
+        for i in sl:
+            for q in ("weight", "bias"):
+                state[f"lpips.net.net.slice{k + 1}.{i}.{q}"] = lw[f"features.{i}.{q}"]
+    for k in range(5):
+        state[f"lpips.net.lin{k}.model.1.weight"] = state[f"lpips.net.lins.{k}.model.1.weight"] = lw[f"lin{k}.model.1.weight"]
+    p = tmp_path / "with_lpips.ckpt"
+    torch.save({"state_dict": state, "pytorch-lightning_version": "2.5.0"}, p)
+    got = ck.load_lpips_weights(p)
+    assert torch.equal(got["conv28.weight"], lw["features.28.weight"]) and torch.equal(got["lin4"], lw["lin4.model.1.weight"].reshape(-1))
+    assert not any(k.startswith("lpips") for k in ck.load_siu3r_state_dict(p, verbose=False))
+    q = tmp_path / "model_only.ckpt"
+    torch.save({"state_dict": {k: v for k, v in state.items() if k.startswith("model.")}}, q)
+    assert ck.load_lpips_weights(q) is None
+    r = tmp_path / "partial.ckpt"
+    _write_lightning_ckpt(r, _small_sd())   # (carries one stray lpips tensor)
+    with pytest.raises(RuntimeError, match="incomplete"):
+        ck.load_lpips_weights(r)
+
+
 def test_bare_state_dict_and_model_prefix(tmp_path):
     sd = _small_sd()
     p = tmp_path / "bare.pt"
