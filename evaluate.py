@@ -90,7 +90,12 @@ def main():
     n = min(len(data), a.limit) if a.limit else len(data)
     mine = scannet.shard(n, rank, world)
     size = (data.image_size, data.image_size)
-    model = SIU3RModel(load_weights(a.model_path), image_size=size, precision=a.precision, device=dev)
+    raw = None
+    if a.model_path and Path(a.model_path).exists():
+        from siu3r_amd.checkpoint import read_checkpoint_file
+
+        raw = read_checkpoint_file(a.model_path)  # read ONCE: the model's tensors and (below) the `lpips.*` keys come from the same object
+    model = SIU3RModel(load_weights(a.model_path, ckpt=raw), image_size=size, precision=a.precision, device=dev)
     renderer = SplattingCUDA()
     lp = None
     lp_file = a.lpips_weights or a.model_path
@@ -99,7 +104,7 @@ def main():
         from siu3r_amd.lpips import LPIPS
 
         try:
-            lw = load_lpips_weights(lp_file)
+            lw = load_lpips_weights(lp_file, ckpt=raw if lp_file == a.model_path else None)
         except RuntimeError as e:   # an incomplete network: an error when the file was named for it, a note when it is just the model file
             if a.lpips_weights:
                 raise
@@ -108,6 +113,7 @@ def main():
         if lw is None and a.lpips_weights:
             raise RuntimeError(f"{a.lpips_weights}: no LPIPS network found")
         lp = LPIPS(lw, device=dev) if lw is not None else None
+    del raw
     out_dir = Path(a.output_path)
     out_dir.mkdir(parents=True, exist_ok=True)
     acc, my_scenes, t0 = M.MetricAccumulator(), [], time.perf_counter()
@@ -129,7 +135,7 @@ def main():
     if rank == 0:
         result = M.MetricAccumulator.from_vectors(gathered.numpy()).compute()
         for mode in ("context", "target"):
-            recs = [r for per_rank in all_recs for r in per_rank.get(mode, [])]
+            recs = E.ordered_map_records([t for per_rank in all_recs for t in per_rank.get(mode, [])])  # scene order, not rank order: ties
             if recs:
                 result[f"{mode}_map"] = M.mean_average_precision(recs)  # (evaluator.py:388-399: the whole torchmetrics result dict)
         with open(out_dir / "results.json", "w") as fh:

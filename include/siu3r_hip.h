@@ -26,7 +26,7 @@ extern "C" {
 #define SIU3R_F64 3
 
 const char* siu3r_last_error(void);
-#define SIU3R_ABI_VERSION 8 /* 8: LPIPS (siu3r_maxpool2x2s2, siu3r_lpips_layer); 7: device-side poses for the gsplat seam (siu3r_raster_project_dp, siu3r_sh_eval_dp, siu3r_blend_background_dp), precomputed K2 colours (sh_degree < 0), all-channel list composite; 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok), siu3r_attn_params.kv_bxor / kv_x3, siu3r_gemm_params.c_x3_col0; 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
+#define SIU3R_ABI_VERSION 9 /* 9: siu3r_raster_tune (replaces the SIU3R_FEAT_FORM / SIU3R_FEAT_NP environment switches; the shared-batch matrix-core composite is gone: no workspace = 32-channel kernel); 8: LPIPS (siu3r_maxpool2x2s2, siu3r_lpips_layer); 7: device-side poses for the gsplat seam (siu3r_raster_project_dp, siu3r_sh_eval_dp, siu3r_blend_background_dp), precomputed K2 colours (sh_degree < 0), all-channel list composite; 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok), siu3r_attn_params.kv_bxor / kv_x3, siu3r_gemm_params.c_x3_col0; 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
 int siu3r_abi_version(void);
 
 /* ---- seam 1: curope.rope_2d(tokens, positions, base, fwd)
@@ -326,21 +326,28 @@ int siu3r_raster_composite_rgb(const siu3r_raster_cam* cams_host, int V, const v
  * tile_start i32 [V,T+2] ([0..T] clamped to cap_d, [T+1] = true pair count), ids i32 [V,cap_d] */
 int siu3r_raster_tile_lists(const siu3r_raster_cam* cams_host, int V, const int32_t* bin_start, const void* entries, int64_t cap_e,
                             int32_t* tile_count, int32_t* tile_start, int32_t* ids, int64_t cap_d, uint64_t* stats, void* stream);
-/* stage 4 (mode 1): feats [G,channels] -> out [V,H,W,channels] (+ alphas [V,H,W]) over the tile lists.  channels >= 32 (arrays below 4 GiB): all
- * channels in one pass per 192-channel chunk, the blend as rank-2 v_mfma_f32_32x32x2_f32 updates, records and feature rows staged by LDS-DMA;
- * otherwise 32 channels per pass (the two forms give identical bits; SIU3R_FEAT_FORM=1 forces the second).  Feature values must be finite.
+/* stage 4 (mode 1): feats [G,channels] -> out [V,H,W,channels] (+ alphas [V,H,W]) over the tile lists, 32 channels per pass (alpha and
+ * transmittance re-evaluated per pass).  A pixel only ever sees the feature rows of entries that reach it with alpha >= 1/255.
  * An empty scene (G == 0; then rec / feats / ids may be null) renders zero maps. */
 int siu3r_raster_composite_feat(const siu3r_raster_cam* cams_host, int V, const void* cams_dev, int64_t G, const int32_t* tile_start,
                                 const int32_t* ids, int64_t cap_d, const float* rec, const float* feats, int channels, float* out,
                                 float* out_alpha, void* stream);
 /* the same with a WORKSPACE (device, ws_bytes >= siu3r_raster_composite_feat_ws_bytes(width, height, V, cap_d), 4-byte aligned): for
- * channels >= 32 the tile lists are first cut per 8 x 8 pixel quadrant (a conservative footprint test; 16 * cap_d + 16 * T bytes per view)
- * and every wave of the composite walks its own quadrant's list with wave-private LDS staging -- no workgroup barrier in the kernel.
- * Identical bits to siu3r_raster_composite_feat (which it falls back to without a workspace; SIU3R_FEAT_FORM=4 / 1 force the other forms). */
+ * channels >= 32 (arrays below 4 GiB) the tile lists are first cut per 8 x 8 pixel quadrant (a conservative footprint test; 16 * cap_d +
+ * 16 * T bytes per view) and every wave of the composite walks its own quadrant's list with wave-private LDS staging, all channels in
+ * one pass per 192-channel chunk, the blend as rank-2 v_mfma_f32_32x32x2_f32 updates (exact f32, accumulating in list order) -- no
+ * workgroup barrier in the kernel.  Identical bits to siu3r_raster_composite_feat FOR FINITE FEATURES (which it falls back to without a
+ * workspace, below 32 channels, or after siu3r_raster_tune(0, 1)).  Restriction: every pixel of a quadrant takes part in every entry of
+ * the quadrant's list with weight 0 where the entry does not reach it, and list tails are padded with Gaussian 0's row, so a NON-FINITE
+ * feature value (0 * inf = NaN) in any listed Gaussian -- or in Gaussian 0 -- poisons pixels the 32-channel kernel leaves untouched:
+ * callers that may hold non-finite features select the 32-channel kernel (tests/test_raster_gpu.py pins both behaviours). */
 int64_t siu3r_raster_composite_feat_ws_bytes(int width, int height, int V, int64_t cap_d);
 int siu3r_raster_composite_feat_ws(const siu3r_raster_cam* cams_host, int V, const void* cams_dev, int64_t G, const int32_t* tile_start,
                                    const int32_t* ids, int64_t cap_d, const float* rec, const float* feats, int channels, float* out,
                                    float* out_alpha, void* ws, int64_t ws_bytes, void* stream);
+/* tuning / A-B switches of the rasterizer (not for concurrent use).  key 0: 1 = the 32-channel kernel for every N-channel composite, 0 =
+ * default (matrix-core form where it applies); key 1: accumulator blocks per chunk of the matrix-core form (1 .. 6, default 6) */
+int siu3r_raster_tune(int key, int value);
 /* x *= s in place (the reference rescales the scene x10 in place, src/models/gaussian_renderer.py:43-46) */
 int siu3r_scale_inplace(float* x, int64_t n, float s, void* stream);
 /* query-class-logit lifting (reference src/pipeline.py:137-193): rendered [V,H,W,q*C] -> sem_id, ins_id int64 [V,H,W];

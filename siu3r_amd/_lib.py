@@ -84,7 +84,7 @@ class RasterCam(C.Structure):
 
 # name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/siu3r_hip.h.
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
-ABI_VERSION = 8  # SIU3R_ABI_VERSION of include/siu3r_hip.h these ctypes declarations mirror
+ABI_VERSION = 9  # SIU3R_ABI_VERSION of include/siu3r_hip.h these ctypes declarations mirror
 
 SIGNATURES = {
     "siu3r_last_error": [],
@@ -121,6 +121,7 @@ SIGNATURES = {
     "siu3r_raster_tile_lists": [C.POINTER(RasterCam), _I, _P, _P, _L, _P, _P, _P, _L, _P, _P],
     "siu3r_raster_composite_feat": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _L, _P, _P, _I, _P, _P, _P],
     "siu3r_raster_composite_feat_ws_bytes": [_I, _I, _I, _L],
+    "siu3r_raster_tune": [_I, _I],
     "siu3r_raster_composite_feat_ws": [C.POINTER(RasterCam), _I, _P, _L, _P, _P, _L, _P, _P, _I, _P, _P, _P, _L, _P],
     "siu3r_scale_inplace": [_P, _L, _F, _P],
     "siu3r_quat_scale_to_cov6": [_P, _P, _P, _L, _P],

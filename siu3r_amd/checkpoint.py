@@ -170,10 +170,11 @@ def check_keys(sd: Dict[str, torch.Tensor], expected: Optional[Iterable[str]] = 
     return sorted(exp - have), sorted(have - exp)
 
 
-def load_siu3r_state_dict(path, strict: bool = False, verbose: bool = True) -> Dict[str, torch.Tensor]:
+def load_siu3r_state_dict(path, strict: bool = False, verbose: bool = True, ckpt=None) -> Dict[str, torch.Tensor]:
     """Everything `Pipeline.load_from_checkpoint(path, strict=False).model.state_dict()` would hold, as CPU tensors keyed by the
-    reference's parameter names -- what `SIU3RModel(state_dict, ...)` takes."""
-    sd, kind = extract_state_dict(read_checkpoint_file(path))
+    reference's parameter names -- what `SIU3RModel(state_dict, ...)` takes.  ckpt: the file's content when the caller has already read it
+    (`read_checkpoint_file(path)`: a Lightning checkpoint with optimizer state is multi-GB; evaluate.py also takes its LPIPS tensors from it)."""
+    sd, kind = extract_state_dict(read_checkpoint_file(path) if ckpt is None else ckpt)
     if kind == "release":
         sd = mast3r_to_siu3r(sd)
     else:
@@ -190,13 +191,15 @@ def load_siu3r_state_dict(path, strict: bool = False, verbose: bool = True) -> D
     return sd
 
 
-def load_lpips_weights(path) -> Optional[Dict[str, torch.Tensor]]:
+def load_lpips_weights(path, ckpt=None) -> Optional[Dict[str, torch.Tensor]]:
     """The LPIPS (VGG16 + lin layers) tensors of a checkpoint file, or None when it holds none.  A Pipeline checkpoint carries them under
     `lpips.` (src/pipeline.py:35: the metric is a sub-module of the LightningModule); a state dict of the metric alone or of the `lpips`
-    package's network is accepted too (siu3r_amd.lpips.weights_from_state_dict matches the key tails)."""
+    package's network is accepted too (siu3r_amd.lpips.weights_from_state_dict matches the key tails).  ckpt: the already-read content of
+    `path` (see load_siu3r_state_dict)."""
     from .lpips import weights_from_state_dict
 
-    ckpt = read_checkpoint_file(path)
+    if ckpt is None:
+        ckpt = read_checkpoint_file(path)
     sd = ckpt.get("state_dict", ckpt) if isinstance(ckpt, dict) else ckpt
     if not isinstance(sd, dict):
         return None

@@ -35,14 +35,15 @@ def normalised_intrinsics(fx, fy, cx, cy, views: int, size: int = 256) -> torch.
     return K.repeat(1, views, 1, 1)
 
 
-def load_weights(model_path):
-    """state dict for SIU3RModel: a real checkpoint through siu3r_amd.checkpoint, or (no path) the seeded synthetic weights."""
+def load_weights(model_path, ckpt=None):
+    """state dict for SIU3RModel: a real checkpoint through siu3r_amd.checkpoint (ckpt: its already-read content), or (no path) the
+    seeded synthetic weights."""
     if model_path:
         if not Path(model_path).exists():
             raise FileNotFoundError(f"Model file {model_path} does not exist.")
         from .checkpoint import load_siu3r_state_dict
 
-        return load_siu3r_state_dict(model_path)
+        return load_siu3r_state_dict(model_path, ckpt=ckpt)
     from . import synthetic_weights as OW  # synthetic stand-in weights (plumbing run: no checkpoint is available offline)
 
     print("no --model_path: using seeded synthetic weights (plumbing only)", file=sys.stderr)

@@ -14,7 +14,13 @@ packed=True, absgrad / sparse_grad False, rasterize_mode="classic") and viewer.p
 memory, blockIdx.y = view); covariances are read as stored.  `viewmats` / `Ks` / `backgrounds` stay on the device: the kernels take the
 pose from the tensors (siu3r_raster_project_dp), nothing is copied to the host per call.  Arguments that only steer gsplat's own
 memory layout or its backward pass (`packed`, `sparse_grad`, `absgrad`, `channel_chunk`) do not change the forward result and are
-accepted; arguments that select an algorithm this renderer does not implement are refused by name."""
+accepted; arguments that select an algorithm this renderer does not implement are refused by name.
+
+One extension, `finite_features` (default True).  For C >= 32 feature channels the blend runs on the matrix cores, where every pixel of an
+8 x 8 quadrant takes part in every entry of the quadrant's list (weight 0 where the entry does not reach it; list tails padded with
+Gaussian 0's row): bit-identical to gsplat's per-pixel walk for finite features, but an inf / NaN feature value turns into NaN in pixels
+the Gaussian does not touch (0 * inf).  Callers whose features may be non-finite pass `finite_features=False` and get the 32-channel
+kernel, whose pixels only see the rows that blend into them (tests/test_raster_gpu.py::test_k3_composite_with_a_non_finite_feature_row)."""
 from __future__ import annotations
 
 import torch
@@ -26,7 +32,8 @@ _RESULT_NEUTRAL = ("packed", "sparse_grad", "absgrad", "channel_chunk", "segment
 
 def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height, near_plane=0.01, far_plane=1e10, radius_clip=0.0,
                   eps2d=0.3, sh_degree=None, packed=True, tile_size=16, backgrounds=None, render_mode="RGB", sparse_grad=False, absgrad=False,
-                  rasterize_mode="classic", channel_chunk=32, distributed=False, camera_model="pinhole", covars=None, **other):
+                  rasterize_mode="classic", channel_chunk=32, distributed=False, camera_model="pinhole", covars=None, finite_features=True,
+                  **other):
     other = {k: v for k, v in other.items() if k not in _RESULT_NEUTRAL}
     if other:
         raise TypeError(f"gsplat.rasterization arguments outside the SIU3R call sites: {sorted(other)}")
@@ -59,7 +66,7 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
         if colors.shape[1] == 3:  # three channels travel in the per-Gaussian record: the fused composite, no per-tile lists in HBM
             o = raster.rasterize_views_k3_rgb(cams, means, covars, opacities, colors, pose_dev=pose)
         else:
-            o = raster.rasterize_views_k3(cams, means, covars, opacities, colors, pose_dev=pose)
+            o = raster.rasterize_views_k3(cams, means, covars, opacities, colors, pose_dev=pose, matrix_form=bool(finite_features))
         out, alphas = o["colors"], o["alphas"]
         meta["radii"] = o["radii"]
     else:

@@ -29,6 +29,10 @@
 #include "common.h"
 #include "gemm_epilogue_pp.h"
 
+#ifndef SIU3R_PP_SCHED
+#define SIU3R_PP_SCHED 0  // 0: LDS-DMA pieces issued in the MEM phase; 1: between the MFMAs of the MFMA phase (group 1 one phase further ahead)
+#endif
+
 namespace siu3r_gemm_pp {
 
 constexpr unsigned OOB = 0xffffff00u;
@@ -342,12 +346,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params
   // stage that is free by then: the loop body stays branch-free and the vmcnt counts constant.  (A burst of pieces blocks the issuing
   // wave for ~150 cycles per piece -- the CU takes one 1-KiB piece per ~35 cycles from all of its waves, whatever the piece's shape:
   // tools/probes/dma_probe.hip -- which is why the MEM phase carries nothing else that is slow.)
-  auto issue = [&](int s, int stage) {
+  auto issue_piece = [&](int s, int stage, int k) {  // piece k of the wave's PPW pieces of step s: A pieces first, then W
     const int sg = sbase + (s < ns ? s : ns - 1);
     unsigned char* dstA = smem + stage * STAGE_BYTES + wave * (A_PCS * 1024);
     unsigned char* dstW = smem + stage * STAGE_BYTES + BM * 64 + wave * (W_PCS * 1024);
-#pragma unroll
-    for (int i = 0; i < A_PCS; ++i) {
+    if (k < A_PCS) {
+      const int i = k;
       if (MODE == 0 && APS) {  // (kpad == K: no tail)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(dstA + i * 1024), 16, a_voff[i], (sg >> 1) * 128 + (sg & 1) * 32, 0, 0);
       } else if (MODE == 0) {
@@ -363,12 +367,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params
         const unsigned voff = ok ? a_voff[i] + (unsigned)(((s_ky * iw + s_kx) * cin + s_c0) * ESZ) : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(dstA + i * 1024), 16, voff, 0, 0, 0);
       }
+    } else {
+      const int i = k - A_PCS;
+      const int soffW = X3 ? (sg >> 1) * 128 + (sg & 1) * 32 : sg * 64;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr)(dstW + i * 1024), 16, w_voff[i], soffW, 0, 0);
     }
-    const int soffW = X3 ? (sg >> 1) * 128 + (sg & 1) * 32 : sg * 64;
+    if (k == PPW - 1) {
+      if (MODE == 1 && s + 1 < ns) cursor_advance();
+      if (MODE == 2 && s + 1 < ns) state_advance();
+    }
+  };
+  auto issue = [&](int s, int stage) {
 #pragma unroll
-    for (int i = 0; i < W_PCS; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr)(dstW + i * 1024), 16, w_voff[i], soffW, 0, 0);
-    if (MODE == 1 && s + 1 < ns) cursor_advance();
-    if (MODE == 2 && s + 1 < ns) state_advance();
+    for (int k = 0; k < PPW; ++k) issue_piece(s, stage, k);
   };
 
   f32x16 acc[MI][NJ];
@@ -454,15 +465,42 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params
     if constexpr (YOUNG == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   };
+  // IMF: the pieces are issued BETWEEN the MFMAs of a wave's MFMA phase (its vector-memory issue port is idle there and the matrix pipe
+  // paces the wave anyway), so that a MEM phase is fragment reads only and ends before the partner's MFMA phase does.  Group 0 issues
+  // phase p + PD/SPP during MFMA(p) in I_2p+1 (its ring slot, that of phase p - 1, was last read in I_2p-1); group 1 multiplies in I_2p+2,
+  // where the slot of phase p itself is free (both groups have read it: I_2p, I_2p+1 with lgkmcnt(0) before barrier 2p+2), so it issues
+  // phase p + PD/SPP + 1 -- one phase further ahead, which gives both groups the same (PD/SPP - 1) phases of flight at their wait points
+  // (group 0: end of MFMA(p), group 1: end of MEM(p): both in front of barrier 2p+2, behind which phase p + 1 is first read).
+  constexpr bool IMF = SIU3R_PP_SCHED == 1;
+  const int pd_grp = (IMF && grp == 1) ? PD + SPP : PD;
 #pragma unroll
   for (int s_ = 0; s_ < PD; ++s_) issue(s_, s_);
-  wait_young();
+  if (IMF && grp == 1) {
+#pragma unroll
+    for (int s_ = PD; s_ < PD + SPP; ++s_) issue(s_, s_);
+    static_assert(PD * PPW == 12, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // phase 0 landed, PD steps in flight
+  } else {
+    wait_young();
+  }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one interval behind group 0
   if constexpr ((dbg & 64) != 0) tlast = (unsigned)__builtin_readcyclecounter();
 
-  int st_rd = 0, st_is = PD % NSTAGE;
+  int st_rd = 0, st_is = pd_grp % NSTAGE;
+  // (IMF) piece k of step s + pd_grp + u goes out behind MFMA number c of step u: the PPW pieces evenly over the step's MFMAs
+  auto mf_hook = [&](int s, int u, int c) {
+    if constexpr (IMF) {
+      constexpr int TOT = (X3 ? 3 : 2) * MI * NJ;
+#pragma unroll
+      for (int k = 0; k < PPW; ++k)
+        if (dma && c == ((2 * k + 1) * TOT) / (2 * PPW) + 1) {
+          issue_piece(s + pd_grp + u, st_is + u, k);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+  };
   for (int s = 0; s < ns; s += SPP) {
     // ---- MEM: fragments of this phase's steps, LDS-DMA pieces of the steps PD ahead.  (The hi / lo split is NOT done here: the partner
     // wave multiplies at s_setprio 1 meanwhile and this wave's VALU would get the left-over issue slots only -- 40 VALU took ~600 cycles.)
@@ -470,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params
 #pragma unroll
     for (int u = 0; u < SPP; ++u)
       if (!(dbg & 4)) read_frags(u, st_rd + u);
-    if (dma) {
+    if (dma && !IMF) {
 #pragma unroll
       for (int u = 0; u < SPP; ++u) issue(s + PD + u, st_is + u);
     }
@@ -534,6 +572,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params
         for (int g = 0; g < 2 * NM; ++g) {
           const int r = g / NM, ij = g % NM, i = ij / NJ, j = ij % NJ;
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].h, bh[j][r], acc[i][j], 0, 0, 0);
+          mf_hook(s, u, g + 1);
           if constexpr (!nosplit) {
             const int p0 = g * NP / (2 * NM), p1 = (g + 1) * NP / (2 * NM);  // pairs dealt evenly over the 2 NM MFMAs
 #pragma unroll
@@ -544,14 +583,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const siu3r_gemm_params
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].h, bh[j][0], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NJ; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].h, bh[j][0], acc[i][j], 0, 0, 0);
+            mf_hook(s, u, 2 * NM + i * NJ + j + 1);
+          }
       } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fa[u][i][ks]), bh[j][ks], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fa[u][i][ks]), bh[j][ks], acc[i][j], 0, 0, 0);
+              mf_hook(s, u, (ks * MI + i) * NJ + j + 1);
+            }
       }
     }
     __builtin_amdgcn_s_setprio(0);

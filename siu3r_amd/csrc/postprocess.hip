@@ -102,7 +102,9 @@ __device__ __forceinline__ float sample256(const float* p256, int64_t base, int 
   return (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
 }
 
+#ifdef SIU3R_TOOLS_BUILD
 __device__ unsigned long long g_pp_dbg[4];  // probes only: [0] label pixels that differ between two back-to-back argmax passes, [1] NaN reads
+#endif
 
 // grid: (ceil(T*H*W/256), B).  SYS: system-scope loads of the volume (the shipped form, see sample256); false: plain loads (SIU3R_PP_DBG probes)
 template <bool SYS>
@@ -132,7 +134,9 @@ __global__ __launch_bounds__(256) void pp_argmax_kernel(const float* p256, const
     for (int k = 0; k < nk; ++k) {
       const int q = kept_idx[b * Q + k];
       const float wv = sample256<SYS>(p256, base, MS, Q, q, y0, y1, x0, x1, ly, lx) * scores[b * Q + q];
+#ifdef SIU3R_TOOLS_BUILD
       if (!SYS && wv != wv) atomicAdd(&g_pp_dbg[1], 1ull);  // (probe variant only: a NaN-filled volume read before its writer's values)
+#endif
       if (wv > best) {  // strict: first maximum wins, like torch.argmax
         best = wv;
         bk = k;
@@ -251,7 +255,9 @@ __global__ __launch_bounds__(256) void pp_qcl_kernel(const float* p256, const fl
 
 inline dim3 g1(int64_t n, int blk = 256) { return dim3((unsigned)cdiv64(n, blk)); }
 
-// ---- probes of the round-4 stale read (SIU3R_PP_DBG, tools/label_flake_probe.py): never active in the product path
+// ---- probes of the round-4 stale read (SIU3R_PP_DBG, tools/label_flake_probe.py): compiled into tools builds only
+// (tools/ab_build.sh <tag> -DSIU3R_TOOLS_BUILD); the shipped library has neither the kernels nor the environment switch
+#ifdef SIU3R_TOOLS_BUILD
 __global__ void pp_dbg_fill_kernel(float* p, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -261,6 +267,7 @@ __global__ void pp_dbg_diff_kernel(const int32_t* a, const int32_t* b, int64_t n
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && a[i] != b[i]) atomicAdd(&g_pp_dbg[0], 1ull);
 }
+#endif
 
 }  // namespace
 
@@ -277,16 +284,16 @@ extern "C" int siu3r_panoptic_stage1(const float* class_logits, const float* mas
               "panoptic_stage1: mask volume / pixel count must stay below 2^31");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(pp_class_kernel, dim3(B), dim3(64), 0, s, class_logits, probs, scores, labels, kept_idx, n_keep, Q, C, threshold, area, orig);
+  const int64_t nvol = (int64_t)B * T * mask_size * mask_size * Q;
+  const int64_t npix = (int64_t)T * H * W;
+  const dim3 ag((unsigned)cdiv64(npix, 256), B);
+#ifdef SIU3R_TOOLS_BUILD
   // SIU3R_PP_DBG (probes only; bit 0: plain loads in the argmax, bit 1: a stream synchronisation between the volume's writer and the
   // argmax, bit 2: the volume is NaN-filled before its writer runs, bit 3: the argmax runs twice back to back -- first into `seg` as
   // scratch -- and the label pixels on which the passes disagree are counted and reported on stderr)
-  const char* dbg_env = getenv("SIU3R_PP_DBG");
-  const int dbg = dbg_env ? atoi(dbg_env) : 0;
-  const int64_t nvol = (int64_t)B * T * mask_size * mask_size * Q;
+  static const int dbg = getenv("SIU3R_PP_DBG") ? atoi(getenv("SIU3R_PP_DBG")) : 0;
   if (dbg & 4) hipLaunchKernelGGL(pp_dbg_fill_kernel, dim3(4096), dim3(256), 0, s, p256, nvol);
   hipLaunchKernelGGL(pp_mask256_kernel, g1(nvol), dim3(256), 0, s, mask_logits_cl, p256, B * T, IH, IW, mask_size, Q);
-  const int64_t npix = (int64_t)T * H * W;
-  const dim3 ag((unsigned)cdiv64(npix, 256), B);
   if (dbg & 2) (void)hipStreamSynchronize(s);
   if (dbg & 8) {
     hipLaunchKernelGGL(pp_argmax_kernel<false>, ag, dim3(256), 0, s, p256, scores, kept_idx, n_keep, seg, area, orig, T, H, W, mask_size, Q, mask_threshold);
@@ -304,6 +311,10 @@ extern "C" int siu3r_panoptic_stage1(const float* class_logits, const float* mas
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pp_dbg), z, sizeof(z));
     if (h[0] || h[1]) fprintf(stderr, "SIU3R_PP_DBG=%d: two back-to-back argmax passes disagree on %llu label pixels; %llu NaN reads of the volume\n", dbg, h[0], h[1]);
   }
+#else
+  hipLaunchKernelGGL(pp_mask256_kernel, g1(nvol), dim3(256), 0, s, mask_logits_cl, p256, B * T, IH, IW, mask_size, Q);
+  hipLaunchKernelGGL(pp_argmax_kernel<true>, ag, dim3(256), 0, s, p256, scores, kept_idx, n_keep, lab_map, area, orig, T, H, W, mask_size, Q, mask_threshold);
+#endif
   hipLaunchKernelGGL(pp_accept_kernel, g1(B, 64), dim3(64), 0, s, area, orig, kept_idx, n_keep, labels, scores, seg_id, seg_label, seg_fused, seg_score, acc_list, n_acc, Q, overlap, fuse_mask, B);
   hipLaunchKernelGGL(pp_write_kernel, dim3((unsigned)cdiv64(npix, 256), B), dim3(256), 0, s, lab_map, seg_id, seg_label, n_keep, seg, sem, ins, npix, Q);
   SIU3R_LAUNCH_CHECK("siu3r_panoptic_stage1");

@@ -1161,221 +1161,13 @@ __global__ void blend_bg_kernel(int64_t n, int C, float* colors, const float* al
 // left to the alpha / transmittance steps (the SIMD's other wave runs its own while this wave's MFMAs execute).  lane = pixel of the wave's 8 x 8 quadrant for that step (once per entry, for all
 // channels; lists cut to the quadrant by the extent test at load time); v_permlane32_swap turns two weight registers into the two A
 // operands (pixels 0-31 / 32-63 of the quadrant, k = entry).  Accumulators: 2 x NP blocks of 16 registers.
-#ifndef SIU3R_FEAT_DBG
-#define SIU3R_FEAT_DBG 0  // tools/ab_raster.sh probes: 3 = counters instead of the result, 6 = no output stores, 7 = no MFMAs
-#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-template <int NP>
-__global__ __launch_bounds__(256, 2) void composite_feat4_kernel(const Cam* __restrict__ cams, Geo geo, const int32_t* __restrict__ tile_start,
-                                                                 const int32_t* __restrict__ ids, int64_t cap_d, const float* __restrict__ rec,
-                                                                 const float* __restrict__ feats, int channels, int64_t G, int V, float* __restrict__ out,
-                                                                 float* __restrict__ out_alpha) {
-  // Staging: batches of NB = 32 list entries, DOUBLE-BUFFERED in LDS and filled by LDS-DMA (buffer_load ... lds: global -> LDS without
-  // passing through registers) one batch ahead; the Gaussian ids travel two batches ahead (a register of wave 0, then LDS), because
-  // record and feature addresses depend on them.  While batch b is blended, batch b + 1's records (32 B each) and feature rows
-  // (64 * NP pieces of 16 B ... per entry) are in flight and batch b + 2's ids are being fetched: no wave waits for HBM inside the loop
-  // except at the one vmcnt(0) per batch, by which time the data has had a whole batch to arrive (the counters of the synchronous
-  // version: 69 % of all wave cycles parked in s_waitcnt / barriers, matrix pipe 18 % busy).
-  constexpr int NB = 32, CW = 32 * NP;
-  __shared__ int s_id[3][NB];
-  __shared__ __attribute__((aligned(16))) float s_rec[2][NB][8];  // {mx, my, depth, 0 | conic a, b, c, opacity}
-  __shared__ __attribute__((aligned(16))) float s_f[2][NB][CW];
-  const int v = blockIdx.z;
-  const Cam& c = cams[v];
-  const int tile = blockIdx.x, tx = tile % geo.gw, ty = tile / geo.gw;
-  // chunk blockIdx.y covers CW channels from ch0; the last chunk of a wide matrix is shifted back to end at the last channel, and so
-  // is the last 32-channel block of a chunk (32 <= nch <= CW, the launcher's rule): every window lies inside the feature row; channels
-  // two windows share are computed twice, identically
-  const int ch0 = min((int)blockIdx.y * CW, max(0, channels - CW)), nch = min(CW, channels - ch0);
-  const int last_off = nch - 32;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
-  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-  const int width = c.width, height = c.height;
-  const bool inside = px < width && py < height;
-  const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
-  const int32_t* ts = tile_start + (int64_t)v * (geo.T + 2);
-  const int32_t* idp = ids + (int64_t)v * cap_d;
-  const int beg = ts[tile], end = ts[tile + 1];
-  const float alpha_min = c.alpha_min, alpha_max = c.alpha_max, t_min = c.t_min;
-  float T = 1.0f, O = 0.f;
-  f32x16 acc[2][NP];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int n = 0; n < NP; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][n][r] = 0.f;
-  bool done = !inside;
-#if SIU3R_FEAT_DBG == 3
-  int dbg_pairs = 0, dbg_mfma = 0, dbg_lanes = 0;
-#endif
-  // buffer resources (32-bit byte offsets; the launcher checks that both arrays stay below 4 GiB): an out-of-range offset reads zeros
-  const __amdgpu_buffer_rsrc_t r_rec = __builtin_amdgcn_make_buffer_rsrc((void*)rec, (short)0, (int)((int64_t)V * G * 48), 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_feat = __builtin_amdgcn_make_buffer_rsrc((void*)feats, (short)0, (int)((int64_t)G * channels * 4), 0x00020000);
-  const unsigned vg48 = (unsigned)((int64_t)v * G * 48);
 
-  // issue the DMAs of the batch whose ids are in s_id[ring]: records by wave 0 (lane = 2 * entry + half), feature rows by everybody
-  // (piece e = entry * (CW / 4) + 16-byte column); a wave instruction fills 64 consecutive 16-byte slots of the destination
-  auto issue = [&](int ring, int buf) {
-    if (wave == 0) {
-      const int j = lane >> 1;
-      const unsigned off = vg48 + (unsigned)s_id[ring][j] * 48u + (unsigned)(lane & 1) * 16u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rec, (lds_ptr_t)&s_rec[buf][0][0], 16, off, 0, 0, 0);
-    }
-    constexpr int PCS = NB * (CW / 4);  // 16-byte pieces per batch (a multiple of 256: NB * CW / 4 = 256 * NP)
-#pragma unroll
-    for (int k = 0; k < PCS / 256; ++k) {
-      const int e = k * 256 + threadIdx.x;
-      const int j = e / (CW / 4), cw = (e - j * (CW / 4)) * 4;
-      const int co = (cw >> 5) == NP - 1 ? last_off + (cw & 31) : cw;
-      const unsigned off = ((unsigned)s_id[ring][j] * (unsigned)channels + (unsigned)(ch0 + co)) * 4u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_feat, (lds_ptr_t)((char*)&s_f[buf][0][0] + (k * 256 + wave * 64) * 16), 16, off, 0, 0, 0);
-    }
-  };
-
-  const float (*recb)[8] = s_rec[0];  // the records of the batch being blended
-  auto weight = [&](int j) -> float {  // the blending weight of entry j for this lane's pixel (0: does not blend); advances T, O, done
-    if (done) return 0.f;
-    const float dx = recb[j][0] - pxf, dy = recb[j][1] - pyf;
-    const float4 co = *(const float4*)&recb[j][4];
-    const float sigma = conic_sigma(co.x, co.y, co.z, dx, dy);
-    if (sigma < 0.0f) return 0.f;
-    const float a = fminf(alpha_max, co.w * exp_det(-sigma));
-    if (a < alpha_min) return 0.f;
-    const float nT = __builtin_fmaf(-T, a, T);
-    if (nT <= t_min) {
-      done = true;
-      return 0.f;
-    }
-    const float w = a * T;
-    O += w;
-    T = nT;
-    return w;
-  };
-
-  // prologue: ids of batch 0 -> LDS, ids of batch 1 -> wave 0's register, DMAs of batch 0
-  int idreg = 0;
-  if (threadIdx.x < NB) {
-    s_id[0][threadIdx.x] = beg + (int)threadIdx.x < end ? idp[beg + threadIdx.x] : 0;
-    idreg = beg + NB + (int)threadIdx.x < end ? idp[beg + NB + threadIdx.x] : 0;
-  }
-  __syncthreads();
-  if (beg < end) issue(0, 0);
-  int nb = 0;
-  for (int base = beg; base < end; base += NB, ++nb) {
-    // batch nb's DMAs (issued one batch ago) and the ids of batch nb + 1 (loaded one batch ago) have landed
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x < NB) s_id[(nb + 1) % 3][threadIdx.x] = idreg;
-    if (__syncthreads_count(done) == 256) break;  // (also: everybody is past batch nb - 1's LDS reads, batch nb's data is visible to all)
-    const int cnt = min(NB, end - base), buf = nb & 1;
-    recb = s_rec[buf];
-    if (threadIdx.x < NB) idreg = base + 2 * NB + (int)threadIdx.x < end ? idp[base + 2 * NB + threadIdx.x] : 0;
-    if (base + NB < end) issue((nb + 1) % 3, buf ^ 1);
-    // which entries of batch nb can reach THIS wave's quadrant: lanes 0..31 test one entry each (no second barrier, no serial section)
-    unsigned qm;
-    {
-      bool reach = false;
-      if (lane < cnt) {
-        const float4 r0 = *(const float4*)&s_rec[buf][lane][0], r1 = *(const float4*)&s_rec[buf][lane][4];
-        // alpha >= alpha_min  <=>  sigma <= L = ln(opacity / alpha_min); on that ellipse |dx| <= sqrt(2 L c / det), |dy| <= sqrt(2 L a / det).
-        // Conservative (margins far above the rounding of exp_det and of this bound): an entry dropped here can never pass the
-        // per-pixel test, an entry kept needlessly only costs time.
-        const float det = conic_det(r1.x, r1.y, r1.z);
-        const float L = logf(r1.w / alpha_min) * 1.001f + 0.001f;
-        reach = !(L < 0.f);
-        if (reach && det > 0.f && L == L) {
-          const float ex = sqrtf(2.0f * L * r1.z / det) + 0.01f, ey = sqrtf(2.0f * L * r1.x / det) + 0.01f;
-          if (ex == ex && ey == ey)
-            reach = r0.x - ex <= (float)qx0 + 7.5f && r0.x + ex >= (float)qx0 + 0.5f && r0.y - ey <= (float)qy0 + 7.5f && r0.y + ey >= (float)qy0 + 0.5f;
-        }
-      }
-      qm = (unsigned)__ballot(reach);  // (cnt <= 32: lanes 32..63 vote false)
-    }
-    const float (*sfb)[CW] = s_f[buf];
-    if (__ballot(!done) == 0ull) continue;  // the whole quadrant is saturated: only the barrier is left for this wave
-    while (qm) {
-      const int j0 = __builtin_ctz(qm);
-      qm &= qm - 1u;
-      const float w0 = weight(j0);
-      int j1 = j0;
-      float w1 = 0.f;
-      if (qm) {
-        j1 = __builtin_ctz(qm);
-        qm &= qm - 1u;
-        w1 = weight(j1);
-      }
-#if SIU3R_FEAT_DBG == 3
-      dbg_pairs += 1;
-#endif
-      if (__ballot(w0 != 0.f || w1 != 0.f) == 0ull) continue;
-#if SIU3R_FEAT_DBG == 3
-      dbg_mfma += 1;
-      dbg_lanes += __popcll(__ballot(w0 != 0.f)) + __popcll(__ballot(w1 != 0.f));
-#endif
-      // A operands: lanes 0-31 carry k = 0 (entry j0), lanes 32-63 k = 1 (entry j1); block 0 = pixels 0-31 of the quadrant, block 1 = 32-63
-      // (hipcc uses only the FIRST result of a two-operand v_permlane32_swap correctly here -- the second A operand came out as the first
-      // in the ISA -- so each operand takes "the value lane ^ 32 holds" through the single-operand form, which is right whichever
-      // registers the allocator picks: see attention.hip)
-      const bool lo = lane < 32;
-      auto other_half = [&](float x) {
-        const unsigned u = __builtin_bit_cast(unsigned, x);
-        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-        return __builtin_bit_cast(float, lo ? sw[1] : sw[0]);
-      };
-      const float w1_other = other_half(w1), w0_other = other_half(w0);
-      const float a_lo = lo ? w0 : w1_other;   // block 0 (pixels 0-31): k = 0 -> w0 of pixel lane, k = 1 -> w1 of pixel lane - 32
-      const float a_hi = lo ? w0_other : w1;   // block 1 (pixels 32-63): k = 0 -> w0 of pixel lane + 32, k = 1 -> w1 of pixel lane
-      const float* frow = &sfb[lane < 32 ? j0 : j1][lane & 31];
-#if SIU3R_FEAT_DBG == 7
-      acc[0][0][0] += a_lo * frow[0] + a_hi;  // (ablation: no MFMAs, the stores stay)
-#else
-      float b[NP];  // all B operands of the pair first: the MFMA burst below then runs without an LDS round trip between its groups
-#pragma unroll
-      for (int n = 0; n < NP; ++n) b[n] = frow[32 * n];
-#pragma unroll
-      for (int n = 0; n < NP; ++n) {
-        acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, b[n], acc[0][n], 0, 0, 0);
-        acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, b[n], acc[1][n], 0, 0, 0);
-      }
-#endif
-    }
-  }
-#if SIU3R_FEAT_DBG == 3
-  if (lane == 0 && out_alpha && blockIdx.y == 0) {  // (probe build: counters instead of the first alphas; tools/mb_feat.py prints them)
-    atomicAdd(&out_alpha[0], (float)dbg_pairs);
-    atomicAdd(&out_alpha[1], (float)dbg_mfma);
-    atomicAdd(&out_alpha[2], (float)dbg_lanes);
-    atomicAdd(&out_alpha[3], (float)(end - beg) * 0.25f);
-  }
-  return;
-#endif
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (an early exit leaves the next batch's DMAs in flight: they must land before the LDS is released)
-  // C/D layout: column (channel) = lane & 31, row (pixel of the 32-pixel block) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const size_t hw = (size_t)width * height;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int p = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int ox = qx0 + (p & 7), oy = qy0 + (p >> 3);
-#if SIU3R_FEAT_DBG == 6
-      if (ox < width && oy < height && T == 123.456f) {  // (ablation: the MFMAs stay alive, the stores never execute)
-#else
-      if (ox < width && oy < height) {
-#endif
-        float* o = out + ((size_t)v * hw + (size_t)oy * width + ox) * channels + ch0 + (lane & 31);
-#pragma unroll
-        for (int n = 0; n < NP; ++n) o[n == NP - 1 ? last_off : 32 * n] = acc[a][n][r];
-      }
-    }
-  if (inside && blockIdx.y == 0 && out_alpha) out_alpha[(size_t)v * hw + (size_t)py * width + px] = O;
-}
-
-// ---- K3 composite, matrix-core form without a workgroup barrier: per-QUADRANT lists + wave-private staging --------------------------------
-// composite_feat4_kernel stages a tile's list in batches that its four waves share, so every batch ends in a barrier that the wave with
-// the longest quadrant list decides (counters: 54 % of the wave cycles parked).  Here the lists are cut per 8 x 8 quadrant FIRST
+// ---- no workgroup barrier: per-QUADRANT lists + wave-private staging -------------------------------------------------------------------
+// (Round 5's first matrix-core form staged a tile's list in batches that its four waves shared: every batch ended in a barrier that the
+// wave with the longest quadrant list decided -- counters: 54 % of the wave cycles parked, 0.69 ms per 168-channel frame against 0.40
+// here; removed in round 6, callers without a workspace get the 32-channel kernel.)  The lists are cut per 8 x 8 quadrant FIRST
 // (ql_build_kernel: the same conservative extent test, order kept; 4 B per (quadrant, entry) pair), and each wave of the composite walks
 // its own quadrant's list with its own LDS ring (3 chunks of 8 entries: records + feature rows by LDS-DMA two chunks ahead, ids three
 // ahead): no __syncthreads in the kernel, a saturated quadrant's wave simply leaves, pairs are formed over the whole quadrant list
@@ -1761,40 +1553,26 @@ extern "C" int siu3r_raster_tile_lists(const siu3r_raster_cam* cams_host, int V,
   return 0;
 }
 
+// tuning switches (siu3r_raster_tune; tests and tools A/B the forms through it -- no environment variable is read on the render path)
+static int g_feat_form = 0;  // 0: matrix-core form where it applies; 1: the 32-channel kernel everywhere
+static int g_feat_np = 6;    // accumulator blocks (of 32 channels) per chunk of the matrix-core form, 1 .. 6
+extern "C" int siu3r_raster_tune(int key, int value) {
+  SIU3R_CHECK(key == 0 || key == 1, "raster_tune: unknown key %d", key);
+  if (key == 0) g_feat_form = value == 1 ? 1 : 0;
+  else g_feat_np = value < 1 ? 6 : (value > 6 ? 6 : value);
+  return 0;
+}
+
 extern "C" int siu3r_raster_composite_feat(const siu3r_raster_cam* cams_host, int V, const void* cams_dev, int64_t G, const int32_t* tile_start,
                                            const int32_t* ids, int64_t cap_d, const float* rec, const float* feats, int channels, float* out,
                                            float* out_alpha, void* stream) {
   if (int rc = check_views(cams_host, V, "raster_composite_feat")) return rc;
   SIU3R_CHECK(cams_dev && tile_start && (ids || cap_d == 0 || G == 0) && ((rec && feats) || G == 0) && out && channels > 0, "raster_composite_feat: bad arguments");  // (an empty scene has empty lists: nothing is dereferenced)
   const Geo geo = make_geo(cams_host[0].width, cams_host[0].height);
-  const char* form_env = getenv("SIU3R_FEAT_FORM");  // 1 = the 32-channel kernel everywhere (A/B; the tests cross-check the two forms bit for bit)
-  const int form = form_env ? atoi(form_env) : 4;
-  // (the matrix-core form addresses records and features through buffer resources: 32-bit byte offsets)
-  const bool fits32 = (int64_t)V * G * 48 < (1ll << 31) * 2 - 64 && (int64_t)G * channels * 4 < (1ll << 31) * 2 - 64 && (((uintptr_t)feats) & 3) == 0;  // (rows need not be 16-byte aligned: q x 21 channels rarely are)
-  if (form == 1 || channels < 32 || !fits32) {
-    const int nchunk = (channels + CHUNK - 1) / CHUNK;
-    SIU3R_CHECK(nchunk <= 65535 && V <= 65535, "raster_composite_feat: too many channel chunks / views");
-    hipLaunchKernelGGL(composite_feat_kernel, dim3(geo.T, nchunk, V), dim3(256), 0, (hipStream_t)stream, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, rec,
-                       feats, channels, G, out, out_alpha);
-  } else {
-    // rank-2 updates on the matrix cores, 32 * NP channels per chunk (NP = 1 .. 6)
-    const char* np_env = getenv("SIU3R_FEAT_NP");  // (A/B: blocks per chunk)
-    const int np_max = np_env ? max(1, min(6, atoi(np_env))) : 6;
-    const int np = channels >= 32 * np_max ? np_max : (channels + 31) / 32;
-    const int nchunk = (channels + 32 * np - 1) / (32 * np);
-    SIU3R_CHECK(nchunk <= 65535 && V <= 65535, "raster_composite_feat: too many channel chunks / views");
-    const dim3 grid(geo.T, nchunk, V);
-#define SIU3R_F4(N) hipLaunchKernelGGL(composite_feat4_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, rec, feats, channels, G, V, out, out_alpha)
-    switch (np) {
-      case 1: SIU3R_F4(1); break;
-      case 2: SIU3R_F4(2); break;
-      case 3: SIU3R_F4(3); break;
-      case 4: SIU3R_F4(4); break;
-      case 5: SIU3R_F4(5); break;
-      default: SIU3R_F4(6); break;
-    }
-#undef SIU3R_F4
-  }
+  const int nchunk = (channels + CHUNK - 1) / CHUNK;
+  SIU3R_CHECK(nchunk <= 65535 && V <= 65535, "raster_composite_feat: too many channel chunks / views");
+  hipLaunchKernelGGL(composite_feat_kernel, dim3(geo.T, nchunk, V), dim3(256), 0, (hipStream_t)stream, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, rec,
+                     feats, channels, G, out, out_alpha);
   SIU3R_LAUNCH_CHECK("siu3r_raster_composite_feat");
   return 0;
 }
@@ -1810,18 +1588,16 @@ extern "C" int siu3r_raster_composite_feat_ws(const siu3r_raster_cam* cams_host,
   if (int rc = check_views(cams_host, V, "raster_composite_feat_ws")) return rc;
   SIU3R_CHECK(cams_dev && tile_start && (ids || cap_d == 0 || G == 0) && ((rec && feats) || G == 0) && out && channels > 0, "raster_composite_feat_ws: bad arguments");
   const Geo geo = make_geo(cams_host[0].width, cams_host[0].height);
-  const char* form_env = getenv("SIU3R_FEAT_FORM");  // 1 = 32-channel kernel, 4 = matrix cores with shared batches, default 5 = per-quadrant lists
-  const int form = form_env ? atoi(form_env) : 5;
+  // (the matrix-core form addresses records and features through buffer resources: 32-bit byte offsets; rows need only 4-byte alignment)
   const bool fits32 = (int64_t)V * G * 48 < (1ll << 31) * 2 - 64 && (int64_t)G * channels * 4 < (1ll << 31) * 2 - 64 && (((uintptr_t)feats) & 3) == 0;
   const int64_t need = (int64_t)V * (16 * cap_d + 16 * (int64_t)geo.T);
-  if (form != 5 || channels < 32 || !fits32 || !ws || ws_bytes < need || (((uintptr_t)ws) & 3))
+  if (g_feat_form == 1 || channels < 32 || !fits32 || !ws || ws_bytes < need || (((uintptr_t)ws) & 3))
     return siu3r_raster_composite_feat(cams_host, V, cams_dev, G, tile_start, ids, cap_d, rec, feats, channels, out, out_alpha, stream);
   hipStream_t s = (hipStream_t)stream;
   int32_t* qids = (int32_t*)ws;
   int32_t* qcnt = qids + (int64_t)V * 4 * cap_d;
   hipLaunchKernelGGL(ql_build_kernel, dim3(geo.T, V), dim3(256), 0, s, (const Cam*)cams_dev, geo, tile_start, ids, cap_d, rec, G, qids, qcnt);
-  const char* np_env = getenv("SIU3R_FEAT_NP");  // (A/B: blocks per chunk)
-  const int np_max = np_env ? max(1, min(6, atoi(np_env))) : 6;
+  const int np_max = g_feat_np;
   const int np = channels >= 32 * np_max ? np_max : (channels + 31) / 32;
   const int nchunk = (channels + 32 * np - 1) / (32 * np);
   SIU3R_CHECK(nchunk <= 65535 && V <= 65535, "raster_composite_feat_ws: too many channel chunks / views");

@@ -135,8 +135,9 @@ def load_segmentation_dir(pred_dir: Path, gt_dir: Path):
 def accumulate_dir(path, acc: Optional[M.MetricAccumulator] = None, scenes: Optional[Sequence[str]] = None, write_scene_scores: bool = True,
                    map_records: Optional[Dict[str, list]] = None, lpips=None) -> M.MetricAccumulator:
     """Fold the scene directories under `path` (all, or the named subset: a rank's shard) into additive statistics.  map_records: a dict
-    that receives, per mode ("context" / "target"), one COCO match record per scene for the mean average precision (metrics.map_scene_records;
-    not additive: the caller gathers the lists and calls metrics.mean_average_precision on rank 0).  lpips: a siu3r_amd.lpips.LPIPS (GPU);
+    that receives, per mode ("context" / "target"), one (scene directory name, COCO match record) pair per scene for the mean average precision
+    (metrics.map_scene_records; not additive: the caller gathers the lists and hands them to `ordered_map_records` ->
+    metrics.mean_average_precision on rank 0 -- the accumulation breaks score ties by input order, so the order must not depend on the sharding).  lpips: a siu3r_amd.lpips.LPIPS (GPU);
     when given, every rendered image also gets its `lpips` score (evaluator.py:263)."""
     from PIL import Image
 
@@ -173,8 +174,15 @@ def accumulate_dir(path, acc: Optional[M.MetricAccumulator] = None, scenes: Opti
                 if map_records is not None:
                     pj = d / f"{mode}_seg_pred" / "pred.json"  # (evaluator.py:175-180: label and score of a predicted id come from here)
                     preds = json.load(open(pj)) if pj.exists() else None
-                    map_records.setdefault(mode, []).append(M.map_scene_records(M.map_scene_inputs(*maps, preds)))
+                    map_records.setdefault(mode, []).append((d.name, M.map_scene_records(M.map_scene_inputs(*maps, preds))))
     return acc
+
+
+def ordered_map_records(named: Sequence) -> list:
+    """(scene name, record) pairs from any number of ranks -> the records in the order a single process walks the result tree (sorted
+    scene directories, evaluator.py:346-399).  mean_average_precision sorts detection scores stably, so ties -- every score is 1.0 when
+    pred.json is absent -- resolve by this order: without it the value would change with the world size."""
+    return [r for _, r in sorted(named, key=lambda t: t[0])]
 
 
 def evaluate_dir(path, write: bool = True, lpips=None) -> Dict[str, object]:
@@ -182,7 +190,7 @@ def evaluate_dir(path, write: bool = True, lpips=None) -> Dict[str, object]:
     recs: Dict[str, list] = {}
     res = accumulate_dir(path, map_records=recs, lpips=lpips).compute()
     for mode, r in recs.items():
-        res[f"{mode}_map"] = M.mean_average_precision(r)
+        res[f"{mode}_map"] = M.mean_average_precision(ordered_map_records(r))
     if write:
         with open(Path(path) / "results.json", "w") as fh:
             json.dump(res, fh, indent=4)

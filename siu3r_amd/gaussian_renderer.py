@@ -125,13 +125,23 @@ def lift_query_class_logits(render_qc_logits: List[torch.Tensor], query_scores: 
 _PREPARED: dict = {}  # rasterize_splats' one-entry cache of the view-independent preparation (release_prepared_splats() drops it)
 
 
-def release_prepared_splats():
+def _clear_prepared():
+    for f in _PREPARED.get("finalizers", ()):  # one finalizer per live source tensor: detached when the entry goes, so that a long-lived
+        f.detach()                             # tensor edited in place between frames does not collect one per rebuild
     _PREPARED.clear()
+
+
+def release_prepared_splats():
+    _clear_prepared()
 
 
 def _drop_prepared(token):
     if _PREPARED.get("token") is token:
-        _PREPARED.clear()
+        _clear_prepared()
+
+
+def _tensor_sig(t):
+    return (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype)
 
 
 def rasterize_splats(splats: dict, camtoworlds: torch.Tensor, Ks: torch.Tensor, width: int, height: int, sh_degree: int = 4,
@@ -147,30 +157,32 @@ def rasterize_splats(splats: dict, camtoworlds: torch.Tensor, Ks: torch.Tensor, 
 
     # view-independent preparation (covariances from quats / scales, activations, the concatenated coefficient block): computed once per
     # splat set -- a viewer renders many frames of one scene (the block alone is 600 MB for 2 M Gaussians).  The one-entry cache holds
-    # WEAK references to the source tensors and is valid only while every one of them is the very same live object at the same version
-    # counter (an in-place edit bumps `_version`; a new scene whose tensors reuse the old addresses is a different object); it is dropped
-    # as soon as one of the sources dies, so that it neither serves a stale scene nor pins the prepared tensors after the splats are gone.
+    # WEAK references to the source tensors it was built from and is valid while every one of them is alive and the tensor passed now has
+    # the same storage address, version counter (an in-place edit bumps `_version`, which views and `.detach()` share with their base),
+    # shape, strides and dtype -- so another view of the same live storage still hits.  It is dropped as soon as one of the sources dies
+    # (a new scene whose tensors reuse the old addresses is then a rebuild): it neither serves a stale scene nor pins the prepared tensors.
     names = ("means", "quats", "scales", "opacities", "sh0", "shN")
     src = [splats.get(k) for k in names]
     prep = _PREPARED.get("entry")
-    valid = prep is not None and all((r is None and t is None) or (r is not None and t is not None and r() is t and ver == t._version)
-                                     for (r, ver), t in zip(prep[0], src))
+    valid = prep is not None and all((r is None and t is None) or (r is not None and t is not None and r() is not None and sig == _tensor_sig(t))
+                                     for (r, sig), t in zip(prep[0], src))
     if not valid:
         means = splats["means"].float()
         cov6 = raster.quat_scale_to_cov6(splats["quats"], torch.exp(splats["scales"].float()))
         opac = torch.sigmoid(splats["opacities"].float())
         coeffs = torch.cat([splats["sh0"], splats["shN"]], 1).float() if splats.get("shN") is not None else splats["sh0"].float()
         token = object()
-        refs = []
+        refs, fins = [], []
         for t in src:
             if t is None:
-                refs.append((None, 0))
+                refs.append((None, None))
             else:
-                refs.append((weakref.ref(t), t._version))
-                weakref.finalize(t, _drop_prepared, token)
-        _PREPARED.clear()
+                refs.append((weakref.ref(t), _tensor_sig(t)))
+                fins.append(weakref.finalize(t, _drop_prepared, token))
+        _clear_prepared()
         prep = _PREPARED["entry"] = (refs, means, cov6, opac, coeffs)
         _PREPARED["token"] = token
+        _PREPARED["finalizers"] = fins
     _, means, cov6, opac, coeffs = prep
     assert coeffs.shape[1] >= (sh_degree + 1) ** 2
     cols, alphas, visible, pairs = [], [], [], []

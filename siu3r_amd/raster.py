@@ -328,10 +328,18 @@ def rasterize_k2(cam: RasterCam, means, cov6, shs, opacities, **kw) -> Dict[str,
                 n_touched=None if o["n_touched"] is None else o["n_touched"][0], state=o["state"])
 
 
+def tune(key: int, value: int) -> None:
+    """siu3r_raster_tune: key 0 -- 1 = the 32-channel kernel for every N-channel composite (features that may be non-finite; A/B), 0 = default;
+    key 1 -- accumulator blocks per chunk of the matrix-core composite (1 .. 6).  Process-wide, not for concurrent use."""
+    check(_lib.lib().siu3r_raster_tune(int(key), int(value)))
+
+
 def rasterize_views_k3(cams: Sequence[RasterCam], means, cov6, opacities, feats, entry_capacity=None, pair_capacity=None,
-                       check_overflow=True, pose_dev=None) -> Dict[str, torch.Tensor]:
-    """feats [G,C] -> colors [V,H,W,C], alphas [V,H,W] (+ state).  gsplat semantics: the per-tile lists are materialised once
-    and shared by every 32-channel chunk."""
+                       check_overflow=True, pose_dev=None, matrix_form=True) -> Dict[str, torch.Tensor]:
+    """feats [G,C] -> colors [V,H,W,C], alphas [V,H,W] (+ state).  gsplat semantics: the per-tile lists are materialised once; for
+    C >= 32 they are cut per 8 x 8 quadrant and blended on the matrix cores, all channels at once (identical bits for FINITE features).
+    matrix_form=False: the 32-channel kernel, whose pixels only ever see the rows that blend into them -- for features that may hold
+    inf / NaN (include/siu3r_hip.h, siu3r_raster_composite_feat_ws)."""
     _gpu(means, cov6, opacities, feats)
     if check_overflow == "deferred":
         raise ValueError('check_overflow="deferred" is only safe on the RGB composites (an overflowing view is NaN-poisoned there); the '
@@ -348,7 +356,7 @@ def rasterize_views_k3(cams: Sequence[RasterCam], means, cov6, opacities, feats,
         lib = _lib.lib()
         tstart, ids_all, cap_d = st["tile_start_all"], st["ids_all"], st["cap_d"]
         # workspace of the per-quadrant lists (C >= 32: every wave of the composite walks its own 8 x 8 quadrant's list)
-        ws = torch.empty((int(lib.siu3r_raster_composite_feat_ws_bytes(W, H, V, cap_d)) // 4,), dtype=torch.int32, device=dev) if Cc >= 32 else None
+        ws = torch.empty((int(lib.siu3r_raster_composite_feat_ws_bytes(W, H, V, cap_d)) // 4,), dtype=torch.int32, device=dev) if (Cc >= 32 and matrix_form) else None
         st["feat_ws"] = ws
         check(lib.siu3r_raster_composite_feat_ws(st["cams"], V, _p(st["cams_dev"]), G, _p(tstart), _p(ids_all), cap_d, _p(st["rec"]), _p(feats), Cc,
                                                  _p(out), _p(alpha), _p(ws), 0 if ws is None else ws.numel() * 4, _stream()))

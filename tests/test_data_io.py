@@ -135,7 +135,8 @@ def test_eval_files_round_trip(tmp_path):
     ra, rb = {}, {}
     E.accumulate_dir(tmp_path, scenes=["scene0000_00_context0_20"], write_scene_scores=False, map_records=ra)
     E.accumulate_dir(tmp_path, scenes=["scene0001_00_context5_15"], write_scene_scores=False, map_records=rb)
-    assert M.mean_average_precision(ra["target"] + rb["target"]) == res["target_map"]
+    assert M.mean_average_precision(E.ordered_map_records(rb["target"] + ra["target"])) == res["target_map"]  # (rank order != scene order)
+    assert [n for n, _ in ra["target"]] == ["scene0000_00_context0_20"]
 
 
 def test_segment_id_encoding_is_the_references():

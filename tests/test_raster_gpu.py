@@ -88,14 +88,20 @@ def test_k3_channels(channels):
     assert err <= 2e-6 and erra <= 2e-6
 
 
-FORMS = ("4", "5")
+@pytest.fixture
+def feat_form():
+    """raster.tune(0, ...) for one test: 1 = the 32-channel kernel everywhere, 0 = the shipped default (matrix-core form where it applies)"""
+    from siu3r_amd import raster
+
+    yield lambda v: raster.tune(0, v)
+    raster.tune(0, 0)
 
 
 @pytest.mark.parametrize("channels", [168, 3 * 64 + 8, 130, 105, 63, 32, 21])
-def test_k3_all_channel_composite_equals_the_chunked_one(channels, monkeypatch):
-    """The matrix-core list composite (composite_feat4_kernel: alpha / transmittance once per (pixel, entry) for all channels, lists cut to
+def test_k3_all_channel_composite_equals_the_chunked_one(channels, feat_form):
+    """The matrix-core list composite (composite_feat5_kernel: alpha / transmittance once per (pixel, entry) for all channels, lists cut to
     the wave's 8 x 8 quadrant, the blend as rank-2 v_mfma_f32_32x32x2_f32 updates -- exact f32, accumulating like the oracle's fmaf chain --
-    with records and feature rows double-buffered in LDS by LDS-DMA) against the 32-channel-chunk kernel it replaces (SIU3R_FEAT_FORM=1):
+    with records and feature rows staged in a wave-private LDS ring by LDS-DMA) against the 32-channel-chunk kernel it replaces (raster.tune(0, 1)):
     bit-identical maps; and against the C oracle, on a ragged frame with several views in one call: q x 21 = 168 logit channels (6 blocks,
     the last one a shifted window), 200 (two chunks, the second shifted back), 130, 105 and 63 (q x 21 with odd q: feature rows that are only
     4-byte aligned), 32 and 21 (below one block: the 32-channel kernel serves it)."""
@@ -110,15 +116,11 @@ def test_k3_all_channel_composite_equals_the_chunked_one(channels, monkeypatch):
     cams = [_k3_cam(H, W, seed=s_, near=1.0, far=9.0) for s_ in (2, 4, 6)]
     cov6 = raster.cov6_from_cov3x3(cov)
     args = (cams, means.cuda(), cov6.cuda(), opac.cuda(), feats.cuda())
-    monkeypatch.setenv("SIU3R_FEAT_FORM", "1")
+    feat_form(1)
     old = raster.rasterize_views_k3(*args)
-    for form in FORMS:
-        monkeypatch.setenv("SIU3R_FEAT_FORM", form)
-        new = raster.rasterize_views_k3(*args)
-        assert torch.equal(new["colors"], old["colors"]) and torch.equal(new["alphas"], old["alphas"]), (form, float((new["colors"] - old["colors"]).abs().max()))
-    monkeypatch.delenv("SIU3R_FEAT_FORM")
-    dflt = raster.rasterize_views_k3(*args)
-    assert torch.equal(dflt["colors"], new["colors"])  # the default is the last (shipped) form
+    feat_form(0)
+    new = raster.rasterize_views_k3(*args)
+    assert torch.equal(new["colors"], old["colors"]) and torch.equal(new["alphas"], old["alphas"]), float((new["colors"] - old["colors"]).abs().max())
     for v in (0, 2):
         ref = RO.forward(cams[v], means.numpy(), cov6.numpy(), opac.numpy(), feats.numpy(), want_lists=False)
         assert ref["D"] > 3000
@@ -126,7 +128,7 @@ def test_k3_all_channel_composite_equals_the_chunked_one(channels, monkeypatch):
         assert float(np.abs(new["alphas"][v].cpu().numpy() - ref["alpha"]).max()) <= 2e-6
 
 
-def test_k3_all_channel_composite_on_needles(monkeypatch):
+def test_k3_all_channel_composite_on_needles(feat_form):
     """Long thin splats seen diagonally (1 : 3000 axes, hundreds of pixels long): the conic's a c and b^2 agree to many digits, and the
     per-quadrant footprint test divides by their difference.  The quadrant lists must still keep every entry that blends: maps
     bit-identical to the kernel that walks the uncut tile lists."""
@@ -144,13 +146,40 @@ def test_k3_all_channel_composite_on_needles(monkeypatch):
     feats = torch.randn(G, channels, generator=g)
     cams = [_k3_cam(H, W, seed=s_, near=0.5, far=9.0) for s_ in (2, 4)]
     args = (cams, means.cuda(), raster.cov6_from_cov3x3(cov).cuda(), opac.cuda(), feats.cuda())
-    monkeypatch.setenv("SIU3R_FEAT_FORM", "1")
+    feat_form(1)
     old = raster.rasterize_views_k3(*args)
     assert float(old["alphas"].mean()) > 0.5 and int(old["state"]["D"]) > 20 * G
-    for form in FORMS:
-        monkeypatch.setenv("SIU3R_FEAT_FORM", form)
-        new = raster.rasterize_views_k3(*args)
-        assert torch.equal(new["colors"], old["colors"]) and torch.equal(new["alphas"], old["alphas"]), (form, float((new["colors"] - old["colors"]).abs().max()))
+    feat_form(0)
+    new = raster.rasterize_views_k3(*args)
+    assert torch.equal(new["colors"], old["colors"]) and torch.equal(new["alphas"], old["alphas"]), float((new["colors"] - old["colors"]).abs().max())
+
+
+def test_k3_composite_with_a_non_finite_feature_row(feat_form):
+    """include/siu3r_hip.h, siu3r_raster_composite_feat_ws: the matrix-core form multiplies every listed row into every pixel of the
+    quadrant (weight 0 where the entry does not reach), so an inf / NaN feature poisons pixels the 32-channel kernel leaves alone.  Pinned:
+    the 32-channel kernel (raster.tune(0, 1), what compat.gsplat.rasterization(finite_features=False) selects) keeps the damage to the
+    pixels the Gaussian blends into; the matrix-core form's NaN set contains that set, and everything outside ITS NaN set is bit-identical."""
+    from siu3r_amd import raster
+
+    H, W, G, channels = 96, 128, 2000, 64
+    means, cov, opac, _ = random_scene(G, seed=31, depth=(1.0, 6.0), scale=(0.02, 0.1))
+    feats = torch.randn(G, channels, generator=torch.Generator().manual_seed(3))
+    bad = 777
+    feats[bad, 5] = float("inf")
+    cams = [_k3_cam(H, W, seed=2, near=0.5, far=9.0)]
+    args = (cams, means.cuda(), raster.cov6_from_cov3x3(cov).cuda(), opac.cuda())
+    feat_form(1)
+    clean = raster.rasterize_views_k3(*args, torch.nan_to_num(feats, posinf=0.0).cuda())["colors"]
+    old = raster.rasterize_views_k3(*args, feats.cuda())["colors"]
+    feat_form(0)
+    new = raster.rasterize_views_k3(*args, feats.cuda())["colors"]
+    bad_old, bad_new = ~torch.isfinite(old).all(-1), ~torch.isfinite(new).all(-1)
+    assert int(bad_old.sum()) > 0, "the scene must show the bad Gaussian"
+    assert bool((bad_old & ~bad_new).sum() == 0) and int(bad_new.sum()) >= int(bad_old.sum())
+    assert int(bad_new.sum()) < H * W // 2                       # (a neighbourhood, not the frame)
+    assert torch.equal(new[~bad_new], old[~bad_new])
+    ch = [c for c in range(channels) if c != 5]
+    assert torch.equal(old[..., ch], clean[..., ch])             # the 32-channel kernel: only channel 5, only where the Gaussian blends
 
 
 def test_k3_all_channel_composite_empty_and_culled():
@@ -249,6 +278,42 @@ def test_viewer_render_semantics(degree):
     assert np.abs(alphas[0, ..., 0].cpu().numpy() - ref["alpha"]).max() <= 2e-6
     assert np.abs(colors[0].cpu().numpy() - want).max() <= 5e-6
     assert float(colors.min()) >= 0.0 and ref["D"] > 1000
+
+
+def test_prepared_splat_cache_hits_views_and_sheds_finalizers():
+    """rasterize_splats' one-entry cache of the view-independent preparation (round-5 advisor): another view of the same live storage
+    hits, an in-place edit rebuilds WITHOUT piling finalizers onto the long-lived tensors, and the entry dies with its sources."""
+    import gc
+
+    from siu3r_amd import gaussian_renderer as GR
+
+    G, H, W = 800, 64, 80
+    means, cov, opac, sh = random_scene(G, seed=9)
+    g = torch.Generator().manual_seed(10)
+    coeffs = sh.permute(0, 2, 1).contiguous()
+    splats = dict(means=means.cuda(), quats=torch.randn(G, 4, generator=g).cuda(), scales=torch.log(0.02 + 0.1 * torch.rand(G, 3, generator=g)).cuda(),
+                  opacities=torch.logit(opac.clamp(0.02, 0.98)).cuda(), sh0=coeffs[:, :1].cuda(), shN=coeffs[:, 1:].cuda())
+    c2w, K = look_at_camera(3), default_K().clone()
+    K[0] *= W
+    K[1] *= H
+    GR.release_prepared_splats()
+    a, _, _ = GR.rasterize_splats(splats, c2w[None], K[None], W, H, sh_degree=2)
+    entry = GR._PREPARED["entry"]
+    GR.rasterize_splats(splats, c2w[None], K[None], W, H, sh_degree=2)
+    assert GR._PREPARED["entry"] is entry
+    views = {k: v.detach() for k, v in splats.items()}        # fresh tensor objects over the same storage: still a hit
+    b, _, _ = GR.rasterize_splats(views, c2w[None], K[None], W, H, sh_degree=2)
+    assert GR._PREPARED["entry"] is entry and torch.equal(a, b)
+    old_fins = list(GR._PREPARED["finalizers"])
+    for _ in range(5):                                            # in-place edits between frames: rebuilds, one finalizer set at a time
+        splats["means"].add_(0.01)
+        GR.rasterize_splats(splats, c2w[None], K[None], W, H, sh_degree=2)
+        assert GR._PREPARED["entry"] is not entry and len(GR._PREPARED["finalizers"]) == 6
+        entry = GR._PREPARED["entry"]
+    assert not any(f.alive for f in old_fins)
+    del splats, views
+    gc.collect()
+    assert not GR._PREPARED
 
 
 def test_capacity_overflow_is_detected_and_retried():

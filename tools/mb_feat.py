@@ -1,6 +1,6 @@
 """N-channel (gsplat-semantics) list composite on the pixel-aligned pair scene, 6 views @512^2 in one call: ms per frame of the whole call and of the
 composite kernel alone (graph-free: HIP events around the composite entry point on prepared lists), per channel count and kernel form
-(SIU3R_FEAT_FORM=1: 32-channel chunks, 4 = default: matrix-core rank-2 updates).  python tools/mb_feat.py [channels ...]"""
+(form 1: 32-channel chunks, raster.tune(0, 1); form 5 = default: matrix-core rank-2 updates over per-quadrant lists).  python tools/mb_feat.py [channels ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -35,8 +35,8 @@ def ev_ms(fn, reps=5):
 for C in chans:
     feats = torch.randn(means.shape[0], C, generator=torch.Generator().manual_seed(5)).to(dev)
     outs = {}
-    for form in ("1", "4", "5"):
-        os.environ["SIU3R_FEAT_FORM"] = form
+    for form in ("1", "5"):
+        raster.tune(0, 1 if form == "1" else 0)
         run = lambda: raster.rasterize_views_k3(cams, m10, c100, opac, feats)
         o = run()
         st = o["state"]
@@ -46,14 +46,10 @@ for C in chans:
         comp = lambda: _lib.check(_lib.lib().siu3r_raster_composite_feat_ws(st["cams"], nv, _p(st["cams_dev"]), means.shape[0], _p(st["tile_start_all"]), _p(st["ids_all"]),
                                                                             st["cap_d"], _p(st["rec"]), _p(feats), C, _p(out), _p(al), _p(ws), 0 if ws is None else ws.numel() * 4, _stream()))
         ms_comp = ev_ms(comp, 10) / nv
-        if os.environ.get("MB_FEAT_COUNTERS"):  # probe build (-DSIU3R_FEAT_DBG=3): the kernel leaves counters in the first alphas of view 0
-            al.zero_(); comp(); torch.cuda.synchronize()
-            c_ = al.flatten()[:4].tolist()
-            print(f"        counters (all {nv} views): entry pairs walked {c_[0]:.0f}, pairs with an MFMA group {c_[1]:.0f}, blending (lane, entry) slots {c_[2]:.0f}, "
-                  f"list entries x waves {c_[3] * 4:.0f}; per wave: pairs {c_[0] / (nv * 4096):.0f}, with MFMAs {c_[1] / (nv * 4096):.0f}; lane utilisation of an MFMA pair {c_[2] / max(1, c_[1]) / 128:.3f}")
         Gv, Dp = st.totals(0), st.totals(1)
         b = sum(raster.algorithmic_bytes(means.shape[0], gv, d, H * W, channels=C) for gv, d in zip(Gv, Dp)) / nv
         outs[form] = o["colors"]
         print(f"C={C:4d} form {form}: call {ms_call:.3f} ms/frame ({b / ms_call / 1e6:.0f} GB/s alg. = {b / ms_call / 1e6 / 8000:.3f} of 8 TB/s), composite kernel {ms_comp:.3f} ms/frame; "
               f"D/view {sum(Dp) / nv:.0f}", flush=True)
-    print(f"        forms bit-identical: {torch.equal(outs['1'], outs['4']) and torch.equal(outs['1'], outs['5'])}")
+    raster.tune(0, 0)
+    print(f"        forms bit-identical: {torch.equal(outs['1'], outs['5'])}")
