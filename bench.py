@@ -406,7 +406,7 @@ def render_legs(gauss, B, H, W, dev, world, step=None):
     def leg(means, cov, sh, opac, label):
         """means [b,G,3] ... on the device; forward rescales means / covariances in place, hence the fresh copies"""
         b = means.shape[0]
-        ext, Kt = ext1[None].repeat(b, 1, 1, 1), Kt1[None].repeat(b, 1, 1, 1)
+        ext, Kt = ext1[None].repeat(b, 1, 1, 1).to(dev), Kt1[None].repeat(b, 1, 1, 1).to(dev)  # camera tensors on the device, as the pipeline holds them
         fresh = lambda: Gaussians(means=means.clone(), covariances=cov.clone(), harmonics=sh, opacities=opac)
         rend.forward(fresh(), ext, Kt, (H, W), render_color=True)  # warm-up
         reps = 6
@@ -430,14 +430,14 @@ def render_legs(gauss, B, H, W, dev, world, step=None):
                 "overflow_check": "deferred (SplattingCUDA(deferred_overflow_check=True): no device synchronisation per call; verified after the timed calls)",
                 "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_view": bytes_alg, "traffic": None,
-                             "note": "whole per-frame pipeline (project, per-view radix sort, coarse binning, composite), incl. host-side camera prep"}}
+                             "note": "whole per-frame pipeline (camera preparation on the device, project, per-view radix sort, coarse binning, composite)"}}
 
     out["render"] = leg(gauss.means, gauss.covariances, gauss.harmonics, gauss.opacities, "the network's own output (synthetic weights)")
 
     if step is not None:
         # SURVEY 8(d) config 2, second figure: network + 6-view colour render per pair, every step complete (forward incl. its host
         # pick-up of the segment table, then SplattingCUDA.forward on that step's own Gaussians: in-place x10 rescale as in the reference)
-        ext_b, Kt_b = ext1[None].repeat(B, 1, 1, 1), Kt1[None].repeat(B, 1, 1, 1)
+        ext_b, Kt_b = ext1[None].repeat(B, 1, 1, 1).to(dev), Kt1[None].repeat(B, 1, 1, 1).to(dev)
 
         def both():
             g_ = step()[0]

@@ -26,7 +26,7 @@ extern "C" {
 #define SIU3R_F64 3
 
 const char* siu3r_last_error(void);
-#define SIU3R_ABI_VERSION 9 /* 9: siu3r_raster_tune (replaces the SIU3R_FEAT_FORM / SIU3R_FEAT_NP environment switches; the shared-batch matrix-core composite is gone: no workspace = 32-channel kernel); 8: LPIPS (siu3r_maxpool2x2s2, siu3r_lpips_layer); 7: device-side poses for the gsplat seam (siu3r_raster_project_dp, siu3r_sh_eval_dp, siu3r_blend_background_dp), precomputed K2 colours (sh_degree < 0), all-channel list composite; 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok), siu3r_attn_params.kv_bxor / kv_x3, siu3r_gemm_params.c_x3_col0; 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
+#define SIU3R_ABI_VERSION 9 /* 9: siu3r_raster_project_c2w + siu3r_raster_cam.k2_near / k2_far (the reference renderer's own pose tensors, consumed on the device), siu3r_raster_tune (replaces the SIU3R_FEAT_FORM / SIU3R_FEAT_NP environment switches; the shared-batch matrix-core composite is gone: no workspace = 32-channel kernel); 8: LPIPS (siu3r_maxpool2x2s2, siu3r_lpips_layer); 7: device-side poses for the gsplat seam (siu3r_raster_project_dp, siu3r_sh_eval_dp, siu3r_blend_background_dp), precomputed K2 colours (sh_degree < 0), all-channel list composite; 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok), siu3r_attn_params.kv_bxor / kv_x3, siu3r_gemm_params.c_x3_col0; 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
 int siu3r_abi_version(void);
 
 /* ---- seam 1: curope.rope_2d(tokens, positions, base, fwd)
@@ -283,6 +283,8 @@ typedef struct {
   float dilation;      /* K2 low-pass 0.3 */
   int32_t nt_post_blend; /* K2 n_touched: count a pixel when the transmittance AFTER blending the Gaussian is > 0.5
                             (1, the MonoGS fork's `test_T > 0.5f`) or the one before it (0) */
+  float k2_near, k2_far; /* K2, siu3r_raster_project_c2w only: the planes of the [0, 1]-depth projection matrix the device derives
+                            (cuda_splatting.py:16-43); ignored when `proj` is given by the host */
 } siu3r_raster_cam;
 /* frame geometry / workspace sizes: out8 = {gw, gh, T = tiles, cb = coarse-bin edge in tiles, NB = coarse bins,
  * nchunks_sort (columns of rs_hist), nchunks_bin (columns of bin_hist), sizeof(siu3r_raster_cam)} */
@@ -305,6 +307,16 @@ int siu3r_raster_project_dp(const siu3r_raster_cam* cams_host, int V, void* cams
                             const float* means, const float* cov, int cov_stride, const float* opacities, const float* colors, int channels,
                             int sh_planar, float* rec, int32_t* radii, int32_t* rect, int32_t* tiles_touched, uint32_t* keys, uint64_t* stats,
                             void* stream);
+/* the same with the pose AS THE REFERENCE'S RENDERER HOLDS IT (SplattingCUDA.forward, src/models/gaussian_renderer.py:29-74; render_cuda,
+ * cuda_splatting.py:46-121), both families: c2w_dev [V,4,4] camera-to-world extrinsics and Kn_dev [V,3,3] NORMALISED intrinsics, row-major
+ * fp32 device tensors.  A one-thread-per-view kernel on the stream derives w2c = inverse(c2w with its translation * t_scale), campos and,
+ * mode 0: fov from the K^-1 edge rays (utils/projection.py:247-261), tanfovx / tanfovy, proj = Proj(k2_near, k2_far, fov) * w2c; mode 1:
+ * fx, fy, cx, cy = K * (width, height) -- in fp64, rounded once -- and overwrites those fields of the uploaded blocks: no pose value is
+ * read on the host (the reference's .inverse() / get_fov run on its device too).  A singular c2w gives a NaN pose (nothing passes the depth test). */
+int siu3r_raster_project_c2w(const siu3r_raster_cam* cams_host, int V, void* cams_dev, const float* c2w_dev, const float* Kn_dev, float t_scale,
+                             int64_t G, const float* means, const float* cov, int cov_stride, const float* opacities, const float* colors,
+                             int channels, int sh_planar, float* rec, int32_t* radii, int32_t* rect, int32_t* tiles_touched, uint32_t* keys,
+                             uint64_t* stats, void* stream);
 /* stage 2: per view, stable LSD radix sort (4 x 8 bits) of keys_a [V,G] with the Gaussian index as payload; keys_b / ids_a / ids_b
  * [V,G] ping-pong buffers; rs_hist i32 [V,256,nchunks_sort], rs_tot i32 [V,256]; stats: stage 1's counters (device).  Culled Gaussians
  * (key 0xffffffff) leave the sort in its first pass: the result is the (depth, id)-ordered list of the n = stats[v][0] VISIBLE Gaussians in

@@ -49,6 +49,7 @@ typedef struct {
   float t_min;         /* 1e-4 */
   float dilation;      /* 0.3 (K2 low-pass) */
   int32_t nt_post_blend; /* n_touched counts a pixel when the transmittance AFTER (1: `test_T > 0.5f`, MonoGS fork) or BEFORE (0) the blend is > 0.5 */
+  float k2_near, k2_far; /* (device-side pose preparation of the product only: unused here) */
 } raster_cam;
 
 typedef struct {

@@ -78,7 +78,7 @@ class RasterCam(C.Structure):
         ("near_plane", C.c_float), ("far_plane", C.c_float), ("eps2d", C.c_float), ("radius_clip", C.c_float),
         ("extent_sigma", C.c_float), ("opacity_aware_extent", C.c_int32),
         ("alpha_min", C.c_float), ("alpha_max", C.c_float), ("t_min", C.c_float), ("dilation", C.c_float),
-        ("nt_post_blend", C.c_int32),
+        ("nt_post_blend", C.c_int32), ("k2_near", C.c_float), ("k2_far", C.c_float),
     ]
 
 
@@ -130,6 +130,7 @@ SIGNATURES = {
     "siu3r_sh_eval_dp": [_P, _P, _P, _I, _I, _P, _L, _P],
     "siu3r_blend_background_dp": [_P, _P, _P, _I, _L, _P],
     "siu3r_raster_project_dp": [C.POINTER(RasterCam), _I, _P, _P, _P, _L, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "siu3r_raster_project_c2w": [C.POINTER(RasterCam), _I, _P, _P, _P, _F, _L, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "siu3r_lift_ids": [_P, _I, _I, _I, _I, _I, _F, _I, C.c_uint32, _P, _P, _P, _P, _P],
     "siu3r_panoptic_stage1": [_P] * 20 + [_I] * 9 + [_F, _F, _F, C.c_uint32, _P],
     "siu3r_panoptic_qcl": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -1409,10 +1409,108 @@ __global__ void cam_pose_kernel(Cam* cams, int V, const float* viewmats, const f
   cams[v].cy = Ks[9 * v + 5];
 }
 
+// Both families, pose handed over as the REFERENCE holds it (gaussian_renderer.py:29-41): camera-to-world extrinsics [V,4,4] and NORMALISED
+// intrinsics [V,3,3] in device memory.  One thread per view derives what the host-side preparation of cuda_splatting.render_cuda /
+// SplattingCUDA.forward computes -- world->camera = inverse(extrinsics with the translation scaled by t_scale, :43-44), the camera centre,
+// K2: field of view from the K^-1 edge rays (utils/projection.py:247-261), tan(fov / 2), the [0, 1]-depth projection matrix
+// (cuda_splatting.py:16-43; near / far from the uploaded block's k2_near / k2_far) and P = Proj * W2C; K3: pixel-unit fx, fy, cx, cy --
+// and writes it into the uploaded camera blocks, so that the host never reads the pose (no .cpu() per render call).  Evaluated in fp64
+// and rounded once: the reference evaluates the same formulas in fp32 on its device; both are parameter preparation, the values agree
+// to fp32 rounding (tests read the finished block back and hand it to the oracle).
+__device__ inline bool inv4x4_d(const double* m, double* o) {
+  double inv[16];
+  inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+  inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+  inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+  inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+  inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+  inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+  inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+  inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+  inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+  inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+  inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+  inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+  inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+  inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+  inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+  inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+  const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+  if (det == 0.0) return false;
+  const double r = 1.0 / det;
+  for (int i = 0; i < 16; ++i) o[i] = inv[i] * r;
+  return true;
+}
+__global__ void cam_pose_c2w_kernel(Cam* cams, int V, const float* c2w, const float* Kn, float t_scale) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  Cam& c = cams[v];
+  double E[16], W[16];
+  for (int i = 0; i < 16; ++i) E[i] = (double)c2w[16 * v + i];
+  // (the reference scales the translation in fp32, gaussian_renderer.py:44: the product is rounded to fp32 first)
+  E[3] = (double)((float)E[3] * t_scale);
+  E[7] = (double)((float)E[7] * t_scale);
+  E[11] = (double)((float)E[11] * t_scale);
+  if (!inv4x4_d(E, W))
+    for (int i = 0; i < 16; ++i) W[i] = __builtin_nan("");  // a singular pose poisons the view instead of rendering something
+  for (int i = 0; i < 16; ++i) c.w2c[i] = (float)W[i];
+  c.campos[0] = (float)E[3];
+  c.campos[1] = (float)E[7];
+  c.campos[2] = (float)E[11];
+  const float* K = Kn + 9 * v;
+  if (c.mode == 0) {
+    // rays K^-1 (x, y, 1) of the four edge midpoints, normalised; fov = acos(left . right), acos(top . bottom)
+    const double a = K[0], b = K[1], cc = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], k = K[8];
+    const double det = a * (e * k - f * h) - b * (d * k - f * g) + cc * (d * h - e * g), rd = 1.0 / det;
+    const double Ki[9] = {(e * k - f * h) * rd, (cc * h - b * k) * rd, (b * f - cc * e) * rd, (f * g - d * k) * rd, (a * k - cc * g) * rd,
+                          (cc * d - a * f) * rd, (d * h - e * g) * rd, (b * g - a * h) * rd, (a * e - b * d) * rd};
+    auto ray = [&](double x, double y, double* r) {
+      r[0] = Ki[0] * x + Ki[1] * y + Ki[2];
+      r[1] = Ki[3] * x + Ki[4] * y + Ki[5];
+      r[2] = Ki[6] * x + Ki[7] * y + Ki[8];
+      const double n = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+      r[0] /= n;
+      r[1] /= n;
+      r[2] /= n;
+    };
+    double l[3], r[3], t[3], bt[3];
+    ray(0.0, 0.5, l);
+    ray(1.0, 0.5, r);
+    ray(0.5, 0.0, t);
+    ray(0.5, 1.0, bt);
+    auto clamp1 = [](double x) { return x > 1.0 ? 1.0 : (x < -1.0 ? -1.0 : x); };
+    const double fov_x = acos(clamp1(l[0] * r[0] + l[1] * r[1] + l[2] * r[2])), fov_y = acos(clamp1(t[0] * bt[0] + t[1] * bt[1] + t[2] * bt[2]));
+    const double tan_x = tan(0.5 * fov_x), tan_y = tan(0.5 * fov_y);
+    c.tanfovx = (float)tan_x;
+    c.tanfovy = (float)tan_y;
+    const double near = c.k2_near, far = c.k2_far;
+    const double top = tan_y * near, right = tan_x * near;
+    double P[16] = {0};
+    P[0] = 2.0 * near / (2.0 * right);
+    P[5] = 2.0 * near / (2.0 * top);
+    P[2] = 0.0;   // (right + left) / (right - left) with left = -right
+    P[6] = 0.0;
+    P[14] = 1.0;
+    P[10] = far / (far - near);
+    P[11] = -(far * near) / (far - near);
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        double s = 0.0;
+        for (int q = 0; q < 4; ++q) s += P[4 * i + q] * W[4 * q + j];
+        c.proj[4 * i + j] = (float)s;
+      }
+  } else {
+    c.fx = K[0] * (float)c.width;
+    c.fy = K[4] * (float)c.height;
+    c.cx = K[2] * (float)c.width;
+    c.cy = K[5] * (float)c.height;
+  }
+}
+
 static int project_impl(const siu3r_raster_cam* cams_host, int V, void* cams_dev, int64_t G, const float* means, const float* cov,
                         int cov_stride, const float* opacities, const float* colors, int channels, int sh_planar, float* rec,
                         int32_t* radii, int32_t* rect, int32_t* tiles_touched, uint32_t* keys, uint64_t* stats, void* stream,
-                        const float* viewmats_dev, const float* Ks_dev);
+                        const float* viewmats_dev, const float* Ks_dev, const float* c2w_dev = nullptr, float t_scale = 1.f);
 
 extern "C" int siu3r_raster_project(const siu3r_raster_cam* cams_host, int V, void* cams_dev, int64_t G, const float* means, const float* cov,
                                     int cov_stride, const float* opacities, const float* colors, int channels, int sh_planar, float* rec,
@@ -1431,10 +1529,22 @@ extern "C" int siu3r_raster_project_dp(const siu3r_raster_cam* cams_host, int V,
                       stream, viewmats_dev, Ks_dev);
 }
 
+extern "C" int siu3r_raster_project_c2w(const siu3r_raster_cam* cams_host, int V, void* cams_dev, const float* c2w_dev, const float* Kn_dev, float t_scale,
+                                        int64_t G, const float* means, const float* cov, int cov_stride, const float* opacities, const float* colors,
+                                        int channels, int sh_planar, float* rec, int32_t* radii, int32_t* rect, int32_t* tiles_touched, uint32_t* keys,
+                                        uint64_t* stats, void* stream) {
+  SIU3R_CHECK(c2w_dev && Kn_dev, "raster_project_c2w: null pose pointer");
+  if (cams_host && V > 0 && cams_host[0].mode == 0)
+    for (int v = 0; v < V; ++v)
+      SIU3R_CHECK(cams_host[v].k2_near > 0.f && cams_host[v].k2_far > cams_host[v].k2_near, "raster_project_c2w: view %d needs 0 < k2_near < k2_far", v);
+  return project_impl(cams_host, V, cams_dev, G, means, cov, cov_stride, opacities, colors, channels, sh_planar, rec, radii, rect, tiles_touched, keys, stats,
+                      stream, nullptr, Kn_dev, c2w_dev, t_scale);
+}
+
 static int project_impl(const siu3r_raster_cam* cams_host, int V, void* cams_dev, int64_t G, const float* means, const float* cov,
                         int cov_stride, const float* opacities, const float* colors, int channels, int sh_planar, float* rec,
                         int32_t* radii, int32_t* rect, int32_t* tiles_touched, uint32_t* keys, uint64_t* stats, void* stream,
-                        const float* viewmats_dev, const float* Ks_dev) {
+                        const float* viewmats_dev, const float* Ks_dev, const float* c2w_dev, float t_scale) {
   if (int rc = check_views(cams_host, V, "raster_project")) return rc;
   SIU3R_CHECK(cams_dev && stats, "raster_project: null pointer");
   SIU3R_CHECK(G >= 0 && G < (1ll << 31), "raster_project: G = %ld out of range", (long)G);
@@ -1454,6 +1564,7 @@ static int project_impl(const siu3r_raster_cam* cams_host, int V, void* cams_dev
     return 2;
   }
   if (viewmats_dev) hipLaunchKernelGGL(cam_pose_kernel, dim3((V + 63) / 64), dim3(64), 0, s, (Cam*)cams_dev, V, viewmats_dev, Ks_dev);
+  if (c2w_dev) hipLaunchKernelGGL(cam_pose_c2w_kernel, dim3((V + 63) / 64), dim3(64), 0, s, (Cam*)cams_dev, V, c2w_dev, Ks_dev, t_scale);
   // SH floats the views of the call may read (the block is loaded once per Gaussian, at the first view that sees it)
   int nf_chunk = 0;
   for (int v = 0; v < V; ++v) {

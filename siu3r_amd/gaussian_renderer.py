@@ -37,16 +37,23 @@ class SplattingCUDA:
                 cam_rot_delta=None, cam_trans_delta=None):
         """reference signature gaussian_renderer.py:29-41.  extrinsics [b,v,4,4] camera-to-world (OpenCV),
         intrinsics [b,v,3,3] normalised.  NOTE (quirk 1, reproduced): means / covariances are rescaled x10 / x100
-        IN PLACE on the Gaussians (:43-46)."""
+        IN PLACE on the Gaussians (:43-46).  Camera tensors on the GPU are consumed there: the x10 translation scale (:44), the inverse,
+        the field of view and the projection matrix are derived inside the projection call (siu3r_raster_project_c2w) -- with
+        deferred_overflow_check the whole forward enqueues without a host synchronisation
+        (tests/test_raster_gpu.py::test_splatting_forward_does_not_synchronise)."""
         b, v, _, _ = extrinsics.shape
-        extrinsics = extrinsics.detach().float().cpu().clone()
-        extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * self.scale_factor
+        on_dev = extrinsics.is_cuda and intrinsics.is_cuda
+        if on_dev:
+            extrinsics, intr, t_scale = extrinsics.detach().float(), intrinsics.detach().float(), self.scale_factor
+        else:
+            extrinsics = extrinsics.detach().float().cpu().clone()
+            extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * self.scale_factor
+            intr, t_scale = intrinsics.detach().float().cpu(), 1.0
         raster.scale_inplace_(gaussians.covariances, self.scale_factor ** 2)
         raster.scale_inplace_(gaussians.means, self.scale_factor)
         near, far = 1.0, self.far * self.scale_factor
         color = depth = None
         all_qc: Optional[List[torch.Tensor]] = None
-        intr = intrinsics.detach().float().cpu()
         if render_color:
             colors, depths = [], []
             for i in range(b):  # each batch item has its own Gaussians; its v views are rendered back to back
@@ -54,7 +61,8 @@ class SplattingCUDA:
                     extrinsics[i], intr[i], torch.full((v,), near), torch.full((v,), far), image_shape,
                     self.background_color[None].repeat(v, 1), gaussians.means[i][None].expand(v, -1, -1),
                     gaussians.covariances[i][None].expand(v, -1, -1, -1), gaussians.harmonics[i][None].expand(v, -1, -1, -1),
-                    gaussians.opacities[i][None].expand(v, -1), check_overflow="deferred" if self.deferred_overflow_check else True)
+                    gaussians.opacities[i][None].expand(v, -1), check_overflow="deferred" if self.deferred_overflow_check else True,
+                    translation_scale=t_scale)
                 colors.append(c_i)
                 depths.append(d_i)
             color = torch.stack(colors).clamp_(0.0, 1.0)  # (:73) clamp is pure data conditioning on the output buffer
@@ -68,14 +76,18 @@ class SplattingCUDA:
                 qcl = gaussians.seg_query_class_logits[i]  # [n, q, c]
                 n, q, c = qcl.shape
                 feats = qcl.reshape(n, q * c)
-                cams = []
-                for j in range(v):
-                    K = intr[i, j].clone()
-                    K[0, :] *= width
-                    K[1, :] *= height
-                    w2c = torch.linalg.inv(extrinsics[i, j])
-                    cams.append(raster.make_cam_k3(w2c, K[0, 0], K[1, 1], K[0, 2], K[1, 2], width, height, near_plane=near, far_plane=far))
-                out = raster.rasterize_views_k3(cams, means, cov6, opac, feats)  # all v views in one call: [v, h, w, q*c]
+                cams, pose = [], None
+                if on_dev:  # frame size and planes only: the pose is taken from the device tensors
+                    cams = [raster.make_cam_k3(torch.eye(4), 1.0, 1.0, 0.0, 0.0, width, height, near_plane=near, far_plane=far) for _ in range(v)]
+                    pose = (extrinsics[i], intr[i], t_scale)
+                else:
+                    for j in range(v):
+                        K = intr[i, j].clone()
+                        K[0, :] *= width
+                        K[1, :] *= height
+                        w2c = torch.linalg.inv(extrinsics[i, j])
+                        cams.append(raster.make_cam_k3(w2c, K[0, 0], K[1, 1], K[0, 2], K[1, 2], width, height, near_plane=near, far_plane=far))
+                out = raster.rasterize_views_k3(cams, means, cov6, opac, feats, pose_c2w=pose)  # all v views in one call: [v, h, w, q*c]
                 # reference layout 'n h w (q c) -> n q c h w' as a view of the channel-last buffer
                 all_qc.append(out["colors"].view(v, height, width, q, c).permute(0, 3, 4, 1, 2))
         return {"render_color": color, "render_depth": depth, "render_qc_logits": all_qc}

@@ -26,14 +26,20 @@ def _set(arr, values):
         arr[i] = float(v)
 
 
-def make_cam_k2(w2c, full_proj, tanfovx, tanfovy, campos, bg, width, height, sh_degree=4, sh_band4=False, nt_post_blend=True) -> RasterCam:
-    """sh_degree -1: the colours handed to the rasterizer are precomputed [G,1,3] values, blended as given (no SH, no clamp)"""
+def make_cam_k2(w2c, full_proj, tanfovx, tanfovy, campos, bg, width, height, sh_degree=4, sh_band4=False, nt_post_blend=True, near=None,
+                far=None) -> RasterCam:
+    """sh_degree -1: the colours handed to the rasterizer are precomputed [G,1,3] values, blended as given (no SH, no clamp).
+    w2c / full_proj / tanfov / campos None + (near, far): the pose comes from device tensors (`pose_c2w` of the rasterize_* calls,
+    siu3r_raster_project_c2w) and only the projection planes travel in the block."""
     c = RasterCam()
     c.mode, c.width, c.height = 0, int(width), int(height)
-    _set(c.w2c, w2c.reshape(-1).tolist())
-    _set(c.proj, full_proj.reshape(-1).tolist())
-    c.tanfovx, c.tanfovy = float(tanfovx), float(tanfovy)
-    _set(c.campos, campos)
+    if w2c is not None:
+        _set(c.w2c, w2c.reshape(-1).tolist())
+        _set(c.proj, full_proj.reshape(-1).tolist())
+        c.tanfovx, c.tanfovy = float(tanfovx), float(tanfovy)
+        _set(c.campos, campos)
+    if near is not None:
+        c.k2_near, c.k2_far = float(near), float(far)
     _set(c.bg, bg)
     c.sh_degree, c.sh_band4, c.k2_znear_cull = int(sh_degree), int(bool(sh_band4)), 0.2
     c.alpha_min, c.alpha_max, c.t_min, c.dilation = 1.0 / 255.0, 0.99, 1e-4, 0.3
@@ -194,9 +200,11 @@ def _pose_dev(pose_dev, V, dev):
 
 
 def _project_sort_bin(cams: Sequence[RasterCam], means, cov, opac, colors, channels, entry_capacity=None, check_overflow=True,
-                      sh_planar=False, pose_dev=None) -> _State:
+                      sh_planar=False, pose_dev=None, pose_c2w=None) -> _State:
     """pose_dev: None, or (viewmats [V,4,4] world->camera, Ks [V,3,3] pixel units) as DEVICE tensors (gsplat family): the kernels take the
-    pose from them (siu3r_raster_project_dp) and `cams` only carries frame size, planes and thresholds."""
+    pose from them (siu3r_raster_project_dp) and `cams` only carries frame size, planes and thresholds.
+    pose_c2w: None, or (extrinsics [V,4,4] camera-to-world, normalised intrinsics [V,3,3], t_scale) as DEVICE tensors + a float, either
+    family: what SplattingCUDA.forward receives; inverse / fov / projection are derived on the device (siu3r_raster_project_c2w)."""
     V, G, dev = len(cams), means.shape[0], means.device
     arr = _cam_array(cams)
     geo = geometry(cams[0].width, cams[0].height, G)
@@ -208,7 +216,13 @@ def _project_sort_bin(cams: Sequence[RasterCam], means, cov, opac, colors, chann
                 stats=torch.empty((V, 4), dtype=torch.int64, device=dev), defer=not check_overflow, cap_d_hint=None)
     st["tiles_touched"] = st["tiles_touched_all"][0]
     lib = _lib.lib()
-    if pose_dev is None:
+    if pose_c2w is not None:
+        e_, k_, t_scale = pose_c2w
+        e_, k_ = st["pose_dev"] = _pose_dev((e_, k_), V, dev)  # (kept with the state: the launches read them asynchronously)
+        check(lib.siu3r_raster_project_c2w(arr, V, _p(st["cams_dev"]), _p(e_), _p(k_), float(t_scale), G, _p(means), _p(cov), _cov_stride(cov), _p(opac),
+                                           _p(colors), channels, int(bool(sh_planar)), _p(st["rec"]), _p(st["radii"]), _p(st["rect"]),
+                                           _p(st["tiles_touched_all"]), _p(st["keys"]), _p(st["stats"]), _stream()))
+    elif pose_dev is None:
         check(lib.siu3r_raster_project(arr, V, _p(st["cams_dev"]), G, _p(means), _p(cov), _cov_stride(cov), _p(opac), _p(colors), channels,
                                        int(bool(sh_planar)), _p(st["rec"]), _p(st["radii"]), _p(st["rect"]), _p(st["tiles_touched_all"]),
                                        _p(st["keys"]), _p(st["stats"]), _stream()))
@@ -298,7 +312,7 @@ def _with_retry(run, entry_capacity, check_overflow):
 
 
 def rasterize_views_k2(cams: Sequence[RasterCam], means, cov6, shs, opacities, want_n_touched=True, entry_capacity=None,
-                       check_overflow=True, sh_planar=False) -> Dict[str, torch.Tensor]:
+                       check_overflow=True, sh_planar=False, pose_c2w=None) -> Dict[str, torch.Tensor]:
     """V views of one Gaussian set.  means [G,3]; cov6 [G,6] (upper triangle) or [G,3,3]; shs [G,ncoef,3], or with sh_planar
     [G,3,25] (Gaussians.harmonics as stored); opacities [G] (fp32, GPU) -> image [V,3,H,W], radii [V,G,2] i32, depth [V,H,W],
     opacity [V,H,W], n_touched [V,G] i32 (None when not wanted) + the call's state."""
@@ -309,7 +323,7 @@ def rasterize_views_k2(cams: Sequence[RasterCam], means, cov6, shs, opacities, w
     ncoef = shs.shape[2] if sh_planar else shs.shape[1]
 
     def run(cap):
-        st = _project_sort_bin(cams, means, cov6, opacities, shs, ncoef, cap, check_overflow, sh_planar)
+        st = _project_sort_bin(cams, means, cov6, opacities, shs, ncoef, cap, check_overflow, sh_planar, pose_c2w=pose_c2w)
         image = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
         depth = torch.empty((V, H, W), dtype=torch.float32, device=dev)
         alpha = torch.empty((V, H, W), dtype=torch.float32, device=dev)
@@ -335,7 +349,7 @@ def tune(key: int, value: int) -> None:
 
 
 def rasterize_views_k3(cams: Sequence[RasterCam], means, cov6, opacities, feats, entry_capacity=None, pair_capacity=None,
-                       check_overflow=True, pose_dev=None, matrix_form=True) -> Dict[str, torch.Tensor]:
+                       check_overflow=True, pose_dev=None, matrix_form=True, pose_c2w=None) -> Dict[str, torch.Tensor]:
     """feats [G,C] -> colors [V,H,W,C], alphas [V,H,W] (+ state).  gsplat semantics: the per-tile lists are materialised once; for
     C >= 32 they are cut per 8 x 8 quadrant and blended on the matrix cores, all channels at once (identical bits for FINITE features).
     matrix_form=False: the 32-channel kernel, whose pixels only ever see the rows that blend into them -- for features that may hold
@@ -349,7 +363,7 @@ def rasterize_views_k3(cams: Sequence[RasterCam], means, cov6, opacities, feats,
     H, W, Cc = cams[0].height, cams[0].width, feats.shape[1]
 
     def run(cap):
-        st = _project_sort_bin(cams, means, cov6, opacities, None, 0, cap, check_overflow, pose_dev=pose_dev)
+        st = _project_sort_bin(cams, means, cov6, opacities, None, 0, cap, check_overflow, pose_dev=pose_dev, pose_c2w=pose_c2w)
         st["cap_d_hint"] = int(pair_capacity) if pair_capacity else default_pair_capacity(G)
         out = torch.empty((V, H, W, Cc), dtype=torch.float32, device=dev)
         alpha = torch.empty((V, H, W), dtype=torch.float32, device=dev)

@@ -492,6 +492,99 @@ def test_splatting_cuda_colour_against_oracle():
         assert float(np.abs(dep[v] - ref["depth"]).max()) <= 5e-5 * max(1.0, float(ref["depth"].max()))
 
 
+def _splat_inputs(seed=17, H=96, W=128, G=6000, V=3, q=3):
+    from siu3r_amd.gaussians_types import Gaussians
+
+    means, cov, opac, sh = random_scene(G, seed=seed, spread=0.15, depth=(0.15, 0.8), scale=(0.001, 0.01))
+    qcl = torch.randn(G, q, 21, generator=torch.Generator().manual_seed(seed + 1))
+    mk = lambda: Gaussians(means=means[None].cuda(), covariances=cov[None].cuda(), harmonics=sh[None].cuda(), opacities=opac[None].cuda(), scales=None,
+                           rotations=None, seg_query_class_logits=[qcl.cuda()])
+    ext = torch.stack([look_at_camera(s_, 0.02) for s_ in range(V)])[None]
+    K = default_K()[None, None].repeat(1, V, 1, 1)
+    return mk, ext, K
+
+
+def test_splatting_forward_with_the_camera_tensors_on_the_gpu():
+    """SplattingCUDA.forward with extrinsics / intrinsics as GPU tensors (what the pipeline holds, gaussian_renderer.py:29-41): inverse, x10
+    translation scale, field of view and projection matrix are derived on the device (siu3r_raster_project_c2w, fp64 rounded once).  The
+    finished camera blocks are read back: they agree with the host preparation to fp32 rounding, and the host path fed with exactly those
+    blocks renders the identical bits -- i.e. the device route changes the camera's last bits, nothing else.  Against the host route
+    itself the images agree to the sensitivity of a frame to such a pose change."""
+    import ctypes as C
+
+    from siu3r_amd import _lib, cuda_splatting as cs, raster
+    from siu3r_amd.gaussian_renderer import SplattingCUDA
+
+    H, W, V = 96, 128, 3
+    mk, ext, K = _splat_inputs(H=H, W=W, V=V)
+    host = SplattingCUDA().forward(mk(), ext, K, (H, W), render_color=True, render_qc_logits=True)
+    devo = SplattingCUDA().forward(mk(), ext.cuda(), K.cuda(), (H, W), render_color=True, render_qc_logits=True)
+    for k in ("render_color", "render_depth"):
+        d = (host[k] - devo[k]).abs()
+        assert float(d.mean()) <= 2e-6 * max(1.0, float(host[k].abs().max())) and float((d > 1e-3 * max(1.0, float(host[k].abs().max()))).float().mean()) < 1e-3, k
+    d = (host["render_qc_logits"][0] - devo["render_qc_logits"][0]).abs()
+    assert float(d.mean()) <= 1e-5 and float((d > 1e-3).float().mean()) < 1e-3
+    # the camera blocks the device derived, K2 family
+    g = mk()
+    raster.scale_inplace_(g.covariances, 100.0)
+    raster.scale_inplace_(g.means, 10.0)
+    near, far = torch.full((V,), 1.0), torch.full((V,), 1000.0)
+    bg = torch.zeros(V, 3)
+    args = (near, far, (H, W), bg, g.means[0][None].expand(V, -1, -1), g.covariances[0][None].expand(V, -1, -1, -1), g.harmonics[0][None].expand(V, -1, -1, -1),
+            g.opacities[0][None].expand(V, -1))
+    img_d, dep_d, aux = cs.render_cuda(ext[0].cuda(), K[0].cuda(), *args, return_aux=True, translation_scale=10.0)
+    st = aux[0]["state"]
+    blocks = st["cams_dev"].cpu().numpy().tobytes()
+    cams = []
+    for v in range(V):
+        c = _lib.RasterCam.from_buffer_copy(blocks[v * C.sizeof(_lib.RasterCam):(v + 1) * C.sizeof(_lib.RasterCam)])
+        e = ext[0, v].clone()
+        e[:3, 3] *= 10.0
+        fov = cs.get_fov(K[0, v][None])
+        tan = (0.5 * fov).tan()[0]
+        proj = cs.get_projection_matrix(torch.tensor([1.0]), torch.tensor([1000.0]), fov[:, 0], fov[:, 1])[0]
+        w2c = torch.linalg.inv(e)
+        full = proj @ w2c
+        assert np.allclose(np.array(c.w2c), w2c.reshape(-1).numpy(), rtol=2e-6, atol=2e-6)
+        assert np.allclose(np.array(c.proj), full.reshape(-1).numpy(), rtol=5e-6, atol=5e-6)
+        assert abs(c.tanfovx - float(tan[0])) <= 1e-6 and abs(c.tanfovy - float(tan[1])) <= 1e-6
+        assert np.allclose(np.array(c.campos), e[:3, 3].numpy(), rtol=1e-7, atol=0)
+        cams.append(c)
+    same = raster.rasterize_views_k2(cams, g.means[0], g.covariances[0], g.harmonics[0], g.opacities[0], want_n_touched=True, sh_planar=True)
+    assert torch.equal(same["image"], img_d) and torch.equal(same["depth"], dep_d)
+    assert torch.equal(same["radii"], aux[0]["radii"]) and torch.equal(same["n_touched"], aux[0]["n_touched"])
+
+
+def test_splatting_forward_does_not_synchronise():
+    """SURVEY section 8(b) "no hidden syncs": with the camera tensors on the GPU and the deferred overflow check, SplattingCUDA.forward
+    (colour + depth + the q x 21 logit maps need the synchronous check, so: colour + depth) enqueues its work without a single
+    synchronising torch call -- torch.cuda.set_sync_debug_mode("error") raises on .cpu() / .item() / blocking copies."""
+    from siu3r_amd.gaussian_renderer import SplattingCUDA
+
+    H, W, V = 96, 128, 3
+    mk, ext, K = _splat_inputs(H=H, W=W, V=V)
+    ext_d, K_d = ext.cuda(), K.cuda()
+    r = SplattingCUDA(deferred_overflow_check=True)
+    warm = r.forward(mk(), ext_d, K_d, (H, W), render_color=True)   # (first call: buffer-size hints, pinned staging)
+    r.check_pending()
+    g = mk()
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        out = r.forward(g, ext_d, K_d, (H, W), render_color=True)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    r.check_pending()
+    assert torch.equal(out["render_color"], warm["render_color"]) and torch.equal(out["render_depth"], warm["render_depth"])
+    # the host-tensor route does synchronise when handed GPU tensors' values (.cpu()): the mode would catch it
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        with pytest.raises(RuntimeError):
+            ext_d.cpu()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+
+
 @pytest.mark.parametrize("case", ["a", "b"])
 def test_lifting_on_reference_generated_fixtures(case):
     """siu3r_lift_ids (wave-per-pixel reduction, guarded atomicMin) on tests/golden/lifting_{a,b}.npz, the vectors produced by executing the
