@@ -373,56 +373,143 @@ __global__ void dwconv_gelu_kernel(const void* x, void* y, int dtype, const floa
 struct MsdShapes {
   int h[4], w[4], start[4];
 };
-__global__ void msdeform_kernel(const void* value, int v_dtype, const float* offs_aw, const float* ref, MsdShapes sh,
-                                void* out, int out_dtype, int B, int S, int Q, int heads, int d, int L, int P) {
+// LT, PT > 0: levels / points known at compile time -- the softmax weights are computed once (the generic form evaluated every expf
+// twice), all loops unroll, the corner tests become weights (an out-of-range corner reads a clamped in-range texel with weight 0: same
+// sums, no divergent skips) and the compiler issues a point's four 16-byte gathers together.  LT = 0: any L <= 4, any P.
+template <int LT, int PT>
+__global__ __launch_bounds__(256, 4) void msdeform_kernel(const void* value, int v_dtype, const float* offs_aw, const float* ref, MsdShapes sh,
+                                                       void* out, int out_dtype, int B, int S, int Q, int heads, int d, int L, int P, int qb) {
   const int D4 = d >> 2;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)B * Q * heads * D4) return;
-  const int dc = (int)(idx % D4) * 4;
-  int64_t r = idx / D4;
-  const int hd = (int)(r % heads);
-  r /= heads;
-  const int q = (int)(r % Q);
-  const int b = (int)(r / Q);
-  const int LP = L * P;
-  const float* row = offs_aw + ((int64_t)b * Q + q) * (heads * LP * 3);
-  const float* offs = row + hd * LP * 2;
-  const float* logit = row + heads * LP * 2 + hd * LP;
-  float mx = -INFINITY;
-  for (int i = 0; i < LP; ++i) mx = fmaxf(mx, logit[i]);
-  float den = 0.f;
-  for (int i = 0; i < LP; ++i) den += expf(logit[i] - mx);
-  f32x4v acc;
+  int dc, hd, q, b;
+  if (qb > 0) {
+    // a workgroup = qb = 256 / D4 CONSECUTIVE queries of ONE head: neighbouring queries sample neighbouring texels of the same 4 d-byte
+    // head slice (L1 hits: with the (query, head)-major order below a wave's eight rows were eight heads of one query, no two of which
+    // share a line), and with the head as the fastest block index a head's workgroups all land on XCD (head % 8): its L2 holds one
+    // head's slice of `value` instead of all of them
+    const int ql = (int)threadIdx.x / D4;
+    dc = ((int)threadIdx.x - ql * D4) * 4;
+    int64_t blk = blockIdx.x;
+    hd = (int)(blk % heads);
+    blk /= heads;
+    const int nqb = (Q + qb - 1) / qb;
+    q = (int)(blk % nqb) * qb + ql;
+    b = (int)(blk / nqb);
+    if (q >= Q || b >= B) return;
+  } else {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * Q * heads * D4) return;
+    dc = (int)(idx % D4) * 4;
+    int64_t r = idx / D4;
+    hd = (int)(r % heads);
+    r /= heads;
+    q = (int)(r % Q);
+    b = (int)(r / Q);
+  }
+  if constexpr (LT > 0) {
+    constexpr int LP = LT * PT;
+    static_assert(PT == 4, "one 16-byte load per level");
+    const float* row = offs_aw + ((int64_t)b * Q + q) * (heads * LP * 3);
+    const float* offs = row + hd * LP * 2;
+    const float* logit = row + heads * LP * 2 + hd * LP;
+    float mx = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc.v[j] = 0.f;
-  for (int l = 0; l < L; ++l) {
-    const int hh = sh.h[l], ww = sh.w[l];
-    const float rx = ref[((int64_t)q * L + l) * 2 + 0], ry = ref[((int64_t)q * L + l) * 2 + 1];
-    for (int pt = 0; pt < P; ++pt) {
-      const int i = l * P + pt;
-      const float aw = expf(logit[i] - mx) / den;
-      const float locx = rx + offs[i * 2 + 0] / (float)ww;
-      const float locy = ry + offs[i * 2 + 1] / (float)hh;
-      // grid_sample(align_corners=False): pixel = ((2*loc-1 + 1) * size - 1) / 2
-      const float gx = 2.f * locx - 1.f, gy = 2.f * locy - 1.f;
-      const float fx = ((gx + 1.f) * ww - 1.f) * 0.5f, fy = ((gy + 1.f) * hh - 1.f) * 0.5f;
-      const float x0f = floorf(fx), y0f = floorf(fy);
-      const int x0 = (int)x0f, y0 = (int)y0f;
-      const float lx = fx - x0f, ly = fy - y0f;
-      const float wgt[4] = {(1.f - lx) * (1.f - ly), lx * (1.f - ly), (1.f - lx) * ly, lx * ly};
+    for (int l = 0; l < LT; ++l) {
+      const float4 t = *(const float4*)(logit + 4 * l);
+      mx = fmaxf(fmaxf(mx, fmaxf(t.x, t.y)), fmaxf(t.z, t.w));
+    }
+    float den = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
-        if (xx < 0 || xx >= ww || yy < 0 || yy >= hh) continue;
-        const int64_t s = sh.start[l] + (int64_t)yy * ww + xx;
-        const f32x4v v = load4(value, v_dtype, (((int64_t)b * S + s) * heads + hd) * d + dc);
-        const float wk = wgt[k] * aw;
+    for (int l = 0; l < LT; ++l) {
+      const float4 t = *(const float4*)(logit + 4 * l);
+      den += expf(t.x - mx);
+      den += expf(t.y - mx);
+      den += expf(t.z - mx);
+      den += expf(t.w - mx);
+    }
+    f32x4v acc;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc.v[j] += v.v[j] * wk;
+    for (int j = 0; j < 4; ++j) acc.v[j] = 0.f;
+    const int64_t vb = (int64_t)b * S;
+#pragma unroll 1
+    for (int l = 0; l < LT; ++l) {  // (a level at a time: fully unrolled, the scheduler precomputes every point's addresses and spills)
+      const int hh = sh.h[l], ww = sh.w[l], st0 = sh.start[l];
+      const float rx = ref[((int64_t)q * LT + l) * 2 + 0], ry = ref[((int64_t)q * LT + l) * 2 + 1];
+      const float4 lg = *(const float4*)(logit + 4 * l);
+      const float4 oa = *(const float4*)(offs + 8 * l), ob = *(const float4*)(offs + 8 * l + 4);
+      const float e4[4] = {lg.x, lg.y, lg.z, lg.w};
+      const float o8[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
+      f32x4v v[4][4];
+      float wk[4][4];
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        const float aw = expf(e4[pt] - mx) / den;
+        const float locx = rx + o8[pt * 2 + 0] / (float)ww;
+        const float locy = ry + o8[pt * 2 + 1] / (float)hh;
+        const float gx = 2.f * locx - 1.f, gy = 2.f * locy - 1.f;
+        const float fx = ((gx + 1.f) * ww - 1.f) * 0.5f, fy = ((gy + 1.f) * hh - 1.f) * 0.5f;
+        const float x0f = floorf(fx), y0f = floorf(fy);
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const float lx = fx - x0f, ly = fy - y0f;
+        const float wgt[4] = {(1.f - lx) * (1.f - ly), lx * (1.f - ly), (1.f - lx) * ly, lx * ly};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+          const bool ok = xx >= 0 && xx < ww && yy >= 0 && yy < hh;
+          const int xc = min(max(xx, 0), ww - 1), yc = min(max(yy, 0), hh - 1);
+          const int s_ = st0 + yc * ww + xc;
+          v[pt][k] = load4(value, v_dtype, ((vb + s_) * heads + hd) * d + dc);
+          wk[pt][k] = ok ? wgt[k] * aw : 0.f;
+        }
+      }
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc.v[j] += v[pt][k].v[j] * wk[pt][k];
+    }
+    store4(out, out_dtype, (((int64_t)b * Q + q) * heads + hd) * d + dc, acc);
+  } else {
+    const int LP = L * P;
+    const float* row = offs_aw + ((int64_t)b * Q + q) * (heads * LP * 3);
+    const float* offs = row + hd * LP * 2;
+    const float* logit = row + heads * LP * 2 + hd * LP;
+    float mx = -INFINITY;
+    for (int i = 0; i < LP; ++i) mx = fmaxf(mx, logit[i]);
+    float den = 0.f;
+    for (int i = 0; i < LP; ++i) den += expf(logit[i] - mx);
+    f32x4v acc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc.v[j] = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const int hh = sh.h[l], ww = sh.w[l];
+      const float rx = ref[((int64_t)q * L + l) * 2 + 0], ry = ref[((int64_t)q * L + l) * 2 + 1];
+      for (int pt = 0; pt < P; ++pt) {
+        const int i = l * P + pt;
+        const float aw = expf(logit[i] - mx) / den;
+        const float locx = rx + offs[i * 2 + 0] / (float)ww;
+        const float locy = ry + offs[i * 2 + 1] / (float)hh;
+        // grid_sample(align_corners=False): pixel = ((2*loc-1 + 1) * size - 1) / 2
+        const float gx = 2.f * locx - 1.f, gy = 2.f * locy - 1.f;
+        const float fx = ((gx + 1.f) * ww - 1.f) * 0.5f, fy = ((gy + 1.f) * hh - 1.f) * 0.5f;
+        const float x0f = floorf(fx), y0f = floorf(fy);
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const float lx = fx - x0f, ly = fy - y0f;
+        const float wgt[4] = {(1.f - lx) * (1.f - ly), lx * (1.f - ly), (1.f - lx) * ly, lx * ly};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+          if (xx < 0 || xx >= ww || yy < 0 || yy >= hh) continue;
+          const int64_t s = sh.start[l] + (int64_t)yy * ww + xx;
+          const f32x4v v = load4(value, v_dtype, (((int64_t)b * S + s) * heads + hd) * d + dc);
+          const float wk = wgt[k] * aw;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc.v[j] += v.v[j] * wk;
+        }
       }
     }
+    store4(out, out_dtype, (((int64_t)b * Q + q) * heads + hd) * d + dc, acc);
   }
-  store4(out, out_dtype, (((int64_t)b * Q + q) * heads + hd) * d + dc, acc);
 }
 
 // ================================ GroupNorm (NHWC) ==============================================
@@ -794,7 +881,16 @@ extern "C" int siu3r_msdeform_sample(const void* value, int v_dtype, const float
     start += sh.h[l] * sh.w[l];
   }
   SIU3R_CHECK(start == S, "msdeform_sample: spatial shapes sum %d != S=%d", start, S);
-  hipLaunchKernelGGL(msdeform_kernel, grid1d((int64_t)B * Q * heads * (d / 4)), dim3(256), 0, (hipStream_t)stream, value, v_dtype, offs_aw, ref, sh, out, out_dtype, B, S, Q, heads, d, L, P);
+  const int D4 = d / 4;
+  const int qb = (256 % D4 == 0) ? 256 / D4 : 0;  // queries per workgroup (0: the flat thread order)
+  const dim3 grid = qb ? dim3((unsigned)((int64_t)B * ((Q + qb - 1) / qb) * heads)) : grid1d((int64_t)B * Q * heads * D4);
+  const bool al = (((uintptr_t)offs_aw) & 15) == 0 && P == 4;  // (rows of heads * L * 4 * 3 floats: every head's slice is 16-byte aligned)
+#define SIU3R_MSD(LT_, PT_) hipLaunchKernelGGL((msdeform_kernel<LT_, PT_>), grid, dim3(256), 0, (hipStream_t)stream, value, v_dtype, offs_aw, ref, sh, out, out_dtype, B, S, Q, heads, d, L, P, qb)
+  if (al && L == 1) SIU3R_MSD(1, 4);
+  else if (al && L == 3) SIU3R_MSD(3, 4);
+  else if (al && L == 4) SIU3R_MSD(4, 4);
+  else SIU3R_MSD(0, 0);
+#undef SIU3R_MSD
   SIU3R_LAUNCH_CHECK("siu3r_msdeform_sample");
   return 0;
 }

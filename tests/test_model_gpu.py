@@ -37,6 +37,9 @@ def _setup(H, W, B=1):
     return _STATE[key]
 
 
+ELEMENTWISE_FRAC_TOL, ELEMENTWISE_WORST_TOL = 0.10, 0.25  # see _report
+
+
 def _errs(got, ref):
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     assert got.shape == ref.shape, (got.shape, ref.shape)
@@ -54,6 +57,11 @@ def _report(name, got, ref, tol_max, tol_l2, fails):
     r = ref.detach().float().cpu()
     rel, frac = elementwise_rel(got.detach().float().cpu(), r, float(r.abs().max()))
     ok = math.isfinite(mx) and mx <= tol_max and l2 <= tol_l2
+    # the tail, asserted at what the data supports (round 6; 147 bf16x3 comparisons of one GPU run: at most 6.6 % of a tensor's elements
+    # above 1e-3 -- covariances and rotations, whose near-zero entries sit a thousand times below the tensor's range -- worst element
+    # 9.5e-2): in the 1e-3 mode at least 90 % of the elements are within 1e-3 element-wise and none is off by more than 0.25
+    if tol_max <= 1e-3:
+        ok = ok and frac <= ELEMENTWISE_FRAC_TOL and rel <= ELEMENTWISE_WORST_TOL
     print(f"[model-parity] {name:34s} max_norm_err={mx:.3e} rel_l2={l2:.3e} elementwise_rel worst={rel:.3e} (>1e-3: {frac:.3%}) {'ok' if ok else 'FAIL'}")
     if not ok:
         fails.append((name, mx, l2))
