@@ -761,12 +761,13 @@ class CroCoViTAdapter:
         le = ctx.w.v("adapter.level_embed")
         n2, n3, n4 = 4 * h * w, h * w, h * w // 4
         cc = torch.empty((Z, n2 + n3 + n4, 1024), dtype=torch.float32, device=ctx.dev)
-        c1 = ops.linear(c1, ctx.w.linear(sp + ".fc1"), out_dtype=torch.float32)  # [Z,4h,4w,1024]
+        # (c1 = fc1(c1) [Z,4h,4w,1024] is only ever read through the pixel decoder's lateral 1 x 1 convolution: finish() applies the
+        # composed 64 -> 256 map instead and materialises the 1024-channel map on request only)
         # level_embed is folded into the fc biases (vit_adapter.py:387-391)
         ops.linear(c2.view(Z, n2, -1), ctx.w.linear(sp + ".fc2", key=sp + ".fc2+le", extra_bias=le[0]), out=cc[:, :n2])
         ops.linear(c3.view(Z, n3, -1), ctx.w.linear(sp + ".fc3", key=sp + ".fc3+le", extra_bias=le[1]), out=cc[:, n2:n2 + n3])
         ops.linear(c4.view(Z, n4, -1), ctx.w.linear(sp + ".fc4", key=sp + ".fc4+le", extra_bias=le[2]), out=cc[:, n2 + n3:])
-        return dict(c1=c1, cc=cc, outs=[], dims=(Z, Hi, Wi, h, w, n2, n3, n4), ref=self._ref(Hi, Wi))
+        return dict(c1_feat=c1, cc=cc, outs=[], dims=(Z, Hi, Wi, h, w, n2, n3, n4), ref=self._ref(Hi, Wi))
 
     def interact(self, a, i, x):
         """interaction i (vit_adapter.py:393-418): the extractor(s) that read encoder block ADAPTER_IDX[i]'s tokens x."""
@@ -777,23 +778,59 @@ class CroCoViTAdapter:
                 a["cc"] = self._extractor(f"adapter.interactions.3.extra_extractors.{j}", a["cc"], a["ref"], x, h, w)
         a["outs"].append(x.view(Z, h, w, -1))  # the block's patch tokens as an NHWC map, read in place (batch-strided: the intrinsics token follows each item)
 
-    def finish(self, a):
+    LATERAL = "mask2former.model.pixel_decoder.adapter_1.0"  # the only consumer of f1 (video_seg_decoder.py: the FPN lateral of the 1/4 level)
+
+    def _lateral_weights(self):
+        """f1 = BN1(resize_x4(x1) + ConvT_up(c2) + fc1(c1)) (vit_adapter.py:420-436) is read by ONE layer, the pixel decoder's lateral
+        1 x 1 convolution 1024 -> 256 -- and everything in between is linear per pixel, so the composition is applied instead:
+            lateral(f1) = resize_x4(Wa x1) + ConvT'(c2) + Wc c1_feat + const,   Wa = W_lat diag(s1),  ConvT'[phase] = Wa W_up[phase],
+            Wc = Wa W_fc1 (256 x 64),  const = W_lat b1 + Wa (b_up + b_fc1) + b_lat
+        (a bilinear resize commutes with a per-pixel linear map).  86 GFLOP at 2 x 512^2 become 19 -- the 8192 x 4096 x 1024
+        conv-transpose was the largest single launch of the segmentation chain -- and three 134 MB maps (fc1(c1), the conv-transpose
+        output, f1) are never written.  Composed in fp64, rounded once."""
+        W_ = self.ctx.w
+        key = "adapter.lateral_fused"
+        if key + ".y1" not in W_.lin:
+            d = torch.float64
+            w_lat = W_.t(self.LATERAL + ".weight").reshape(256, -1).to(d)
+            b_lat = W_.t(self.LATERAL + ".bias").to(d) if (self.LATERAL + ".bias") in W_.sd else torch.zeros(256, dtype=d, device=W_.dev)
+            s1, b1 = (t.to(d) for t in W_.bn_affine("adapter.norm1"))
+            w_up, b_up = W_.t("adapter.up.weight").to(d), W_.t("adapter.up.bias").to(d)          # [ci, co, 2, 2]
+            w_fc1 = W_.t("adapter.spm.fc1.weight").reshape(w_up.shape[1], -1).to(d)
+            b_fc1 = W_.t("adapter.spm.fc1.bias").to(d)
+            wa = w_lat * s1[None, :]
+            W_.lin[key + ".y1"] = ops.pack_matrix(wa.float(), None, W_.split)
+            W_.lin[key + ".up"] = ops.pack_conv_transpose(torch.einsum("pc,icyx->ipyx", wa, w_up).float(), None, W_.split)
+            W_.lin[key + ".c1"] = ops.pack_matrix((wa @ w_fc1).float(), (w_lat @ b1 + wa @ (b_up + b_fc1) + b_lat).float(), W_.split)
+        return W_.lin[key + ".y1"], W_.lin[key + ".up"], W_.lin[key + ".c1"]
+
+    def finish(self, a, with_f1: bool = False):
+        """-> [f1 | None, f2, f3, f4]; a["lat1"] = the pixel decoder's lateral convolution of f1 (fp32 [Z,4h,4w,256], before its
+        GroupNorm), computed without f1 (_lateral_weights).  with_f1: also materialise f1 itself (the reference's return value:
+        forward(), intermediates for the parity tests) -- nothing on the model's path reads it."""
         ctx = self.ctx
         Z, Hi, Wi, h, w, n2, n3, n4 = a["dims"]
-        cc, c1 = a["cc"], a["c1"]
-        # bf16 mode: the level-2 slice is copied out as bf16, so that the 8192 x 4096 x 1024 conv-transpose below runs on the LDS-DMA
-        # GEMM instead of the fp32-A kernel (0.34 -> 0.14 ms on the segmentation chain); bf16x3 keeps fp32
-        # the three levels are slices of the token sequence, read in place (batch-strided views)
+        cc = a["cc"]
+        # bf16 mode: the level-2 slice is copied out as bf16, so that the conv-transpose below runs on the LDS-DMA GEMM instead of the
+        # fp32-A kernel; bf16x3 keeps fp32.  The three levels are slices of the token sequence, read in place (batch-strided views)
         c2 = (cc[:, :n2] if ctx.split else cc[:, :n2].to(ctx.act)).view(Z, 2 * h, 2 * w, -1)
         c3 = cc[:, n2:n2 + n3].view(Z, h, w, -1)
         c4 = cc[:, n2 + n3:].view(Z, h // 2, w // 2, -1)
-        c1 = ops.conv_transpose2d(c2, ctx.w.convT("adapter.up"), out_dtype=torch.float32, residual=c1)
         x1, x2, x3, x4 = a["outs"]
-        s1, b1 = ctx.w.bn_affine("adapter.norm1")
+        pw_y1, pw_up, pw_c1 = self._lateral_weights()
+        y1 = ops.linear(x1.view(Z, h * w, -1), pw_y1, out_dtype=torch.float32).view(Z, h, w, 256)
+        t1 = ops.linear(a["c1_feat"].view(Z, 16 * h * w, -1), pw_c1, out_dtype=torch.float32).view(Z, 4 * h, 4 * w, 256)
+        u1 = ops.resize_bilinear(y1, (4 * h, 4 * w), False, addend=t1, out_dtype=torch.float32)
+        a["lat1"] = ops.conv_transpose2d(c2, pw_up, out_dtype=torch.float32, residual=u1)
         s2, b2 = ctx.w.bn_affine("adapter.norm2")
         s3, b3 = ctx.w.bn_affine("adapter.norm3")
         s4, b4 = ctx.w.bn_affine("adapter.norm4")
-        f1 = ops.resize_bilinear(x1, (4 * h, 4 * w), False, addend=c1, ch_scale=s1, ch_shift=b1, out_dtype=ctx.act)
+        f1 = None
+        if with_f1:
+            s1, b1 = ctx.w.bn_affine("adapter.norm1")
+            c1 = ops.linear(a["c1_feat"], ctx.w.linear("adapter.spm.fc1"), out_dtype=torch.float32)  # [Z,4h,4w,1024]
+            c1 = ops.conv_transpose2d(c2, ctx.w.convT("adapter.up"), out_dtype=torch.float32, residual=c1)
+            f1 = ops.resize_bilinear(x1, (4 * h, 4 * w), False, addend=c1, ch_scale=s1, ch_shift=b1, out_dtype=ctx.act)
         f2 = ops.resize_bilinear(x2, (2 * h, 2 * w), False, addend=c2, ch_scale=s2, ch_shift=b2, out_dtype=ctx.act)
         f3 = ops.affine_add(x3, c3, s3, b3, out_dtype=ctx.act)
         f4 = ops.resize_bilinear(x4, (h // 2, w // 2), False, addend=c4, ch_scale=s4, ch_shift=b4, out_dtype=ctx.act)
@@ -804,7 +841,7 @@ class CroCoViTAdapter:
         a = self.spm(img8)
         for i, idx in enumerate(ADAPTER_IDX):
             self.interact(a, i, all_feat[idx])
-        return self.finish(a)
+        return self.finish(a, with_f1=True)
 
     def forward(self, x, all_feat):
         """reference signature (vit_adapter.py:393): returns [f1..f4] as NCHW-shaped (channels-last) tensors."""
@@ -867,10 +904,12 @@ class VideoMask2FormerForVideoSegmentation:
         self.heads = 8
 
     # ---- pixel decoder (video_seg_decoder.py:2072-2196), feats NHWC [N2, h_l, w_l, 1024], strides 4,8,16,32
-    def _pixel_decoder(self, feats):
+    def _pixel_decoder(self, feats, lat1=None):
+        """lat1: adapter_1.0(feats[0]) when the caller already holds it (CroCoViTAdapter.finish composes it without materialising the
+        1024-channel 1/4-resolution map; feats[0] may then be None)"""
         ctx = self.ctx
         pd = "mask2former.model.pixel_decoder"
-        N2 = feats[0].shape[0]
+        N2 = feats[1].shape[0]
         lv = list(feats)[::-1][:3]
         shapes = [(f.shape[1], f.shape[2]) for f in lv]
         S = sum(a * b for a, b in shapes)
@@ -922,9 +961,8 @@ class VideoMask2FormerForVideoSegmentation:
         for (hh, ww) in shapes:
             outs.append(hs[:, o:o + hh * ww].contiguous().view(N2, hh, ww, 256))
             o += hh * ww
-        f0 = feats[0]
-        lat = ops.linear(f0, ctx.w.linear(pd + ".adapter_1.0"), out_dtype=torch.float32)
-        up = ops.resize_bilinear(outs[-1], (f0.shape[1], f0.shape[2]), False)
+        lat = lat1 if lat1 is not None else ops.linear(feats[0], ctx.w.linear(pd + ".adapter_1.0"), out_dtype=torch.float32)
+        up = ops.resize_bilinear(outs[-1], (lat.shape[1], lat.shape[2]), False)
         out = ops.groupnorm(lat, ctx.w.v(pd + ".adapter_1.1.weight"), ctx.w.v(pd + ".adapter_1.1.bias"), addend=up, out_dtype=ctx.act)
         out = ops.conv2d(out, ctx.w.conv(pd + ".layer_1.0"), pad=1, out_dtype=torch.float32)
         out = ops.groupnorm(out, ctx.w.v(pd + ".layer_1.1.weight"), ctx.w.v(pd + ".layer_1.1.bias"), relu=True, out_dtype=ctx.act)
@@ -1048,8 +1086,8 @@ class VideoMask2FormerForVideoSegmentation:
         class_logits = ops.linear(interb, ctx.w.linear("mask2former.class_predictor"), out_dtype=torch.float32)
         return class_logits, masks[-1], masks, inters
 
-    def forward_nhwc(self, feats_nhwc: Sequence[torch.Tensor], B: int, T: int):
-        mask_features, ms = self._pixel_decoder(feats_nhwc)
+    def forward_nhwc(self, feats_nhwc: Sequence[torch.Tensor], B: int, T: int, lat1=None):
+        mask_features, ms = self._pixel_decoder(feats_nhwc, lat1)
         class_logits, mask_cl, all_masks, inters = self._decoder(ms, mask_features, B, T)
         out = VideoMask2FormerForVideoSegmentationOutput(
             loss=None, class_queries_logits=class_logits,
@@ -1105,6 +1143,7 @@ class _Run:
         self.images, self.K = images, K
         self.img_bv = self.img8 = self.enc = self.adapter = self.dstate = self.dec = self.ms = self.seg = self.gaussians = None
         self.gs, self.pts, self.raw = [None, None], [None, None], None
+        self.want_f1 = False  # the adapter's 1024-channel 1/4-resolution map (an inspection output: nothing on the path reads it)
 
 
 class SIU3RModel:
@@ -1227,6 +1266,7 @@ class SIU3RModel:
                 # first call of this shape: eager (packs weights, fills caches) -- and measures the split-K workspace every chain asks for
                 ent = self._graphs[key] = {"graphs": None, "st": None, "slots": {}, "need": need}
             st = _Run(images, K)
+            st.want_f1 = bool(return_intermediates)
 
             def run_eager(name, fn):
                 if eager:
@@ -1288,7 +1328,7 @@ class SIU3RModel:
                 _, _, decs = self.backbone._assemble(st.enc, st.dec)
                 all1 = [t[:, 0, :-1] for t in st.enc["av"]]
                 all2 = [t[:, 1, :-1] for t in st.enc["av"]]
-                self._last = dict(dec1=decs[0], dec2=decs[1], decs=decs, all_feat1=all1, all_feat2=all2, ms=st.ms, pts1=st.pts[0],
+                self._last = dict(dec1=decs[0], dec2=decs[1], decs=decs, all_feat1=all1, all_feat2=all2, ms=st.ms, lat1=st.adapter["lat1"], pts1=st.pts[0],
                                   pts2=st.pts[1], gs_raw1=st.gs[0].reshape(B, H, W, -1), gs_raw2=st.gs[1].reshape(-1, H, W, st.gs[1].shape[-1]), seg_out=st.seg)
             if enable_query_class_logit_lift:
                 return g_, seg_out, masks, infos, qscores
@@ -1488,8 +1528,8 @@ class SIU3RModel:
     def _s_seg(self, st):
         # the adapter is shared by all views (model.py:342-345): one (b,v)-batched pass; Mask2Former sees T = V frames
         B, V, _, H, W = st.images.shape
-        st.ms = self.adapter.finish(st.adapter)
-        st.seg = self.mask2former.forward_nhwc(st.ms, B, V)
+        st.ms = self.adapter.finish(st.adapter, with_f1=st.want_f1)
+        st.seg = self.mask2former.forward_nhwc(st.ms, B, V, lat1=st.adapter["lat1"])
 
     @staticmethod
     def _rest_views(t):
