@@ -85,29 +85,50 @@ __global__ void pp_mask256_kernel(const float* ml, float* out, int BT, int IH, i
   out[idx] = 1.f / (1.f + expf(-v));
 }
 
-template <bool SYS>
+// Bilinear sample of the 256^2 probability volume: PLAIN loads, and arithmetic the compiler cannot pack.
+//
+// Round 4 found the argmax kernel giving ~100 border pixels of a B = 8 batch's first item to a neighbouring segment in one forward of
+// four, with bit-identical inputs; it looked like a stale read of the volume and was worked around with sc0 sc1 loads.  Round 6 took the
+// round-4 code object apart on the tree where it reproduced (tools/pk_hazard_probe.py, tools/probes/pk_hazard/gen.py: the compiler's
+// code and one-edit variants of its assembly, launched behind the stage every forward; profiles/r06_pk_hazard*.txt).  Nothing is stale:
+// the volume is 470 us old when the argmax starts, a NaN-filled or persistent volume changes nothing, and a second and third launch of
+// the same kernel milliseconds later are wrong as often as the first -- each in ITS first workgroups, only while the other streams'
+// (MFMA-dense) kernels share the CUs.  What goes wrong is one instruction of the compiler's inner loop,
+//     v_pk_add_f32 v[18:19], v[18:19], v[20:21] op_sel:[0,1] op_sel_hi:[1,0]
+// an IN-PLACE packed add whose two register pairs were the address operands of this iteration's first two gathers and have since
+// been overwritten with the products: 35-50 % of the forwards with the code as compiled -- also with every wait made vmcnt(0), with 8
+// idle cycles behind every wait or between the dependent packed operations, with scalar products, with reordered loads -- and 0 of 40-120
+// forwards as soon as the add gets a fresh destination, or its operands are registers that never were address operands (the gathers
+// addressed from elsewhere, or the products kept elsewhere), or it is replaced by two scalar adds.  A register-level hazard of packed
+// fp32 on gfx950 that no wait count reaches; the sc0 sc1 loads only moved the timing.  The form below leaves the compiler nothing to
+// pack (every product and sum pinned in its own register by an empty asm; same operations in the same order: identical bits), and
+// tests/test_abi.py checks that no packed-fp32 instruction is left in the two kernels that sample the volume.
 __device__ __forceinline__ float sample256(const float* p256, int64_t base, int MS, int Q, int q, int y0, int y1, int x0,
                                            int x1, float ly, float lx) {
-  // SYSTEM-SCOPE loads (sc0 sc1: past the caches).  Round 4 found pp_argmax_kernel reading STALE values of the mask-probability volume at
-  // B = 8 (419 MB, written by pp_mask256_kernel one launch earlier on the same stream): with six streams on the runtime's four hardware
-  // queues, one forward in four gave ~100 border pixels of item 0 (the first rows of the buffer) to a neighbouring segment, although the
-  // logits, the volume as read back afterwards and a recomputation on the same inputs were bit-identical.  Not reproducible with one
-  // stream or at B <= 2; an event between the two kernels, agent- and system-scope acquire fences at kernel start, a kernel instead of
-  // the memsets, a persistent buffer and reading a private copy of the logits did not help; these loads did (0 of 117 forwards against
-  // ~25 %).  The round-3 code shows the same flake at 2 % (1 of 50).  Root cause not established.
-#define SIU3R_LDP(i) (SYS ? __hip_atomic_load(&p256[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : p256[i])
-  const float v00 = SIU3R_LDP((base + (int64_t)y0 * MS + x0) * Q + q), v01 = SIU3R_LDP((base + (int64_t)y0 * MS + x1) * Q + q);
-  const float v10 = SIU3R_LDP((base + (int64_t)y1 * MS + x0) * Q + q), v11 = SIU3R_LDP((base + (int64_t)y1 * MS + x1) * Q + q);
-#undef SIU3R_LDP
-  return (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+  const float v00 = p256[(base + (int64_t)y0 * MS + x0) * Q + q], v01 = p256[(base + (int64_t)y0 * MS + x1) * Q + q];
+  const float v10 = p256[(base + (int64_t)y1 * MS + x0) * Q + q], v11 = p256[(base + (int64_t)y1 * MS + x1) * Q + q];
+#define SIU3R_PIN(x) asm volatile("" : "+v"(x))
+  float a = (1.f - lx) * v00;
+  SIU3R_PIN(a);
+  float b = lx * v01;
+  SIU3R_PIN(b);
+  float c = (1.f - lx) * v10;
+  SIU3R_PIN(c);
+  float d = lx * v11;
+  SIU3R_PIN(d);
+  float top = a + b;
+  SIU3R_PIN(top);
+  float bot = c + d;
+  SIU3R_PIN(bot);
+  float g = (1.f - ly) * top;
+  SIU3R_PIN(g);
+  float h = ly * bot;
+  SIU3R_PIN(h);
+#undef SIU3R_PIN
+  return g + h;
 }
 
-#ifdef SIU3R_TOOLS_BUILD
-__device__ unsigned long long g_pp_dbg[4];  // probes only: [0] label pixels that differ between two back-to-back argmax passes, [1] NaN reads
-#endif
-
-// grid: (ceil(T*H*W/256), B).  SYS: system-scope loads of the volume (the shipped form, see sample256); false: plain loads (SIU3R_PP_DBG probes)
-template <bool SYS>
+// grid: (ceil(T*H*W/256), B)
 __global__ __launch_bounds__(256) void pp_argmax_kernel(const float* p256, const float* scores, const int32_t* kept_idx,
                                                         const int32_t* n_keep, int32_t* lab_map, int32_t* area,
                                                         int32_t* orig, int T, int H, int W, int MS, int Q,
@@ -133,10 +154,7 @@ __global__ __launch_bounds__(256) void pp_argmax_kernel(const float* p256, const
     int bk = 0;
     for (int k = 0; k < nk; ++k) {
       const int q = kept_idx[b * Q + k];
-      const float wv = sample256<SYS>(p256, base, MS, Q, q, y0, y1, x0, x1, ly, lx) * scores[b * Q + q];
-#ifdef SIU3R_TOOLS_BUILD
-      if (!SYS && wv != wv) atomicAdd(&g_pp_dbg[1], 1ull);  // (probe variant only: a NaN-filled volume read before its writer's values)
-#endif
+      const float wv = sample256(p256, base, MS, Q, q, y0, y1, x0, x1, ly, lx) * scores[b * Q + q];
       if (wv > best) {  // strict: first maximum wins, like torch.argmax
         best = wv;
         bk = k;
@@ -239,7 +257,7 @@ __global__ __launch_bounds__(256) void pp_qcl_kernel(const float* p256, const fl
     src_idx(y, MS, H, y0, y1, ly);
     src_idx(x, MS, W, x0, x1, lx);
     q = kept_idx[b * Q + acc[b * Q + j]];
-    mp = sample256<false>(p256, ((int64_t)b * T + t) * MS * MS, MS, Q, q, y0, y1, x0, x1, ly, lx);  // (the volume's writer finished a host synchronisation ago)
+    mp = sample256(p256, ((int64_t)b * T + t) * MS * MS, MS, Q, q, y0, y1, x0, x1, ly, lx);
   }
   s_mp[threadIdx.x] = mp;
   s_q[threadIdx.x] = q;
@@ -254,20 +272,6 @@ __global__ __launch_bounds__(256) void pp_qcl_kernel(const float* p256, const fl
 }
 
 inline dim3 g1(int64_t n, int blk = 256) { return dim3((unsigned)cdiv64(n, blk)); }
-
-// ---- probes of the round-4 stale read (SIU3R_PP_DBG, tools/label_flake_probe.py): compiled into tools builds only
-// (tools/ab_build.sh <tag> -DSIU3R_TOOLS_BUILD); the shipped library has neither the kernels nor the environment switch
-#ifdef SIU3R_TOOLS_BUILD
-__global__ void pp_dbg_fill_kernel(float* p, int64_t n) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) p[i] = __int_as_float(0x7fc00000);
-}
-__global__ void pp_dbg_diff_kernel(const int32_t* a, const int32_t* b, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && a[i] != b[i]) atomicAdd(&g_pp_dbg[0], 1ull);
-}
-#endif
 
 }  // namespace
 
@@ -287,34 +291,8 @@ extern "C" int siu3r_panoptic_stage1(const float* class_logits, const float* mas
   const int64_t nvol = (int64_t)B * T * mask_size * mask_size * Q;
   const int64_t npix = (int64_t)T * H * W;
   const dim3 ag((unsigned)cdiv64(npix, 256), B);
-#ifdef SIU3R_TOOLS_BUILD
-  // SIU3R_PP_DBG (probes only; bit 0: plain loads in the argmax, bit 1: a stream synchronisation between the volume's writer and the
-  // argmax, bit 2: the volume is NaN-filled before its writer runs, bit 3: the argmax runs twice back to back -- first into `seg` as
-  // scratch -- and the label pixels on which the passes disagree are counted and reported on stderr)
-  static const int dbg = getenv("SIU3R_PP_DBG") ? atoi(getenv("SIU3R_PP_DBG")) : 0;
-  if (dbg & 4) hipLaunchKernelGGL(pp_dbg_fill_kernel, dim3(4096), dim3(256), 0, s, p256, nvol);
   hipLaunchKernelGGL(pp_mask256_kernel, g1(nvol), dim3(256), 0, s, mask_logits_cl, p256, B * T, IH, IW, mask_size, Q);
-  if (dbg & 2) (void)hipStreamSynchronize(s);
-  if (dbg & 8) {
-    hipLaunchKernelGGL(pp_argmax_kernel<false>, ag, dim3(256), 0, s, p256, scores, kept_idx, n_keep, seg, area, orig, T, H, W, mask_size, Q, mask_threshold);
-    hipLaunchKernelGGL(pp_class_kernel, dim3(B), dim3(64), 0, s, class_logits, probs, scores, labels, kept_idx, n_keep, Q, C, threshold, area, orig);  // (counters back to zero)
-  }
-  if (dbg & 1)
-    hipLaunchKernelGGL(pp_argmax_kernel<false>, ag, dim3(256), 0, s, p256, scores, kept_idx, n_keep, lab_map, area, orig, T, H, W, mask_size, Q, mask_threshold);
-  else
-    hipLaunchKernelGGL(pp_argmax_kernel<true>, ag, dim3(256), 0, s, p256, scores, kept_idx, n_keep, lab_map, area, orig, T, H, W, mask_size, Q, mask_threshold);
-  if (dbg & 8) hipLaunchKernelGGL(pp_dbg_diff_kernel, g1(npix * B), dim3(256), 0, s, seg, lab_map, npix * B);
-  if (dbg & 12) {
-    unsigned long long h[4] = {0, 0, 0, 0}, z[4] = {0, 0, 0, 0};
-    (void)hipStreamSynchronize(s);
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pp_dbg), sizeof(h));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pp_dbg), z, sizeof(z));
-    if (h[0] || h[1]) fprintf(stderr, "SIU3R_PP_DBG=%d: two back-to-back argmax passes disagree on %llu label pixels; %llu NaN reads of the volume\n", dbg, h[0], h[1]);
-  }
-#else
-  hipLaunchKernelGGL(pp_mask256_kernel, g1(nvol), dim3(256), 0, s, mask_logits_cl, p256, B * T, IH, IW, mask_size, Q);
-  hipLaunchKernelGGL(pp_argmax_kernel<true>, ag, dim3(256), 0, s, p256, scores, kept_idx, n_keep, lab_map, area, orig, T, H, W, mask_size, Q, mask_threshold);
-#endif
+  hipLaunchKernelGGL(pp_argmax_kernel, ag, dim3(256), 0, s, p256, scores, kept_idx, n_keep, lab_map, area, orig, T, H, W, mask_size, Q, mask_threshold);
   hipLaunchKernelGGL(pp_accept_kernel, g1(B, 64), dim3(64), 0, s, area, orig, kept_idx, n_keep, labels, scores, seg_id, seg_label, seg_fused, seg_score, acc_list, n_acc, Q, overlap, fuse_mask, B);
   hipLaunchKernelGGL(pp_write_kernel, dim3((unsigned)cdiv64(npix, 256), B), dim3(256), 0, s, lab_map, seg_id, seg_label, n_keep, seg, sem, ins, npix, Q);
   SIU3R_LAUNCH_CHECK("siu3r_panoptic_stage1");

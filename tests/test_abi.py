@@ -269,6 +269,25 @@ def test_batch_strided_views_host_logic():
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="needs the ROCm LLVM tools")
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="needs the ROCm LLVM tools")
+def test_volume_sampling_kernels_hold_no_packed_fp32():
+    """Round 6 traced the round-4 panoptic label flake to ONE instruction of the compiled argmax loop: an in-place `v_pk_add_f32` on two
+    register pairs that had been the address operands of the iteration's gathers (csrc/postprocess.hip, sample256;
+    tools/pk_hazard_probe.py reproduces it with the old code object and one-edit variants of its assembly).  The two kernels that
+    sample the probability volume must not contain packed-fp32 arithmetic at all (register pins in the source + -fno-slp-vectorize for
+    the file): checked on the shipped object."""
+    asm = _device_disassembly("postprocess.hip")
+    funcs = re.split(r"\n([0-9a-f]+) <([^>]+)>:\n", asm)
+    seen = 0
+    for name, body in zip(funcs[2::3], funcs[3::3]):
+        if "pp_argmax_kernel" in name or "pp_qcl_kernel" in name:
+            seen += 1
+            packed = [l.strip() for l in body.split("\n") if re.search(r"\bv_pk_\w+_f32\b", l)]
+            assert not packed, f"{name}: {packed[:4]}"
+            assert "global_load_dword" in body and " sc0 sc1" not in body, name  # plain loads: nothing was stale
+    assert seen == 2, seen
+
+
 def test_no_store_data_register_is_rewritten_without_a_wait_state():
     """Round 4 found a 16-byte buffer store (SGPR soffset, hence no compiler-inserted s_nop) whose data register the NEXT instruction
     rewrote: on gfx950 the store read the new value in lanes 12..15 of every row of 16 (448 wrong words of 4 M in the pre-split planes of

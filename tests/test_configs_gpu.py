@@ -152,9 +152,11 @@ def test_config5_eight_views_two_million_gaussians_1080p():
 
 
 def test_batch_of_eight_label_maps_are_run_to_run_identical():
-    """Round 4 regression: at B = 8 (six streams on four hardware queues, 419 MB mask-probability volume) one forward in four read stale
-    values of that volume in the panoptic argmax and moved ~100 border pixels of item 0 to a neighbouring segment, with bit-identical
-    logits.  Sixteen consecutive forwards must give identical segmentation / label maps (and logits)."""
+    """Round 4 regression: at B = 8 (six streams on four hardware queues, 419 MB mask-probability volume) one forward in four moved ~100
+    border pixels of item 0 to a neighbouring segment, with bit-identical logits -- the round-3/4 code object of the argmax kernel still
+    does on this tree (tools/pk_hazard_probe.py: 11-21 of 40 forwards): an in-place packed add on former address registers miscomputes in
+    a launch's first workgroups beside the other streams' kernels (csrc/postprocess.hip, sample256), nothing is stale.  Forty consecutive
+    forwards must give identical segmentation / label maps (and logits, and Gaussians)."""
     from golden_utils import default_K, fixture_images
     from siu3r_amd.model import SIU3RModel
 
@@ -166,7 +168,7 @@ def test_batch_of_eight_label_maps_are_run_to_run_identical():
     model = SIU3RModel(_weights(), image_size=(S, S), precision="bf16x3")
     ref, bad = None, []
     with torch.no_grad():
-        for it in range(16):
+        for it in range(40):
             o = model(img, K, enable_query_class_logit_lift=True)
             torch.cuda.synchronize()
             cur = (o[0].instance_labels.clone(), o[0].semantic_labels.clone(), torch.stack(list(o[2])).clone(), o[1].masks_queries_logits.clone(),
@@ -186,9 +188,8 @@ GAUSSIAN_FIELDS = ("means", "covariances", "harmonics", "opacities", "scales", "
 def test_two_hundred_single_pair_forwards_are_identical():
     """Round 5 companion of the batch-of-eight test: every cross-stream hand-off of the forward (six streams, per-chain HIP graphs, the
     panoptic device stage behind Mask2Former, the eager tail) exercised 200 times at B = 1 @256^2: label maps, segmentation, both logit
-    tensors and all six Gaussian fields bit-identical to the first forward.  (The round-4 stale read showed up at B = 8 only; with plain
-    loads in the argmax kernel -- SIU3R_PP_DBG=1 -- round 5 measured 0 differing forwards in 372 at B = 8, and a torch-free repro of the
-    writer -> reader hand-off beside seven streams of graph replays, tools/probes/stale_probe.hip, 0 stale reads in 2400 iterations.)"""
+    tensors and all six Gaussian fields bit-identical to the first forward.  (The round-4 label flake showed up at B = 8 only; round 6
+    traced it to an in-place packed add in the compiled argmax loop, not to any hand-off: csrc/postprocess.hip, sample256.)"""
     from golden_utils import default_K, fixture_images
     from siu3r_amd.model import SIU3RModel
 

@@ -13,7 +13,7 @@ img = torch.cat([fx_, torch.rand(B - 2, 2, 3, S, S, generator=g), fx_.flip(1)]).
 K = default_K().repeat(B, 1, 1, 1).cuda()
 m = SIU3RModel(OW.make_weights(0), image_size=(S, S), precision="bf16x3")
 ref = None
-print(f"# SIU3R_PP_DBG={os.environ.get('SIU3R_PP_DBG')} B={B}", flush=True)
+print(f"# B={B}", flush=True)
 with torch.no_grad():
     for it in range(int(os.environ.get("DBG_N", "40"))):
         o = m(img, K, enable_query_class_logit_lift=True)
