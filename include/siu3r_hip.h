@@ -26,7 +26,7 @@ extern "C" {
 #define SIU3R_F64 3
 
 const char* siu3r_last_error(void);
-#define SIU3R_ABI_VERSION 9 /* 9: siu3r_raster_project_c2w + siu3r_raster_cam.k2_near / k2_far (the reference renderer's own pose tensors, consumed on the device), siu3r_raster_tune (replaces the SIU3R_FEAT_FORM / SIU3R_FEAT_NP environment switches; the shared-batch matrix-core composite is gone: no workspace = 32-channel kernel); 8: LPIPS (siu3r_maxpool2x2s2, siu3r_lpips_layer); 7: device-side poses for the gsplat seam (siu3r_raster_project_dp, siu3r_sh_eval_dp, siu3r_blend_background_dp), precomputed K2 colours (sh_degree < 0), all-channel list composite; 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok), siu3r_attn_params.kv_bxor / kv_x3, siu3r_gemm_params.c_x3_col0; 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
+#define SIU3R_ABI_VERSION 10 /* 10: siu3r_stem7x7_x3 (the Gaussian heads' stem as one dedicated kernel); 9: siu3r_raster_project_c2w + siu3r_raster_cam.k2_near / k2_far (the reference renderer's own pose tensors, consumed on the device), siu3r_raster_tune (replaces the SIU3R_FEAT_FORM / SIU3R_FEAT_NP environment switches; the shared-batch matrix-core composite is gone: no workspace = 32-channel kernel); 8: LPIPS (siu3r_maxpool2x2s2, siu3r_lpips_layer); 7: device-side poses for the gsplat seam (siu3r_raster_project_dp, siu3r_sh_eval_dp, siu3r_blend_background_dp), precomputed K2 colours (sh_degree < 0), all-channel list composite; 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok), siu3r_attn_params.kv_bxor / kv_x3, siu3r_gemm_params.c_x3_col0; 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
 int siu3r_abi_version(void);
 
 /* ---- seam 1: curope.rope_2d(tokens, positions, base, fwd)
@@ -226,6 +226,15 @@ int siu3r_maxpool2x2s2(const void* x, void* y, int dtype, int N, int IH, int IW,
 /* one feature tap of LPIPS (torchmetrics LearnedPerceptualImagePatchSimilarity("vgg"); third-party, absent from the reference tree):
  * dist[p] = sum_c w[c] * (f0[p][c] / sqrt(eps + |f0[p]|^2) - f1[p][c] / sqrt(eps + |f1[p]|^2))^2 for f0, f1 [npix, C] fp32, w [C] */
 int siu3r_lpips_layer(const float* f0, const float* f1, const float* w, float* dist, int64_t npix, int C, float eps, void* stream);
+/* The Gaussian heads' stem, bf16x3: out = ReLU(conv7x7(img, pad 3) + bias) + up_x2_bilinear_align_corners(up_src)
+ * (reference src/models/heads/dpt_gs_head.py:71-77 input_merger = Conv2d(3, 256, 7, 1, 3) + ReLU, :158-162 feat_up(path_1) + direct_img_feat).
+ * img [B, G, H, W, 4] fp32 (RGB + one zero channel); G weight sets (head g of every batch item): wfrag = MFMA B fragments of the
+ * [256, 3, 7, 7] weights, [G][8][14][2][64] x 8 bf16 (siu3r_amd/ops.py pack_stem7: K ordered (ky, kx in 0..7, c in 0..3), hi = bf16(w),
+ * lo = bf16(w - hi)); bias [G, 256] or NULL; up_src [B, G, H/2, W/2, 256] fp32 or NULL; out [B, G, H, W, 256]: fp32 values, or
+ * (planes_out != 0) the pre-split planes a ping-pong GEMM reads as its A operand (siu3r_gemm_params.a_x3: per pixel and 32 channels one
+ * 128-byte line [hi 32 | lo 32]).  H and W multiples of 16.  Same bf16x3 arithmetic as siu3r_gemm's convolution, another K order. */
+int siu3r_stem7x7_x3(const float* img, const void* wfrag, const float* bias, const float* up_src, float* out, int B, int G, int H, int W,
+                     int planes_out, void* stream);
 /* depth-wise 3x3 + bias + GELU over the 3 token scales of the adapter ConvFFN (vit_adapter.py:16-59) */
 int siu3r_dwconv3x3_gelu(const void* x, void* y, int dtype, const float* w9c, const float* bias, int B, int H,
                          int W, int C, void* stream);

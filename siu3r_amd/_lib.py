@@ -84,7 +84,7 @@ class RasterCam(C.Structure):
 
 # name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/siu3r_hip.h.
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
-ABI_VERSION = 9  # SIU3R_ABI_VERSION of include/siu3r_hip.h these ctypes declarations mirror
+ABI_VERSION = 10  # SIU3R_ABI_VERSION of include/siu3r_hip.h these ctypes declarations mirror
 
 SIGNATURES = {
     "siu3r_last_error": [],
@@ -106,6 +106,7 @@ SIGNATURES = {
     "siu3r_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _I, _P],
     "siu3r_maxpool2x2s2": [_P, _P, _I, _I, _I, _I, _I, _P],
     "siu3r_lpips_layer": [_P, _P, _P, _P, _L, _I, _F, _P],
+    "siu3r_stem7x7_x3": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "siu3r_dwconv3x3_gelu": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "siu3r_msdeform_sample": [_P, _I, _P, _P, C.POINTER(C.c_int32), _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "siu3r_groupnorm": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],

@@ -87,6 +87,13 @@ class _Weights:
             self.lin[key] = ops.stack_packed([build(q) for q in prefixes])
         return self.lin[key]
 
+    def stem7(self, names):
+        """the 7x7 image stems `names` (Conv2d(3, 256, 7, 1, 3)) as the B fragments of siu3r_stem7x7_x3 -> (fragments, bias [G, 256] or None)"""
+        key = "stem7:" + "|".join(names)
+        if key not in self.lin:
+            self.lin[key] = ops.pack_stem7([self.t(n + ".weight") for n in names], [self.t(n + ".bias") if (n + ".bias") in self.sd else None for n in names])
+        return self.lin[key]
+
     def merged(self, key, names):
         if key not in self.lin:
             w = torch.cat([self.t(n + ".weight") for n in names], 0)
@@ -588,12 +595,33 @@ class _DPTHead:
         out: optional [B, H*W, 83] fp32 destination (a view of the model's [B, V, H*W, 83] raw-Gaussian buffer)."""
         ctx, p = self.ctx, self.p
         path1 = self.trunk(tokens, H, W)
-        x = ops.conv2d(img_nhwc8, ctx.w.conv(f"{p}.dpt.input_merger.0", cin_pad=ops.image_channels(ctx.split)), pad=3, out_dtype=ctx.act,
-                       act=ACT_RELU, up_src=path1)
-        x = ops.conv2d(x, ctx.w.conv(f"{p}.dpt.head.0"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
+        if _stem_kernel_ok(ctx, img_nhwc8, path1, H, W):  # the dedicated stem kernel (csrc/stem.hip), planes when head.0's plan reads them
+            Bn = img_nhwc8.shape[0]
+            x = torch.empty((Bn, H, W, 256), dtype=torch.float32, device=ctx.dev)
+            w0 = ctx.w.conv(f"{p}.dpt.head.0")
+            xp = ops.Planes(x, storage=x) if _CONV_PLANES else None
+            reads = xp is not None and not ops._NO_PRESPLIT and bool(ops.conv2d(x, w0, pad=1, act=ACT_RELU, dry_run=True).a_x3_ok)
+            wf, wb = ctx.w.stem7((f"{p}.dpt.input_merger.0",))
+            ops.stem7x7_x3(img_nhwc8.view(Bn, 1, H, W, 4), wf, wb, path1.view(Bn, 1, H // 2, W // 2, 256), x.view(Bn, 1, H, W, 256), planes=reads)
+            if reads:
+                xp.valid = xp.only = True
+            x = ops.conv2d(x, w0, pad=1, out_dtype=ctx.act, act=ACT_RELU, a_planes=xp if reads else None)
+        else:
+            x = ops.conv2d(img_nhwc8, ctx.w.conv(f"{p}.dpt.input_merger.0", cin_pad=ops.image_channels(ctx.split)), pad=3, out_dtype=ctx.act,
+                           act=ACT_RELU, up_src=path1)
+            x = ops.conv2d(x, ctx.w.conv(f"{p}.dpt.head.0"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
         if out is not None:
             return ops.linear(x.view(x.shape[0], H * W, -1), ctx.w.linear(f"{p}.dpt.head.4"), out=out)
         return ops.linear(x, ctx.w.linear(f"{p}.dpt.head.4"), out_dtype=torch.float32)  # [B,H,W,83]
+
+
+_STEM_KERNEL = os.environ.get("SIU3R_NO_STEM_KERNEL", "0") != "1"  # A/B switch: the Gaussian stems on the implicit-GEMM convolution again
+
+
+def _stem_kernel_ok(ctx, img, path1, H, W) -> bool:
+    """siu3r_stem7x7_x3 serves the bf16x3 mode: fp32 RGB0 image, fp32 256-channel upsample source, H and W multiples of 16"""
+    return (_STEM_KERNEL and ctx.split and img.dtype == torch.float32 and img.shape[-1] == 4 and img.is_contiguous() and path1.dtype == torch.float32
+            and path1.shape[-1] == 256 and path1.is_contiguous() and H % 16 == 0 and W % 16 == 0)
 
 
 class _DPTHeadPair:
@@ -677,6 +705,14 @@ class _DPTHeadPair:
         # bf16x3: the stem's full-resolution map (268 MB per view) is read by head.0 only: pre-split planes when head.0's plan reads them
         xp = ops.Planes(x, storage=x) if (ctx.split and _CONV_PLANES) else None
         reads = xp is not None and bool(ops.conv2d_grouped(x, w0, pad=1, act=ACT_RELU, dry_run=True).a_x3_ok)
+        if _stem_kernel_ok(ctx, img_nhwc8, path1, H, W):  # both stems in ONE launch of the dedicated kernel (csrc/stem.hip)
+            wf, wb = ctx.w.stem7(tuple(q + ".dpt.input_merger.0" for q in self.ps))
+            reads = reads and not ops._NO_PRESPLIT
+            ops.stem7x7_x3(img_nhwc8, wf, wb, path1, x, planes=reads)
+            if reads:
+                xp.valid = xp.only = True
+            x = ops.conv2d_grouped(x, w0, pad=1, out_dtype=ctx.act, act=ACT_RELU, a_planes=xp if reads else None)
+            return ops.linear_grouped(x.view(B, G, H * W, -1), self._w("linear", ".dpt.head.4"), out=out)
         wrote = []
         for g, q in enumerate(self.ps):  # the stem: 7x7 image convolution + ReLU + x2 upsample-add of this head's path_1
             xg = ops.Planes(x[:, g], storage=x[:, g]) if reads else None

@@ -799,6 +799,41 @@ def pack_image_nhwc8(img: torch.Tensor, out_dtype):
     return pack_image_nhwc(img, out_dtype, 8)
 
 
+def pack_stem7(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]]):
+    """MFMA B fragments of G stem convolutions [256, 3, 7, 7] for siu3r_stem7x7_x3 -> (bf16 [G, 8, 14, 2, 64, 8], fp32 bias [G, 256] or None).
+    K = 224 ordered (ky, kx in 0..7, c in 0..3) with zero weights at kx = 7 and c = 3; fragment of (wave w, K step s): lane l holds channel
+    32 w + l % 32 and k = 16 s + 8 (l // 32) + 0..7; planes hi = bf16(w) (round to nearest even), lo = bf16(w - hi): the split of every packed weight."""
+    frs = []
+    for w in weights:
+        _gpu(w)
+        assert tuple(w.shape) == (256, 3, 7, 7), w.shape
+        wk = torch.zeros((256, 7, 8, 4), dtype=torch.float32, device=w.device)
+        wk[:, :, :7, :3] = w.detach().float().permute(0, 2, 3, 1)
+        wk = wk.reshape(256, 14, 2, 8)                                   # [n, s, chunk, j]: k = 16 s + 8 chunk + j
+        fr = wk.reshape(8, 32, 14, 2, 8).permute(0, 2, 3, 1, 4)          # [wave, s, chunk, n % 32, j]
+        fr = fr.reshape(8, 14, 64, 8)                                    # lane = 32 chunk + n % 32
+        hi = fr.to(torch.bfloat16)
+        lo = (fr - hi.float()).to(torch.bfloat16)
+        frs.append(torch.stack([hi, lo], dim=2))                         # [8, 14, 2, 64, 8]
+    b = None
+    if any(x is not None for x in biases):
+        b = torch.stack([torch.zeros(256, device=weights[0].device) if x is None else x.detach().float() for x in biases]).contiguous()
+    return torch.stack(frs).contiguous(), b
+
+
+def stem7x7_x3(img: torch.Tensor, wfrag: torch.Tensor, bias: Optional[torch.Tensor], up_src: Optional[torch.Tensor], out: torch.Tensor, planes: bool = False):
+    """out = ReLU(conv7x7(img) + bias) + x2 upsample of up_src, G heads in one launch (siu3r_stem7x7_x3): img [B, G, H, W, 4] fp32,
+    up_src [B, G, H/2, W/2, 256], out [B, G, H, W, 256] fp32 -- written as values or, planes=True, as the pre-split planes of Planes."""
+    _gpu(img, wfrag, bias, up_src, out)
+    B, G, H, W, c = img.shape
+    assert c == 4 and img.dtype == torch.float32 and img.is_contiguous() and tuple(wfrag.shape) == (G, 8, 14, 2, 64, 8) and wfrag.dtype == torch.bfloat16
+    assert out.shape == (B, G, H, W, 256) and out.dtype == torch.float32 and out.is_contiguous()
+    assert bias is None or (tuple(bias.shape) == (G, 256) and bias.is_contiguous())
+    assert up_src is None or (up_src.shape == (B, G, H // 2, W // 2, 256) and up_src.dtype == torch.float32 and up_src.is_contiguous())
+    check(_lib.lib().siu3r_stem7x7_x3(_p(img), _p(wfrag), _p(bias), _p(up_src), _p(out), B, G, H, W, 1 if planes else 0, _stream()))
+    return out
+
+
 def image_channels(split: bool) -> int:
     """channels per pixel of the packed input image: the bf16x3 convolutions gather 16-byte chunks = 4 fp32, so RGB + one zero
     channel halves the K extent of the 7x7 / 3x3 stems against the 8 channels the bf16 gather (8 bf16 per chunk) needs"""

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(l, s), f"{s} declared in include/siu3r_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
     assert set(_lib.SIGNATURES) <= set(syms) | {"siu3r_last_error", "siu3r_abi_version"}
-    assert l.siu3r_abi_version() == _lib.ABI_VERSION == 9
+    assert l.siu3r_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_struct_layouts_match_c():

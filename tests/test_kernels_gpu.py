@@ -85,6 +85,41 @@ def test_gemm_rope_epilogue(mode):
     check(f"gemm_rope_epilogue[{name}]", out, ref, tol)
 
 
+def test_stem7x7_x3_dedicated_kernel():
+    """The Gaussian heads' stem as one dedicated kernel (csrc/stem.hip, siu3r_stem7x7_x3): two heads (weight sets) x two batch items, a
+    ragged tile grid (48 x 32: borders on every side of most tiles), with and without the upsample source and the bias, fp32 output and
+    pre-split planes -- against fp32 torch (dpt_gs_head.py:71-77, 158-162), and against the implicit-GEMM convolution it replaces."""
+    ops = _ops()
+    B, G, H, W = 2, 2, 48, 32
+    img = gen(B, G, 3, H, W, seed=61)
+    ws = [gen(256, 3, 7, 7, seed=62 + g, scale=0.2) for g in range(G)]
+    bs = [gen(256, seed=64 + g) for g in range(G)]
+    low = gen(B, G, 256, H // 2, W // 2, seed=66)
+    imgp = ops.pack_image_nhwc(img.flatten(0, 1).cuda(), torch.float32, 4).view(B, G, H, W, 4)
+    lowc = low.permute(0, 1, 3, 4, 2).contiguous().cuda()
+    for use_up, use_bias in ((True, True), (False, True), (True, False)):
+        wfrag, bias = ops.pack_stem7([w.cuda() for w in ws], [b.cuda() if use_bias else None for b in bs])
+        ref = torch.stack([torch.stack([F.relu(F.conv2d(img[b, g][None], ws[g], bs[g] if use_bias else None, padding=3))[0] for g in range(G)]) for b in range(B)])
+        if use_up:
+            ref = ref + F.interpolate(low.flatten(0, 1), scale_factor=2, mode="bilinear", align_corners=True).view(B, G, 256, H, W)
+        ref = ref.permute(0, 1, 3, 4, 2)
+        out = torch.full((B, G, H, W, 256), float("nan"), device="cuda")
+        ops.stem7x7_x3(imgp, wfrag, bias, lowc if use_up else None, out)
+        check(f"stem7x7_x3 (up {use_up}, bias {use_bias})", out, ref, 2e-5)
+        # pre-split planes: per pixel and 32 channels [hi 32 | lo 32] bf16; hi = the upper 16 bits, hi + lo = the value to 2^-16
+        pl = torch.full((B, G, H, W, 256), float("nan"), device="cuda")
+        ops.stem7x7_x3(imgp, wfrag, bias, lowc if use_up else None, pl, planes=True)
+        raw = pl.view(torch.bfloat16).view(B, G, H, W, 8, 2, 32)
+        hi, lo = raw[..., 0, :].float().reshape(B, G, H, W, 256), raw[..., 1, :].float().reshape(B, G, H, W, 256)
+        assert torch.equal(hi.view(torch.int32), out.view(torch.int32) & -65536), "hi plane = the upper 16 bits of the fp32 output"
+        assert ((hi + lo - out).abs() <= out.abs() * 2.0 ** -15 + 1e-30).all()
+        # the implicit-GEMM route (same bf16x3 products, another summation order)
+        for g in range(G):
+            pw = ops.pack_conv(ws[g].cuda(), bs[g].cuda() if use_bias else None, True, cin_pad=4)
+            old = ops.conv2d(imgp[:, g].contiguous(), pw, stride=1, pad=3, act=ops.ACT_RELU, out_dtype=torch.float32, up_src=lowc[:, g].contiguous() if use_up else None)
+            check(f"stem7x7_x3 vs implicit GEMM, head {g}", out[:, g], old, 2e-6)
+
+
 @pytest.mark.parametrize("tile", [1, 2, 3], ids=["pp256x256", "pp256x128", "pp128x128"])
 def test_conv2d_upsample_add_on_ping_pong_tiles(tile):
     """The same fused stem on forced ping-pong tiles with 64 output channels and two images (the fast row pass carries the upsample-add:
