@@ -26,7 +26,7 @@ extern "C" {
 #define SIU3R_F64 3
 
 const char* siu3r_last_error(void);
-#define SIU3R_ABI_VERSION 10 /* 10: siu3r_stem7x7_x3 (the Gaussian heads' stem as one dedicated kernel); 9: siu3r_raster_project_c2w + siu3r_raster_cam.k2_near / k2_far (the reference renderer's own pose tensors, consumed on the device), siu3r_raster_tune (replaces the SIU3R_FEAT_FORM / SIU3R_FEAT_NP environment switches; the shared-batch matrix-core composite is gone: no workspace = 32-channel kernel); 8: LPIPS (siu3r_maxpool2x2s2, siu3r_lpips_layer); 7: device-side poses for the gsplat seam (siu3r_raster_project_dp, siu3r_sh_eval_dp, siu3r_blend_background_dp), precomputed K2 colours (sh_degree < 0), all-channel list composite; 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok), siu3r_attn_params.kv_bxor / kv_x3, siu3r_gemm_params.c_x3_col0; 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
+#define SIU3R_ABI_VERSION 10 /* 10: siu3r_stem7x7_x3 (the Gaussian heads' stem as one dedicated kernel), siu3r_proj_rows_x3 (the heads' last 1 x 1 convolutions as row streams); 9: siu3r_raster_project_c2w + siu3r_raster_cam.k2_near / k2_far (the reference renderer's own pose tensors, consumed on the device), siu3r_raster_tune (replaces the SIU3R_FEAT_FORM / SIU3R_FEAT_NP environment switches; the shared-batch matrix-core composite is gone: no workspace = 32-channel kernel); 8: LPIPS (siu3r_maxpool2x2s2, siu3r_lpips_layer); 7: device-side poses for the gsplat seam (siu3r_raster_project_dp, siu3r_sh_eval_dp, siu3r_blend_background_dp), precomputed K2 colours (sh_degree < 0), all-channel list composite; 6: pre-split bf16x3 activations (siu3r_gemm_params.c_x3 / a_x3, siu3r_gemm_plan_t.a_x3_ok / c_x3_ok), siu3r_attn_params.kv_bxor / kv_x3, siu3r_gemm_params.c_x3_col0; 5: siu3r_raster_sort takes stage 1's counters (culled Gaussians leave the sort), NaN-poisoned views on entry overflow, siu3r_gemm_tune key 4; 4: siu3r_gemm_plan, split-K workspace capacities + self-resetting tickets, tile_cfg; 3: view-batched sort-free rasterizer */
 int siu3r_abi_version(void);
 
 /* ---- seam 1: curope.rope_2d(tokens, positions, base, fwd)
@@ -235,6 +235,14 @@ int siu3r_lpips_layer(const float* f0, const float* f1, const float* w, float* d
  * 128-byte line [hi 32 | lo 32]).  H and W multiples of 16.  Same bf16x3 arithmetic as siu3r_gemm's convolution, another K order. */
 int siu3r_stem7x7_x3(const float* img, const void* wfrag, const float* bias, const float* up_src, float* out, int B, int G, int H, int W,
                      int planes_out, void* stream);
+/* The last 1 x 1 convolution of a DPT head as a row stream, bf16x3: out[z, m, 0..N) = x[z, m, :] W_g^T + b_g, g = z % G
+ * (reference src/models/heads/dpt_block.py:384-391 gs_params head, Conv2d(256, 83, 1); :357-369 regression head, Conv2d(128, 3 + conf, 1)).
+ * x [Z, M, K] fp32 with contiguous rows; wfrag = MFMA B fragments of the G weight matrices [N, K], [G][ceil(N/32)][K/16][2][64] x 8 bf16
+ * (siu3r_amd/ops.py pack_proj); bias [G, 32 ceil(N/32)] zero padded, or NULL; out [Z, M, N] fp32 with row stride ldc floats and
+ * out_z_stride floats between consecutive z (0 = M * ldc).
+ * Instantiations: K = 256 with 65 <= N <= 96, K = 128 with N <= 32.  Same bf16x3 products as siu3r_gemm, another K order. */
+int siu3r_proj_rows_x3(const float* x, const void* wfrag, const float* bias, float* out, int Z, int G, int64_t M, int K, int N, int ldc,
+                       int64_t out_z_stride, void* stream);
 /* depth-wise 3x3 + bias + GELU over the 3 token scales of the adapter ConvFFN (vit_adapter.py:16-59) */
 int siu3r_dwconv3x3_gelu(const void* x, void* y, int dtype, const float* w9c, const float* bias, int B, int H,
                          int W, int C, void* stream);

@@ -107,6 +107,7 @@ SIGNATURES = {
     "siu3r_maxpool2x2s2": [_P, _P, _I, _I, _I, _I, _I, _P],
     "siu3r_lpips_layer": [_P, _P, _P, _P, _L, _I, _F, _P],
     "siu3r_stem7x7_x3": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "siu3r_proj_rows_x3": [_P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
     "siu3r_dwconv3x3_gelu": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "siu3r_msdeform_sample": [_P, _I, _P, _P, C.POINTER(C.c_int32), _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "siu3r_groupnorm": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],

@@ -94,6 +94,13 @@ class _Weights:
             self.lin[key] = ops.pack_stem7([self.t(n + ".weight") for n in names], [self.t(n + ".bias") if (n + ".bias") in self.sd else None for n in names])
         return self.lin[key]
 
+    def proj(self, names):
+        """the 1 x 1 convolutions / Linears `names` as the B fragments of siu3r_proj_rows_x3 -> (fragments, padded bias or None, N)"""
+        key = "proj:" + "|".join(names)
+        if key not in self.lin:
+            self.lin[key] = ops.pack_proj([self.t(n + ".weight") for n in names], [self.t(n + ".bias") if (n + ".bias") in self.sd else None for n in names])
+        return self.lin[key]
+
     def merged(self, key, names):
         if key not in self.lin:
             w = torch.cat([self.t(n + ".weight") for n in names], 0)
@@ -587,7 +594,8 @@ class _DPTHead:
         x = ops.conv2d(x, ctx.w.conv(f"{p}.dpt.head.0"), pad=1, out_dtype=ctx.act)
         x = ops.resize_bilinear(x, (H, W), True)
         x = ops.conv2d(x, ctx.w.conv(f"{p}.dpt.head.2"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
-        xyz = ops.linear(x, ctx.w.linear(f"{p}.dpt.head.4"), out_dtype=torch.float32)
+        xyz = _head4(ctx, (f"{p}.dpt.head.4",), x.view(x.shape[0], 1, H * W, x.shape[-1]))
+        xyz = ops.linear(x, ctx.w.linear(f"{p}.dpt.head.4"), out_dtype=torch.float32) if xyz is None else xyz.view(x.shape[0], H, W, -1)
         return {"pts3d": ops.pts3d_exp_(xyz)}
 
     def forward_gs(self, tokens, img_nhwc8, H, W, out=None):
@@ -610,9 +618,32 @@ class _DPTHead:
             x = ops.conv2d(img_nhwc8, ctx.w.conv(f"{p}.dpt.input_merger.0", cin_pad=ops.image_channels(ctx.split)), pad=3, out_dtype=ctx.act,
                            act=ACT_RELU, up_src=path1)
             x = ops.conv2d(x, ctx.w.conv(f"{p}.dpt.head.0"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
+        Bn = x.shape[0]
+        if out is not None and out.stride(2) == 1:  # [B, H*W, 83]: one view of every batch item of the raw-Gaussian buffer
+            if _head4(ctx, (f"{p}.dpt.head.4",), x.view(Bn, 1, H * W, x.shape[-1]), out=out.unsqueeze(1)) is not None:
+                return out
         if out is not None:
             return ops.linear(x.view(x.shape[0], H * W, -1), ctx.w.linear(f"{p}.dpt.head.4"), out=out)
+        r = _head4(ctx, (f"{p}.dpt.head.4",), x.view(Bn, 1, H * W, x.shape[-1]))
+        if r is not None:
+            return r.view(Bn, H, W, -1)
         return ops.linear(x, ctx.w.linear(f"{p}.dpt.head.4"), out_dtype=torch.float32)  # [B,H,W,83]
+
+
+_PROJ_KERNEL = os.environ.get("SIU3R_NO_PROJ_KERNEL", "0") != "1"  # A/B switch: the heads' last 1 x 1 convolutions on the GEMM again
+
+
+def _head4(ctx, names, x, out=None):
+    """the last 1 x 1 convolution of G DPT heads (names): x [B, G, M, K] fp32 -> [B, G, M, N] fp32 (into `out` when given).  bf16x3: the
+    row-stream kernel (csrc/proj.hip) where it has an instantiation; returns None when the caller should take the GEMM."""
+    B, G, M, K = x.shape
+    n = ctx.w.sd[names[0] + ".weight"].shape[0]
+    if not (_PROJ_KERNEL and ctx.split and x.dtype == torch.float32 and x.is_contiguous() and ops.proj_rows_ok(K, n)):
+        return None
+    wf, wb, n = ctx.w.proj(tuple(names))
+    if out is None:
+        out = torch.empty((B, G, M, n), dtype=torch.float32, device=x.device)
+    return ops.proj_rows_x3(x, wf, wb, n, out)
 
 
 _STEM_KERNEL = os.environ.get("SIU3R_NO_STEM_KERNEL", "0") != "1"  # A/B switch: the Gaussian stems on the implicit-GEMM convolution again
@@ -691,7 +722,9 @@ class _DPTHeadPair:
         B, G = x.shape[:2]
         x = ops.resize_bilinear(x.flatten(0, 1), (H, W), True).view(B, G, H, W, -1)
         x = ops.conv2d_grouped(x, self._w("conv", ".dpt.head.2"), pad=1, out_dtype=ctx.act, act=ACT_RELU)
-        xyz = ops.linear_grouped(x.view(B, G, H * W, -1), self._w("linear", ".dpt.head.4"), out_dtype=torch.float32)
+        xyz = _head4(ctx, tuple(q + ".dpt.head.4" for q in self.ps), x.view(B, G, H * W, -1))
+        if xyz is None:
+            xyz = ops.linear_grouped(x.view(B, G, H * W, -1), self._w("linear", ".dpt.head.4"), out_dtype=torch.float32)
         return ops.pts3d_exp_(xyz).view(B, G, H, W, 3)
 
     def forward_gs(self, tokens, img_nhwc8, H, W, out):
@@ -712,7 +745,7 @@ class _DPTHeadPair:
             if reads:
                 xp.valid = xp.only = True
             x = ops.conv2d_grouped(x, w0, pad=1, out_dtype=ctx.act, act=ACT_RELU, a_planes=xp if reads else None)
-            return ops.linear_grouped(x.view(B, G, H * W, -1), self._w("linear", ".dpt.head.4"), out=out)
+            return self._gs_head4(x.view(B, G, H * W, -1), out)
         wrote = []
         for g, q in enumerate(self.ps):  # the stem: 7x7 image convolution + ReLU + x2 upsample-add of this head's path_1
             xg = ops.Planes(x[:, g], storage=x[:, g]) if reads else None
@@ -723,7 +756,12 @@ class _DPTHeadPair:
             assert all(wrote), "the two stems of a pair run the same plan"
             xp.valid = xp.only = True
         x = ops.conv2d_grouped(x, w0, pad=1, out_dtype=ctx.act, act=ACT_RELU, a_planes=xp if (reads and all(wrote)) else None)
-        return ops.linear_grouped(x.view(B, G, H * W, -1), self._w("linear", ".dpt.head.4"), out=out)
+        return self._gs_head4(x.view(B, G, H * W, -1), out)
+
+    def _gs_head4(self, x, out):
+        """head.4 of both Gaussian heads into the model's raw-Gaussian buffer: the row-stream kernel (bf16x3, contiguous destination), else the grouped GEMM"""
+        r = _head4(self.ctx, tuple(q + ".dpt.head.4" for q in self.ps), x, out=out)
+        return r if r is not None else ops.linear_grouped(x, self._w("linear", ".dpt.head.4"), out=out)
 
 
 class UnifiedGaussianAdapter:

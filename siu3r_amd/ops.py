@@ -834,6 +834,50 @@ def stem7x7_x3(img: torch.Tensor, wfrag: torch.Tensor, bias: Optional[torch.Tens
     return out
 
 
+def pack_proj(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]]):
+    """MFMA B fragments of G projection matrices [N, K] (a 1 x 1 convolution's [N, K, 1, 1] is reshaped) for siu3r_proj_rows_x3 ->
+    (bf16 [G, NB, K/16, 2, 64, 8], fp32 bias [G, 32 NB] or None, N).  Fragment of (column block nb, K step s): lane l holds column
+    32 nb + l % 32 (zero beyond N) and k = 16 s + 8 (l // 32) + 0..7; planes hi = bf16(w), lo = bf16(w - hi)."""
+    frs, N = [], None
+    for w in weights:
+        _gpu(w)
+        w = w.detach().float().reshape(w.shape[0], -1)
+        N, K = w.shape
+        NB = (N + 31) // 32
+        assert K % 16 == 0
+        wp = torch.zeros((NB * 32, K), dtype=torch.float32, device=w.device)
+        wp[:N] = w
+        fr = wp.reshape(NB, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(NB, K // 16, 64, 8)  # [nb, s, lane = 32 chunk + n % 32, j]
+        hi = fr.to(torch.bfloat16)
+        lo = (fr - hi.float()).to(torch.bfloat16)
+        frs.append(torch.stack([hi, lo], dim=2))
+    b = None
+    if any(x is not None for x in biases):
+        NB = frs[0].shape[0]
+        b = torch.zeros((len(weights), NB * 32), dtype=torch.float32, device=frs[0].device)
+        for i, x in enumerate(biases):
+            if x is not None:
+                b[i, :N] = x.detach().float()
+    return torch.stack(frs).contiguous(), b, N
+
+
+def proj_rows_x3(x: torch.Tensor, wfrag: torch.Tensor, bias: Optional[torch.Tensor], n: int, out: torch.Tensor):
+    """out[b, g, m, :n] = x[b, g, m, :] W_g^T + bias_g (siu3r_proj_rows_x3): x [B, G, M, K] fp32 contiguous, out [B, G, M, n] fp32, dense rows,
+    one stride between the (b, g) items (a [B, G] block of the model's raw-Gaussian buffer, or with G == 1 one view of every batch item)."""
+    _gpu(x, wfrag, bias, out)
+    B, G, M, K = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and wfrag.shape[0] == G and wfrag.dtype == torch.bfloat16
+    assert out.shape == (B, G, M, n) and out.dtype == torch.float32 and out.stride(3) == 1 and out.stride(2) >= n
+    zs = out.stride(1) if G > 1 else out.stride(0)
+    assert zs >= M * out.stride(2) and (B == 1 or G == 1 or out.stride(0) == G * zs), (out.shape, out.stride())
+    check(_lib.lib().siu3r_proj_rows_x3(_p(x), _p(wfrag), _p(bias), _p(out), B * G, G, M, K, n, out.stride(2), zs, _stream()))
+    return out
+
+
+def proj_rows_ok(K: int, n: int) -> bool:
+    return (K == 256 and 65 <= n <= 96) or (K == 128 and n <= 32)
+
+
 def image_channels(split: bool) -> int:
     """channels per pixel of the packed input image: the bf16x3 convolutions gather 16-byte chunks = 4 fp32, so RGB + one zero
     channel halves the K extent of the 7x7 / 3x3 stems against the 8 channels the bf16 gather (8 bf16 per chunk) needs"""

@@ -85,6 +85,34 @@ def test_gemm_rope_epilogue(mode):
     check(f"gemm_rope_epilogue[{name}]", out, ref, tol)
 
 
+def test_proj_rows_x3_dedicated_kernel():
+    """The heads' last 1 x 1 convolutions as row streams (csrc/proj.hip, siu3r_proj_rows_x3): two heads x two batch items, a ragged row
+    count, 83 columns of 256 (rows of 83 floats) and 3 columns of 128 -- against fp32 torch and against the GEMM route it replaces."""
+    ops = _ops()
+    for (K, N, M) in ((256, 83, 1000), (128, 3, 777), (128, 4, 4096)):
+        B, G = 2, 2
+        x = gen(B, G, M, K, seed=71)
+        ws = [gen(N, K, seed=72 + g, scale=0.2) for g in range(G)]
+        bs = [gen(N, seed=74 + g) for g in range(G)]
+        assert ops.proj_rows_ok(K, N)
+        wf, bias, n = ops.pack_proj([w.cuda() for w in ws], [b.cuda() for b in bs])
+        out = torch.full((B, G, M, N), float("nan"), device="cuda")
+        ops.proj_rows_x3(x.cuda(), wf, bias, n, out)
+        ref = torch.stack([torch.stack([x[b, g] @ ws[g].t() + bs[g] for g in range(G)]) for b in range(B)])
+        check(f"proj_rows_x3 {M} x {N} x {K}", out, ref, 2e-5)
+        pw = ops.stack_packed([ops.pack_linear(w.cuda(), b.cuda(), True) for w, b in zip(ws, bs)])
+        old = ops.linear_grouped(x.cuda(), pw, out_dtype=torch.float32)
+        check(f"proj_rows_x3 vs grouped GEMM {M} x {N} x {K}", out, old, 2e-6)
+        wf1, _, _ = ops.pack_proj([ws[0].cuda()], [None])  # one head, no bias, B * G = 1
+        o1 = torch.full((1, 1, M, N), float("nan"), device="cuda")
+        ops.proj_rows_x3(x[:1, :1].contiguous().cuda(), wf1, None, n, o1)
+        check(f"proj_rows_x3 (no bias) {M} x {N} x {K}", o1[0, 0], x[0, 0] @ ws[0].t(), 2e-5)
+        buf = torch.full((B, 2, M, N), float("nan"), device="cuda")  # one head for view 1 of every batch item: a strided [B, 1, M, N] destination
+        ops.proj_rows_x3(x[:, 1:2].contiguous().cuda(), wf[1:2].contiguous(), bias[1:2].contiguous(), n, buf[:, 1].unsqueeze(1))
+        check(f"proj_rows_x3 (batch-strided destination) {M} x {N} x {K}", buf[:, 1], ref[:, 1], 2e-5)
+        assert torch.isnan(buf[:, 0]).all()
+
+
 def test_stem7x7_x3_dedicated_kernel():
     """The Gaussian heads' stem as one dedicated kernel (csrc/stem.hip, siu3r_stem7x7_x3): two heads (weight sets) x two batch items, a
     ragged tile grid (48 x 32: borders on every side of most tiles), with and without the upsample source and the bias, fp32 output and

@@ -39,3 +39,20 @@ for npad in (83, 96, 128):
         ts = [graph_time(lambda: ops.linear_grouped(x, pw, out=out), n=5) for _ in range(3)]
         print(f"N = {npad:3d} (row stride {npad * 4} B) tile_cfg {cfg:2d}: {min(ts) * 1e6:7.1f} us   {(x.numel() + out.numel()) * 4 / min(ts) / 1e12:5.2f} TB/s   [{log[-1].kernel.decode()[:60] if cfg == 0 else ''}]")
     ops.gemm_tune(0, 0)
+
+# the dedicated row-stream kernel (csrc/proj.hip)
+wf, bias, n = ops.pack_proj(W, b)
+out = torch.empty(1, 2, M, 83, device="cuda")
+ts = [graph_time(lambda: ops.proj_rows_x3(x, wf, bias, n, out), n=5) for _ in range(3)]
+print(f"siu3r_proj_rows_x3 N = 83, K = 256: {min(ts) * 1e6:7.1f} us   {(x.numel() + out.numel()) * 4 / min(ts) / 1e12:5.2f} TB/s")
+x2 = (torch.rand(1, 2, M, 128, generator=g) * 2 - 1).cuda()
+W2 = [(torch.rand(3, 128, generator=g) * 0.1 - 0.05).cuda() for _ in range(2)]
+b2 = [torch.rand(3, generator=g).cuda() for _ in range(2)]
+wf2, bias2, n2 = ops.pack_proj(W2, b2)
+out2 = torch.empty(1, 2, M, 3, device="cuda")
+ts = [graph_time(lambda: ops.proj_rows_x3(x2, wf2, bias2, n2, out2), n=5) for _ in range(3)]
+print(f"siu3r_proj_rows_x3 N = 3, K = 128: {min(ts) * 1e6:7.1f} us   {(x2.numel() + out2.numel()) * 4 / min(ts) / 1e12:5.2f} TB/s")
+pw3 = ops.stack_packed([ops.pack_linear(w_, b_, True) for w_, b_ in zip(W2, b2)])
+ops.gemm_tune(0, 0)
+ts = [graph_time(lambda: ops.linear_grouped(x2, pw3, out=out2), n=5) for _ in range(3)]
+print(f"grouped GEMM        N = 3, K = 128: {min(ts) * 1e6:7.1f} us")
