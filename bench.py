@@ -113,6 +113,14 @@ def event_ms(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+def _board_id() -> str:
+    """UUID of the GPU this rank runs on (HIP device properties), for comparing runs: the same tree measured 52.3 / 54.6 / 56.0 pairs/s on three boards"""
+    try:
+        return str(torch.cuda.get_device_properties(torch.cuda.current_device()).uuid)
+    except Exception:
+        return "unknown"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -234,7 +242,8 @@ def main():
                    "steps_in_flight": max(1, args.depth),
                    "pipelining": ("forward_async: step n+1 is enqueued (own buffers, graphs and streams) before step n's segment table is read on the host; "
                                   "every step is complete and inside the timed region; results bit-identical to forward()") if args.depth > 1 else "none (synchronous forward per step)",
-                   "n_segments_per_step": total["n_segments"] / max(1, world), "n_gaussians_per_step": total["n_gaussians"] / max(1, world)},
+                   "n_segments_per_step": total["n_segments"] / max(1, world), "n_gaussians_per_step": total["n_gaussians"] / max(1, world),
+                   "board": _board_id()},  # boards of this pool differ by +-3.5 % on the same tree (README): a number is tied to the one it ran on
         "network_tflops_algorithmic": value * FLOPS_PER_PAIR_512 * (H * W / (512 * 512)) / 1e12,
     }
     if second:
