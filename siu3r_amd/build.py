@@ -19,9 +19,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # per-file extras.  gemm_pp*.hip (the ping-pong GEMM: host side + one unit per tile shape and operand mode): its epilogue walks the accumulator blocks in fully unrolled loops whose bodies are large; above the default
 # pragma-unroll size limit the loops stay rolled, the block index becomes a run-time value and the accumulators move to scratch memory
 _PP = ["-mllvm", "-pragma-unroll-threshold=1000000"]
-# postprocess.hip: no packed fp32 from the SLP vectoriser in the kernels that sample the probability volume (the in-place packed add on
-# former address registers that round 6 found miscomputing beside MFMA-dense kernels: csrc/postprocess.hip, sample256; tests/test_abi.py)
-EXTRA_FLAGS = {"gemm_pp.hip": _PP, **{f"gemm_pp_t{n}{m}.hip": _PP for n in (1, 2, 3) for m in "xb"}, "postprocess.hip": ["-fno-slp-vectorize"]}
+# -fno-slp-vectorize for every translation unit: on gfx950 a packed fp32 instruction whose LOW result selects the HIGH half of its second
+# source (op_sel:[x,1]: what the SLP vectoriser emits for horizontal / crossed pairings, e.g. v_pk_add_f32 v, v, v op_sel:[0,1]
+# op_sel_hi:[1,0]) returns a wrong low half in 0.1-0.3 % of its executions while a bf16 MFMA of ANOTHER wave runs on the same SIMD
+# (tools/probes/pk_hazard/xwave2.hip; the round-4 panoptic label flake).  Without the vectoriser no kernel of the library contains that form
+# (tests/test_abi.py walks the shipped code objects).
+_NOSLP = ["-fno-slp-vectorize"]
+FLAGS = FLAGS + _NOSLP
+EXTRA_FLAGS = {"gemm_pp.hip": _PP, **{f"gemm_pp_t{n}{m}.hip": _PP for n in (1, 2, 3) for m in "xb"}}
 
 
 def _sources():

@@ -89,20 +89,18 @@ __global__ void pp_mask256_kernel(const float* ml, float* out, int BT, int IH, i
 //
 // Round 4 found the argmax kernel giving ~100 border pixels of a B = 8 batch's first item to a neighbouring segment in one forward of
 // four, with bit-identical inputs; it looked like a stale read of the volume and was worked around with sc0 sc1 loads.  Round 6 took the
-// round-4 code object apart on the tree where it reproduced (tools/pk_hazard_probe.py, tools/probes/pk_hazard/gen.py: the compiler's
-// code and one-edit variants of its assembly, launched behind the stage every forward; profiles/r06_pk_hazard*.txt).  Nothing is stale:
-// the volume is 470 us old when the argmax starts, a NaN-filled or persistent volume changes nothing, and a second and third launch of
-// the same kernel milliseconds later are wrong as often as the first -- each in ITS first workgroups, only while the other streams'
-// (MFMA-dense) kernels share the CUs.  What goes wrong is one instruction of the compiler's inner loop,
-//     v_pk_add_f32 v[18:19], v[18:19], v[20:21] op_sel:[0,1] op_sel_hi:[1,0]
-// an IN-PLACE packed add whose two register pairs were the address operands of this iteration's first two gathers and have since
-// been overwritten with the products: 35-50 % of the forwards with the code as compiled -- also with every wait made vmcnt(0), with 8
-// idle cycles behind every wait or between the dependent packed operations, with scalar products, with reordered loads -- and 0 of 40-120
-// forwards as soon as the add gets a fresh destination, or its operands are registers that never were address operands (the gathers
-// addressed from elsewhere, or the products kept elsewhere), or it is replaced by two scalar adds.  A register-level hazard of packed
-// fp32 on gfx950 that no wait count reaches; the sc0 sc1 loads only moved the timing.  The form below leaves the compiler nothing to
-// pack (every product and sum pinned in its own register by an empty asm; same operations in the same order: identical bits), and
-// tests/test_abi.py checks that no packed-fp32 instruction is left in the two kernels that sample the volume.
+// round-4 code object apart (tools/pk_hazard_probe.py, tools/probes/pk_hazard/; profiles/r06_pk_hazard.txt; DESIGN.md section 5, round
+// 6, item 9).  Nothing is stale: the volume is 470 us old when the argmax starts, a NaN-filled or persistent volume changes nothing, a
+// second and third launch of the same kernel milliseconds later are wrong as often as the first.  The SLP vectoriser had turned
+// (a + b, c + d) of the lerp into  v_pk_add_f32 v[18:19], v[18:19], v[20:21] op_sel:[0,1] op_sel_hi:[1,0]  -- and on gfx950 a packed fp32
+// instruction whose LOW result selects the HIGH half of its second source (op_sel:[x,1]) returns a wrong low half in 0.1-0.3 % of its
+// executions while a bf16 MFMA of ANOTHER wave runs on the same SIMD (tools/probes/pk_hazard/xwave2.hip: 90 lines, no library code;
+// every other selection is right, an f32 MFMA neighbour is harmless).  The argmax's first workgroups find room on CUs that run the
+// other streams' two-per-CU bf16x3 GEMM workgroups; no wait count, idle cycle or register choice of the victim closes a hazard between
+// waves (one-edit variants of the compiled assembly: only dropping the crossed packed add does).  The library is built without the SLP
+// vectoriser (siu3r_amd/build.py; tools/scan_pk_opsel_hazard.py finds no such instruction in the shipped objects), and the form below
+// leaves nothing to pack in any case: every product and sum pinned in its own register by an empty asm (same operations in the same
+// order: identical bits); tests/test_abi.py checks both.
 __device__ __forceinline__ float sample256(const float* p256, int64_t base, int MS, int Q, int q, int y0, int y1, int x0,
                                            int x1, float ly, float lx) {
   const float v00 = p256[(base + (int64_t)y0 * MS + x0) * Q + q], v01 = p256[(base + (int64_t)y0 * MS + x1) * Q + q];

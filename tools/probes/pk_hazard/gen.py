@@ -55,3 +55,16 @@ ADDR = '\tv_lshl_add_u64 v[18:19], v[6:7], 0, s[20:21]\n\tv_lshl_add_u64 v[20:21
 assert ADDR in base
 variant(11, [(ADDR, ADDR.replace('v[18:19]', 'v[30:31]').replace('v[20:21]', 'v[32:33]').replace('v[22:23]', 'v[34:35]').replace('v[24:25]', 'v[36:37]'))], bump=38)
 print("ok2")
+
+# the neighbour kernel of standalone.py
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", "burn.s", os.path.join(HERE, "burn.hip")], stderr=subprocess.DEVNULL)
+subprocess.check_call([LL + 'clang', '-x', 'assembler', '-target', 'amdgcn-amd-amdhsa', '-mcpu=gfx950', '-c', 'burn.s', '-o', 'burn.o'])
+subprocess.check_call([LL + 'ld.lld', '-shared', 'burn.o', '-o', 'burn.hsaco'])
+print("burn ok")
+
+# the shipped form of the kernel (csrc/postprocess.hip: plain loads, pinned scalar arithmetic, -fno-slp-vectorize) as a stand-alone code object
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "--cuda-device-only", "-S", "-o", "ppa_fix.s", os.path.join(HERE, "ppa_fix.hip")], stderr=subprocess.DEVNULL)
+assert "v_pk_" not in open("ppa_fix.s").read().split("ppa_fix:")[1].split("s_endpgm")[0]
+subprocess.check_call([LL + 'clang', '-x', 'assembler', '-target', 'amdgcn-amd-amdhsa', '-mcpu=gfx950', '-c', 'ppa_fix.s', '-o', 'ppa_fix.o'])
+subprocess.check_call([LL + 'ld.lld', '-shared', 'ppa_fix.o', '-o', 'ppa_fix.hsaco'])
+print("fix ok")
