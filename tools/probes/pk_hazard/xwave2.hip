@@ -21,11 +21,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
   X(8, " op_sel:[1,0] op_sel_hi:[0,1]", 1, 0, 0, 1)
 
 template <int F>
-__device__ __forceinline__ unsigned long long victim(int iters, int lane, int op, unsigned long long* first) {
+__device__ __forceinline__ unsigned long long victim(int iters, int lane, int op, unsigned long long* first, int same_wave) {
   unsigned long long bad = 0;
+  f32x16 vacc;
+  for (int r = 0; r < 16; ++r) vacc[r] = 0.f;
+  bf16x8 va, vb;
+  for (int j = 0; j < 8; ++j) { va[j] = (__bf16)(1.0f + j); vb[j] = (__bf16)(0.25f); }
   f2 a = {1.0f + lane, 2.0f + 0.5f * lane}, b = {10.0f + 3.0f * lane, 20.0f + 7.0f * lane};
   for (int it = 0; it < iters; ++it) {
     f2 d;
+    if (same_wave) vacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, vb, vacc, 0, 0, 0);  // the victim's OWN MFMA right in front of the packed op
     int s0l = 0, s1l = 0, s0h = 1, s1h = 1;
 #define X(ID, TXT, A, B, C, D) \
     if (F == ID) { s0l = A; s1l = B; s0h = C; s1h = D; \
@@ -42,6 +47,7 @@ __device__ __forceinline__ unsigned long long victim(int iters, int lane, int op
     }
     a.x += 0.25f; b.y -= 0.125f; a.y += 0.5f; b.x += 0.375f;
   }
+  if (vacc[0] == 12345.678f) first[2] = 1;
   return bad;
 }
 
@@ -50,7 +56,7 @@ __global__ __launch_bounds__(512) void xwave2(unsigned long long* err, unsigned 
   if (wave < 4) {
     unsigned long long bad = 0;
     switch (form) {
-#define X(ID, TXT, A, B, C, D) case ID: bad = victim<ID>(iters, lane, op, first); break;
+#define X(ID, TXT, A, B, C, D) case ID: bad = victim<ID>(iters, lane, op, first, same_wave); break;
       FORMS(X)
 #undef X
     }
@@ -92,5 +98,17 @@ int main() {
         printf("%s %-52s | %-20s : %10llu wrong of %.3g%s\n", op ? "mul" : "add", fn[form][0] ? fn[form] : " (default selection)", an[agg], h[0], 1024.0 * 4 * 64 * iters,
                h[0] ? (h[1] == 2 ? "  (low half)" : h[1] == 1 ? "  (high half)" : "  (both halves)") : "");
       }
+  // the victim's own MFMAs (no aggressor waves: they idle): is the hazard also inside one wave?
+  for (int op = 0; op < 2; ++op)
+    for (int form = 0; form < 9; ++form) {
+      unsigned long long h[5] = {0, 0, 0, 0, 0};
+      (void)hipMemset(err, 0, 8); (void)hipMemset(first, 0, 32);
+      const int iters = 100000;
+      hipLaunchKernelGGL(xwave2, dim3(1024), dim3(512), 0, 0, err, first, iters, form, op, 3, 1);
+      (void)hipDeviceSynchronize();
+      (void)hipMemcpy(h, err, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(h + 1, first, 32, hipMemcpyDeviceToHost);
+      printf("%s %-52s | %-20s : %10llu wrong of %.3g%s\n", op ? "mul" : "add", fn[form][0] ? fn[form] : " (default selection)", "OWN bf16 MFMA in front", h[0], 1024.0 * 4 * 64 * iters,
+             h[0] ? (h[1] == 2 ? "  (low half)" : h[1] == 1 ? "  (high half)" : "  (both halves)") : "");
+    }
   return 0;
 }
