@@ -105,6 +105,9 @@ __device__ __forceinline__ float sample256(const float* p256, int64_t base, int 
                                            int x1, float ly, float lx) {
   const float v00 = p256[(base + (int64_t)y0 * MS + x0) * Q + q], v01 = p256[(base + (int64_t)y0 * MS + x1) * Q + q];
   const float v10 = p256[(base + (int64_t)y1 * MS + x0) * Q + q], v11 = p256[(base + (int64_t)y1 * MS + x1) * Q + q];
+#ifdef SIU3R_AB_PACKED_LERP  // A/B builds only (tests/test_postprocess_gpu.py documents how): the rounds 3-5 form, which the SLP vectoriser packs
+  return (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+#endif
 #define SIU3R_PIN(x) asm volatile("" : "+v"(x))
   float a = (1.f - lx) * v00;
   SIU3R_PIN(a);
