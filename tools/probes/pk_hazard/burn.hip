@@ -32,6 +32,14 @@ extern "C" __global__ __launch_bounds__(512) void burn_mfma(const uint4* src, fl
 
 // One-wave workgroups of bf16 MFMAs and nothing else: launched 2048-wide they put two MFMA-issuing waves on every SIMD and leave
 // registers, LDS and wave slots for any other kernel's workgroups -- a neighbour that is certain to share SIMDs with them.
+extern "C" __global__ __launch_bounds__(64) void burn_wave_dep(float* sink, int iters) {  // the same with ONE dependent accumulator chain
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  bf16x8 a, b;
+  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(1.0f + j + threadIdx.x); b[j] = (__bf16)(0.5f); }
+  for (int it = 0; it < iters; ++it) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  if (acc[0] == 1234.5f) sink[blockIdx.x] = acc[0];
+}
 extern "C" __global__ __launch_bounds__(64) void burn_wave(float* sink, int iters) {
   f32x16 acc[4];
   for (int j = 0; j < 4; ++j)

@@ -42,6 +42,7 @@ VARS.append("fix"); NAMES["fix"] = "shipped form: no packed arithmetic at all"
 fns["fix"] = load(os.path.join(BUILD, "ppa_fix.hsaco"), "ppa_fix")
 burn = load(os.path.join(BUILD, "burn.hsaco"), "burn_mfma")
 burn_wave = load(os.path.join(BUILD, "burn.hsaco"), "burn_wave")
+burn_wave_dep = load(os.path.join(BUILD, "burn.hsaco"), "burn_wave_dep")
 
 g = torch.Generator(device="cuda").manual_seed(5)
 # a volume with soft segment borders: smooth per-query fields, so that neighbouring queries compete over wide bands (as the real masks do)
@@ -114,7 +115,7 @@ if os.environ.get("PKH_LIB", "1") == "1":
     only = os.environ.get("PKH_ONLY")
     if only:
         LIBN = {k: f for k, f in LIBN.items() if only in k}
-SYN = [(9, "neighbour: one-wave workgroups of bf16 MFMAs, two per SIMD")] if os.environ.get("PKH_ONLY") else [(9, "neighbour: one-wave workgroups of bf16 MFMAs, two per SIMD"), (0, "neighbour: MFMA + LDS reads"), (1, "neighbour: MFMA + LDS reads + vector work"), (3, "neighbour: MFMA + LDS + vector work + global loads")]
+SYN = [(9, "neighbour: one-wave workgroups of bf16 MFMAs, two per SIMD"), (10, "neighbour: one-wave workgroups, ONE dependent MFMA chain each, two per SIMD"), (11, "neighbour: one dependent-chain MFMA wave per SIMD")] if os.environ.get("PKH_ONLY") else [(9, "neighbour: one-wave workgroups of bf16 MFMAs, two per SIMD"), (10, "neighbour: one-wave workgroups, ONE dependent MFMA chain each, two per SIMD"), (0, "neighbour: MFMA + LDS reads"), (1, "neighbour: MFMA + LDS reads + vector work"), (3, "neighbour: MFMA + LDS + vector work + global loads")]
 for mode, what in [(None, "no neighbour")] + SYN + [(k, k) for k in LIBN]:
     wrong = {v: [0, 0] for v in VARS}
     for it in range(N):
@@ -123,6 +124,10 @@ for mode, what in [(None, "no neighbour")] + SYN + [(k, k) for k in LIBN]:
                 LIBN[mode]()
         elif mode == 9:
             launch(burn_wave, (2048, 1), 64, sb.cuda_stream, ctypes.c_void_p(sink.data_ptr()), ctypes.c_int(60000))
+        elif mode == 10:
+            launch(burn_wave_dep, (2048, 1), 64, sb.cuda_stream, ctypes.c_void_p(sink.data_ptr()), ctypes.c_int(120000))
+        elif mode == 11:
+            launch(burn_wave_dep, (1024, 1), 64, sb.cuda_stream, ctypes.c_void_p(sink.data_ptr()), ctypes.c_int(240000))
         elif mode is not None:
             launch(burn, (256, 1), 512, sb.cuda_stream, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(sink.data_ptr()), ctypes.c_int(20000), ctypes.c_int(mode))
         for v in VARS:
