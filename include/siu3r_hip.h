@@ -395,7 +395,7 @@ int siu3r_split_bf16(const float* x, void* hi, void* lo, void* x3, int64_t rows,
  * (reference src/models/mask2former/image_processing_video_mask2former.py:1238-1481) and the label scatter of
  * SIU3RModel.post_process_gaussians (reference src/models/model.py:267-294).
  * class_logits [B,Q,C] fp32; mask_logits_cl [B,T,IH,IW,Q] fp32 (channel-last).  All other pointers are outputs /
- * workspaces: probs [B,Q,C], scores [B,Q], labels/kept_idx [B,Q] i32, n_keep [B] i32, p256 [B,T,ms,ms,Q] fp32,
+ * workspaces: probs [B,Q,C], scores [B,Q], labels/kept_idx [B,Q] i32, n_keep [B] i32, p256 [B,T,Q,ms,ms] fp32 (the ms x ms probability planes of the KEPT queries of an item: plane k < n_keep[b] belongs to query kept_idx[b,k]; the rest is not written),
  * lab_map [B,T,H,W] i32, area/orig [B,Q] i32, per-kept-query table seg_id/seg_label/seg_fused [B,Q] i32 + seg_score
  * [B,Q] fp32, acc_list [B,Q] / n_acc [B] i32, and the maps seg/sem/ins [B,T,H,W] i32.  fuse_mask bit c = class c fuses. */
 int siu3r_panoptic_stage1(const float* class_logits, const float* mask_logits_cl, float* probs, float* scores,

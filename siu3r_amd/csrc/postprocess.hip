@@ -64,16 +64,18 @@ __global__ void pp_class_kernel(const float* logits, float* probs, float* scores
   }
 }
 
-__global__ void pp_mask256_kernel(const float* ml, float* out, int BT, int IH, int IW, int OS, int Q) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)BT * OS * OS * Q) return;
-  // (32-bit index arithmetic: the launcher keeps the volume below 2^31 elements; 64-bit divisions dominated these kernels)
-  unsigned r = (unsigned)idx / (unsigned)Q;
-  const int q = (int)((unsigned)idx - r * (unsigned)Q);
-  unsigned r2 = r / (unsigned)OS;
-  const int ox = (int)(r - r2 * (unsigned)OS);
-  const int bt = (int)(r2 / (unsigned)OS);
-  const int oy = (int)(r2 - (unsigned)bt * (unsigned)OS);
+// The 256 x 256 probability planes of the KEPT queries only, query-major: out[(b, t), k, oy, ox] for k < n_keep[b] (round 6; rounds 2-5
+// wrote all Q queries channel-last: the argmax then gathered one float per 400-byte pixel record -- 64 cache lines per load instruction
+// -- and three quarters of the volume were never read).  A plane is contiguous: the argmax's and the logit volume's bilinear corners
+// of neighbouring pixels sit next to each other.  Same arithmetic per value as before.
+// grid: (ceil(OS * OS / 256), Q, B * T)
+__global__ __launch_bounds__(256) void pp_mask256_kernel(const float* ml, const int32_t* kept_idx, const int32_t* n_keep, float* out, int T, int IH, int IW, int OS, int Q) {
+  const int bt = blockIdx.z, b = bt / T, k = blockIdx.y;
+  if (k >= n_keep[b]) return;
+  const int q = kept_idx[b * Q + k];
+  const unsigned pix = blockIdx.x * 256u + threadIdx.x;
+  if (pix >= (unsigned)(OS * OS)) return;
+  const int oy = (int)(pix / (unsigned)OS), ox = (int)(pix - (unsigned)oy * (unsigned)OS);
   int y0, y1, x0, x1;
   float ly, lx;
   src_idx(oy, IH, OS, y0, y1, ly);
@@ -82,7 +84,7 @@ __global__ void pp_mask256_kernel(const float* ml, float* out, int BT, int IH, i
   const float v00 = ml[(base + (int64_t)y0 * IW + x0) * Q + q], v01 = ml[(base + (int64_t)y0 * IW + x1) * Q + q];
   const float v10 = ml[(base + (int64_t)y1 * IW + x0) * Q + q], v11 = ml[(base + (int64_t)y1 * IW + x1) * Q + q];
   const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
-  out[idx] = 1.f / (1.f + expf(-v));
+  out[((int64_t)bt * Q + k) * OS * OS + pix] = 1.f / (1.f + expf(-v));
 }
 
 // Bilinear sample of the 256^2 probability volume: PLAIN loads, and arithmetic the compiler cannot pack.
@@ -101,10 +103,10 @@ __global__ void pp_mask256_kernel(const float* ml, float* out, int BT, int IH, i
 // vectoriser (siu3r_amd/build.py; tools/scan_pk_opsel_hazard.py finds no such instruction in the shipped objects), and the form below
 // leaves nothing to pack in any case: every product and sum pinned in its own register by an empty asm (same operations in the same
 // order: identical bits); tests/test_abi.py checks both.
-__device__ __forceinline__ float sample256(const float* p256, int64_t base, int MS, int Q, int q, int y0, int y1, int x0,
-                                           int x1, float ly, float lx) {
-  const float v00 = p256[(base + (int64_t)y0 * MS + x0) * Q + q], v01 = p256[(base + (int64_t)y0 * MS + x1) * Q + q];
-  const float v10 = p256[(base + (int64_t)y1 * MS + x0) * Q + q], v11 = p256[(base + (int64_t)y1 * MS + x1) * Q + q];
+// plane: the MS x MS probabilities of one (item, view, kept query)
+__device__ __forceinline__ float sample256(const float* plane, int MS, int y0, int y1, int x0, int x1, float ly, float lx) {
+  const float v00 = plane[y0 * MS + x0], v01 = plane[y0 * MS + x1];
+  const float v10 = plane[y1 * MS + x0], v11 = plane[y1 * MS + x1];
 #ifdef SIU3R_AB_PACKED_LERP  // A/B builds only (tests/test_postprocess_gpu.py documents how): the rounds 3-5 form, which the SLP vectoriser packs
   return (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
 #endif
@@ -150,12 +152,12 @@ __global__ __launch_bounds__(256) void pp_argmax_kernel(const float* p256, const
     float ly, lx;
     src_idx(y, MS, H, y0, y1, ly);
     src_idx(x, MS, W, x0, x1, lx);
-    const int64_t base = ((int64_t)b * T + t) * MS * MS;
+    const int64_t base = ((int64_t)b * T + t) * Q;  // first plane of this (item, view)
     float best = -INFINITY;
     int bk = 0;
     for (int k = 0; k < nk; ++k) {
       const int q = kept_idx[b * Q + k];
-      const float wv = sample256(p256, base, MS, Q, q, y0, y1, x0, x1, ly, lx) * scores[b * Q + q];
+      const float wv = sample256(p256 + (base + k) * MS * MS, MS, y0, y1, x0, x1, ly, lx) * scores[b * Q + q];
       if (wv > best) {  // strict: first maximum wins, like torch.argmax
         best = wv;
         bk = k;
@@ -257,8 +259,9 @@ __global__ __launch_bounds__(256) void pp_qcl_kernel(const float* p256, const fl
     float ly, lx;
     src_idx(y, MS, H, y0, y1, ly);
     src_idx(x, MS, W, x0, x1, lx);
-    q = kept_idx[b * Q + acc[b * Q + j]];
-    mp = sample256(p256, ((int64_t)b * T + t) * MS * MS, MS, Q, q, y0, y1, x0, x1, ly, lx);
+    const int k = acc[b * Q + j];
+    q = kept_idx[b * Q + k];
+    mp = sample256(p256 + (((int64_t)b * T + t) * Q + k) * MS * MS, MS, y0, y1, x0, x1, ly, lx);
   }
   s_mp[threadIdx.x] = mp;
   s_q[threadIdx.x] = q;
@@ -292,7 +295,7 @@ extern "C" int siu3r_panoptic_stage1(const float* class_logits, const float* mas
   const int64_t nvol = (int64_t)B * T * mask_size * mask_size * Q;
   const int64_t npix = (int64_t)T * H * W;
   const dim3 ag((unsigned)cdiv64(npix, 256), B);
-  hipLaunchKernelGGL(pp_mask256_kernel, g1(nvol), dim3(256), 0, s, mask_logits_cl, p256, B * T, IH, IW, mask_size, Q);
+  hipLaunchKernelGGL(pp_mask256_kernel, dim3((unsigned)cdiv64((int64_t)mask_size * mask_size, 256), Q, B * T), dim3(256), 0, s, mask_logits_cl, kept_idx, n_keep, p256, T, IH, IW, mask_size, Q);
   hipLaunchKernelGGL(pp_argmax_kernel, ag, dim3(256), 0, s, p256, scores, kept_idx, n_keep, lab_map, area, orig, T, H, W, mask_size, Q, mask_threshold);
   hipLaunchKernelGGL(pp_accept_kernel, g1(B, 64), dim3(64), 0, s, area, orig, kept_idx, n_keep, labels, scores, seg_id, seg_label, seg_fused, seg_score, acc_list, n_acc, Q, overlap, fuse_mask, B);
   hipLaunchKernelGGL(pp_write_kernel, dim3((unsigned)cdiv64(npix, 256), B), dim3(256), 0, s, lab_map, seg_id, seg_label, n_keep, seg, sem, ins, npix, Q);

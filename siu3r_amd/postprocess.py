@@ -53,7 +53,7 @@ class VideoMask2FormerImageProcessor:
         i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
         f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         probs, scores, labels, kept_idx, n_keep = f32(B, Q, Cc), f32(B, Q), i32(B, Q), i32(B, Q), i32(B)
-        p256 = f32(B, T, MASK_SIZE, MASK_SIZE, Q)
+        p256 = f32(B, T, Q, MASK_SIZE, MASK_SIZE)  # planes of the kept queries (k < n_keep[b]); the rest stays unwritten
         lab_map, area, orig = i32(B, T, H, W), i32(B, Q), i32(B, Q)
         # the tables the host reads, in ONE buffer: [seg_id | seg_label | seg_fused | acc_list | seg_score bits] x [B, Q], then n_keep, n_acc
         tab = i32(5 * B * Q + 2 * B)

@@ -81,6 +81,20 @@ def test_panoptic_postprocess_full_size(target):
     assert tuple(res["query_class_logits"].shape) == tuple(ref["query_class_logits"].shape) and err <= 2e-6, err
 
 
+
+def _old_layout_volume(pend, B, T, Q, MS=256):
+    """the stage's probability planes [B, T, Q, MS, MS] (kept queries only, query-major: round 6) as the channel-last volume
+    [B, T, MS, MS, Q] of rounds 2-5, which the round-3/4 code objects index"""
+    import torch
+    planes, kept, tab = pend["p256"], pend["kept_idx"], pend["tab"]
+    nk = tab[5 * B * Q:5 * B * Q + B]
+    vol = torch.zeros((B, T, MS, MS, Q), dtype=torch.float32, device=planes.device)
+    for b in range(B):
+        n = int(nk[b])
+        vol[b][..., kept[b, :n].long()] = planes[b, :, :n].permute(0, 2, 3, 1)
+    return vol
+
+
 def test_panoptic_stage_beside_bf16_mfma_waves_is_run_to_run_identical():
     """Round 6 regression of the round-4 panoptic label flake: the device stage on one stream (B = 8, soft segment borders: wide bands
     where two queries compete) while a second stream keeps two bf16-MFMA-issuing waves on every SIMD (tools/probes/pk_hazard/burn.hip,
@@ -129,7 +143,7 @@ def test_panoptic_stage_beside_bf16_mfma_waves_is_run_to_run_identical():
     lab0 = torch.zeros(NC, B, T, H, W, dtype=torch.int32, device="cuda")
     scr = torch.zeros(8192, dtype=torch.int32, device="cuda")
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
-    ref, bad, ctl_wrong, prev = None, [], 0, None
+    ref, bad, ctl_wrong, prev, vol_old = None, [], 0, None, None
     try:
         for it in range(100):
             if it:  # (the first launch runs alone: the reference maps)
@@ -137,13 +151,16 @@ def test_panoptic_stage_beside_bf16_mfma_waves_is_run_to_run_identical():
                     bv = [ctypes.c_void_p(sink.data_ptr()), ctypes.c_int(60000)]
                     ba = (ctypes.c_void_p * 2)(*[ctypes.cast(ctypes.byref(v), ctypes.c_void_p) for v in bv])
                     assert hip.hipModuleLaunchKernel(burn, 2048, 1, 1, 64, 1, 1, 0, ctypes.c_void_p(sb.cuda_stream), ba, None) == 0
-            def control(src, c0, c1):  # launches c0 .. c1 - 1 of the control on the buffers of the stage result `src`
+            def control(src, c0, c1):  # launches c0 .. c1 - 1 of the control on the buffers of the stage result `src` (volume: the old layout)
                 for c in range(c0, c1):
-                    vals = [ctypes.c_void_p(src["p256"].data_ptr()), ctypes.c_void_p(src["keep"][2].data_ptr()), ctypes.c_void_p(src["kept_idx"].data_ptr()),
+                    vals = [ctypes.c_void_p(vol_old.data_ptr()), ctypes.c_void_p(src["keep"][2].data_ptr()), ctypes.c_void_p(src["kept_idx"].data_ptr()),
                             ctypes.c_void_p(src["tab"].data_ptr() + 4 * 5 * B * Q), ctypes.c_void_p(lab0[c].data_ptr()), ctypes.c_void_p(scr.data_ptr()), ctypes.c_void_p(scr.data_ptr() + 16384),
                             ctypes.c_int(T), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(256), ctypes.c_int(Q), ctypes.c_float(0.5)]
                     arr = (ctypes.c_void_p * len(vals))(*[ctypes.cast(ctypes.byref(v), ctypes.c_void_p) for v in vals])
                     assert hip.hipModuleLaunchKernel(e0, (T * H * W + 255) // 256, B, 1, 256, 1, 1, 0, ctypes.c_void_p(sa.cuda_stream), arr, None) == 0
+            if e0 is not None and vol_old is None:  # (the inputs are the same every iteration: converted once, from an untimed stage run)
+                vol_old = _old_layout_volume(proc.begin_panoptic(out, threshold=0.5, target_sizes=[(H, W)] * B, label_ids_to_fuse={0, 1}), B, T, Q)
+                torch.cuda.synchronize()
             with torch.cuda.stream(sa):
                 if e0 is not None and prev is not None:
                     control(prev, 0, NC // 2)  # ahead of the stage, on the previous (identical, complete) buffers: beside the first GEMM launches

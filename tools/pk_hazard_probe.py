@@ -53,6 +53,19 @@ def launch(fn, stream, p256, scores, kept, nkeep, lab, T, H, W, MS, Q, thr, gx, 
     arr = (ctypes.c_void_p * len(vals))(*[ctypes.cast(ctypes.byref(v), ctypes.c_void_p) for v in vals])
     rc = hip.hipModuleLaunchKernel(fn, gx, gy, 1, 256, 1, 1, 0, ctypes.c_void_p(stream), arr, None)
     assert rc == 0, rc
+
+def _old_layout_volume(pend, B, T, Q, MS=256):
+    """the stage's probability planes [B, T, Q, MS, MS] (kept queries only, query-major: round 6) as the channel-last volume
+    [B, T, MS, MS, Q] of rounds 2-5, which the round-3/4 code objects index"""
+    import torch
+    planes, kept, tab = pend["p256"], pend["kept_idx"], pend["tab"]
+    nk = tab[5 * B * Q:5 * B * Q + B]
+    vol = torch.zeros((B, T, MS, MS, Q), dtype=torch.float32, device=planes.device)
+    for b in range(B):
+        n = int(nk[b])
+        vol[b][..., kept[b, :n].long()] = planes[b, :, :n].permute(0, 2, 3, 1)
+    return vol
+
 info = {}
 orig_bp = m.processor.begin_panoptic
 def wrapped(*a, **k):
@@ -61,9 +74,11 @@ def wrapped(*a, **k):
     Bq, T, Q, Cc, IH, IW, H, W = p["dims"]
     nkeep_ptr = p["tab"].data_ptr() + 4 * 5 * Bq * Q
     st = torch.cuda.current_stream().cuda_stream
+    vol = _old_layout_volume(p, Bq, T, Q)  # (round 6: the stage keeps query-major planes of the kept queries; the code objects index the old volume)
+    info["vol_keepalive"] = vol
     for v in range(NV):
-        launch(funcs[v], st, p["p256"].data_ptr(), scores.data_ptr(), p["kept_idx"].data_ptr(), nkeep_ptr, labs[v].data_ptr(), T, H, W, 256, Q, 0.5, (T * H * W + 255) // 256, Bq)
-    info.update(dims=p["dims"], p256=p["p256"].data_ptr(), scores=scores.data_ptr(), kept=p["kept_idx"].data_ptr(), lab=lab_map.data_ptr(), tab=p["tab"].data_ptr())
+        launch(funcs[v], st, vol.data_ptr(), scores.data_ptr(), p["kept_idx"].data_ptr(), nkeep_ptr, labs[v].data_ptr(), T, H, W, 256, Q, 0.5, (T * H * W + 255) // 256, Bq)
+    info.update(dims=p["dims"], p256=vol.data_ptr(), scores=scores.data_ptr(), kept=p["kept_idx"].data_ptr(), lab=lab_map.data_ptr(), tab=p["tab"].data_ptr())
     return p
 m.processor.begin_panoptic = wrapped
 ALLN = {8: "e8 packed sum of v[18:21] into a FRESH destination (not in place)", 9: "e9 products in fresh registers, packed sum IN PLACE on them", 10: "e10 only the packed add replaced by two scalar adds", 11: "e11 gathers addressed from v[30:37]: v[18:21] never address operands, products still land there"}
