@@ -58,6 +58,22 @@ __device__ __forceinline__ float exp_det(float x) {
   p = __builtin_fmaf(p, f, 1.0f);
   return ldexpf(p, (int)n);
 }
+// the same value without a branch (the early return becomes a select; x > 0 or NaN: whatever exp_det returns, i.e. the same chain)
+__device__ __forceinline__ float exp_det_sel(float x) {
+  const float y = x * 1.4426950408889634f;
+  const float n = floorf(y + 0.5f);
+  const float f = y - n;
+  float p = 1.52527338e-5f;
+  p = __builtin_fmaf(p, f, 1.54035304e-4f);
+  p = __builtin_fmaf(p, f, 1.33335581e-3f);
+  p = __builtin_fmaf(p, f, 9.61812911e-3f);
+  p = __builtin_fmaf(p, f, 5.55041087e-2f);
+  p = __builtin_fmaf(p, f, 2.40226507e-1f);
+  p = __builtin_fmaf(p, f, 6.93147181e-1f);
+  p = __builtin_fmaf(p, f, 1.0f);
+  const float r = ldexpf(p, (int)n);
+  return x < -87.0f ? 0.0f : r;
+}
 // Mahalanobis half-form q = 0.5 (a dx^2 + c dy^2) + b dx dy of a pixel offset, in the shared fused order
 __device__ __forceinline__ float conic_sigma(float ca, float cb, float cc, float dx, float dy) {
   const float q = __builtin_fmaf(cc * dy, dy, (ca * dx) * dx);
@@ -693,7 +709,7 @@ __global__ __launch_bounds__(256) void composite_rgb_kernel(const Cam* __restric
   __shared__ __attribute__((aligned(16))) float s_co[STG][4];
   __shared__ __attribute__((aligned(16))) float s_c[STG][4];
   __shared__ int s_wcnt[4][FK];
-  __shared__ unsigned short s_list[4][STG];
+  __shared__ __attribute__((aligned(16))) unsigned short s_list[4][STG];
   const int v = blockIdx.y;
   const Cam& c = cams[v];
   const int tile = blockIdx.x, tx = tile % geo.gw, ty = tile / geo.gw;
@@ -796,43 +812,66 @@ __global__ __launch_bounds__(256) void composite_rgb_kernel(const Cam* __restric
       if (hit) s_list[wave][nq + __popcll(mh & ((1ull << lane) - 1ull))] = (unsigned short)i;
       nq += __popcll(mh);
     }
-    // The walk is a chain of dependent LDS reads (list index -> record) in front of ~50 cycles of arithmetic per entry: the NEXT entry's
-    // index and record are fetched while the current one is evaluated (registers only; same entries, same order, same arithmetic)
+    // The walk.  Rounds 2-5 evaluated one entry per iteration behind four nested early-outs (power > 0, x < -87 inside the exponential,
+    // alpha < alpha_min, saturation): ~55 vector + ~35 scalar / branch instructions per (wave, entry), nine of the vector ones register
+    // moves that rotated the software prefetch, and the early-outs almost never fire wave-wide (a listed entry nearly always has SOME
+    // pixel of the quadrant inside its footprint).  Now: alpha of every lane evaluated branch-free (same operations in the same order
+    // per lane: identical bits), ONE predicated block for the lanes that blend, four entries per iteration in two alternating register
+    // sets (records of the next pair and indices of the pair after it in flight while a pair is evaluated; nothing to rotate).
+    // Entries at or behind nq are dead (index 0, never blended).
     if (SIU3R_COMP_DBG & 1) nq = 0;
-    int jn = nq > 0 ? (int)s_list[wave][0] : 0;
-    float4 An = *(const float4*)s_a[jn], Qn = *(const float4*)s_co[jn];
-    int jnn = nq > 1 ? (int)s_list[wave][1] : 0;
-    for (int ii = 0; !done && ii < nq; ++ii) {
-      const int j = jn;
-      const float4 A = An, Q = Qn;
-      jn = jnn;
-      An = *(const float4*)s_a[jn];
-      Qn = *(const float4*)s_co[jn];
-      jnn = ii + 2 < nq ? (int)s_list[wave][ii + 2] : 0;
+    const unsigned short* lst = s_list[wave];
+    auto blend = [&](const int j, const float4 A, const float4 Q, const bool live) {
       const float dx = A.x - pxf, dy = A.y - pyf;
       const float power = -conic_sigma(Q.x, Q.y, Q.z, dx, dy);
-      if (power > 0.0f) continue;
-      const float a = fminf(alpha_max, Q.w * exp_det(power));
-      if (a < alpha_min) continue;
+      const float a = fminf(alpha_max, Q.w * exp_det_sel(power));
       const float nT = __builtin_fmaf(-T, a, T);  // T (1 - a)
-      if (K3 ? (nT <= t_min) : (nT < t_min)) {
-        done = true;
-        continue;
+      const bool reach = live && !done && !(power > 0.0f) && !(a < alpha_min);
+      const bool sat = reach && (K3 ? (nT <= t_min) : (nT < t_min));
+      done = done || sat;
+      if (reach && !sat) {
+        const float w = a * T;
+        const float4 Cj = *(const float4*)s_c[j];
+        C0 = __builtin_fmaf(Cj.x, w, C0);
+        C1 = __builtin_fmaf(Cj.y, w, C1);
+        C2 = __builtin_fmaf(Cj.z, w, C2);
+        D = __builtin_fmaf(A.z, w, D);
+        O += w;
+        if (NT) {
+          // pixels that count this Gaussian: ballot over the lanes that reached this point, one LDS add per wave
+          const bool cnt = (nt_post ? nT : T) > 0.5f;
+          const unsigned long long mc = __ballot(cnt);
+          if (cnt && lane == (int)__ffsll((long long)mc) - 1) atomicAdd((int*)&s_c[j][3], (int)__popcll(mc));
+        }
+        T = nT;
       }
-      const float w = a * T;
-      const float4 Cj = *(const float4*)s_c[j];
-      C0 = __builtin_fmaf(Cj.x, w, C0);
-      C1 = __builtin_fmaf(Cj.y, w, C1);
-      C2 = __builtin_fmaf(Cj.z, w, C2);
-      D = __builtin_fmaf(A.z, w, D);
-      O += w;
-      if (NT) {
-        // pixels that count this Gaussian: ballot over the lanes that reached this point, one LDS add per wave
-        const bool cnt = (nt_post ? nT : T) > 0.5f;
-        const unsigned long long mc = __ballot(cnt);
-        if (cnt && lane == (int)__ffsll((long long)mc) - 1) atomicAdd((int*)&s_c[j][3], (int)__popcll(mc));
-      }
-      T = nT;
+    };
+    // (two 16-bit indices per 32-bit read: the lists start 4-byte aligned and pairs start at even positions)
+    auto pair_idx = [&](int i, int& ja, int& jb) {
+      const unsigned u = i < nq ? *(const unsigned*)(lst + i) : 0u;
+      ja = (int)(u & 0xffffu);
+      jb = i + 1 < nq ? (int)(u >> 16) : 0;
+    };
+    int ja0, jb0, ja1, jb1;
+    pair_idx(0, ja0, jb0);
+    pair_idx(2, ja1, jb1);
+    float4 Aa0 = *(const float4*)s_a[ja0], Qa0 = *(const float4*)s_co[ja0], Ab0 = *(const float4*)s_a[jb0], Qb0 = *(const float4*)s_co[jb0];
+    for (int ii = 0; ii < nq; ii += 4) {
+      // set 1 <- records of pair ii + 2 (indices loaded one half-iteration ago); indices of pair ii + 4
+      const float4 Aa1 = *(const float4*)s_a[ja1], Qa1 = *(const float4*)s_co[ja1], Ab1 = *(const float4*)s_a[jb1], Qb1 = *(const float4*)s_co[jb1];
+      int jan, jbn;
+      pair_idx(ii + 4, jan, jbn);
+      blend(ja0, Aa0, Qa0, true);
+      blend(jb0, Ab0, Qb0, ii + 1 < nq);
+      if (__ballot(!done) == 0ull) break;
+      // set 0 <- records of pair ii + 4; indices of pair ii + 6
+      Aa0 = *(const float4*)s_a[jan], Qa0 = *(const float4*)s_co[jan], Ab0 = *(const float4*)s_a[jbn], Qb0 = *(const float4*)s_co[jbn];
+      const int ja1c = ja1, jb1c = jb1;
+      pair_idx(ii + 6, ja1, jb1);
+      blend(ja1c, Aa1, Qa1, ii + 2 < nq);
+      blend(jb1c, Ab1, Qb1, ii + 3 < nq);
+      ja0 = jan, jb0 = jbn;
+      if (__ballot(!done) == 0ull) break;
     }
     if (NT) {
       __syncthreads();
@@ -1329,25 +1368,20 @@ __global__ __launch_bounds__(256, 2) void composite_feat5_kernel(const Cam* __re
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int j = 2 * pr + e;
-        float wv = 0.f;
-        if (!done && k * CH + j < n) {
-          const float dx = rb[j][0] - pxf, dy = rb[j][1] - pyf;
-          const float4 co = *(const float4*)&rb[j][4];
-          const float sigma = conic_sigma(co.x, co.y, co.z, dx, dy);
-          if (sigma >= 0.0f) {
-            const float a = fminf(alpha_max, co.w * exp_det(-sigma));
-            if (a >= alpha_min) {
-              const float nT = __builtin_fmaf(-T, a, T);
-              if (nT <= t_min) {
-                done = true;
-              } else {
-                wv = a * T;
-                O += wv;
-                T = nT;
-              }
-            }
-          }
-        }
+        // branch-free per lane (round 6; four nested tests before: the same operations in the same order for every lane that blends,
+        // a zero weight for the others -- O + 0 and T stay as they are)
+        const float dx = rb[j][0] - pxf, dy = rb[j][1] - pyf;
+        const float4 co = *(const float4*)&rb[j][4];
+        const float sigma = conic_sigma(co.x, co.y, co.z, dx, dy);
+        const float a = fminf(alpha_max, co.w * exp_det_sel(-sigma));
+        const float nT = __builtin_fmaf(-T, a, T);
+        const bool reach = !done && k * CH + j < n && sigma >= 0.0f && a >= alpha_min;
+        const bool sat = reach && nT <= t_min;
+        done = done || sat;
+        const bool ok = reach && !sat;
+        const float wv = ok ? a * T : 0.f;
+        O += wv;
+        T = ok ? nT : T;
         w[e] = wv;
       }
       if (__ballot(w[0] != 0.f || w[1] != 0.f) == 0ull) continue;
