@@ -442,6 +442,39 @@ def test_crowded_tile_and_equal_depths():
     assert float(np.abs(out["opacity"].cpu().numpy() - ref["alpha"]).max()) <= 5e-6
 
 
+def test_k2_non_finite_colour_stays_inside_its_footprint():
+    """The RGB composite evaluates alpha branch-free for every lane of a quadrant (round 6) but blends inside ONE predicated block: a
+    Gaussian whose precomputed colour is not finite may only reach the pixels it blends into -- every other pixel of the frame,
+    including those of the same 8 x 8 quadrants, keeps the bits of the render without that Gaussian's colour (a zero-weight
+    multiply-add over all lanes would turn 0 * inf into NaN there)."""
+    from siu3r_amd import raster
+
+    H, W = 96, 128
+    means, cov, opac, sh = random_scene(3000, seed=21)
+    cov6 = raster.cov6_from_cov3x3(cov)
+    g = torch.Generator().manual_seed(22)
+    col = torch.rand(3000, 1, 3, generator=g)
+    cam = _k2_cam(H, W, seed=2)
+    cam.sh_degree = -1  # precomputed colours, blended as given
+    base = raster.rasterize_k2(cam, means.cuda(), cov6.cuda(), col.cuda(), opac.cuda())
+    nt = base["n_touched"].cpu().numpy()
+    cand = np.nonzero((nt > 4) & (nt < 200))[0]
+    assert cand.size > 10
+    bad = int(cand[cand.size // 2])
+    col2 = col.clone()
+    col2[bad, 0, 1] = float("inf")
+    out = raster.rasterize_k2(cam, means.cuda(), cov6.cuda(), col2.cuda(), opac.cuda())
+    img, ref = out["image"].cpu().numpy(), base["image"].cpu().numpy()
+    hit = ~np.isfinite(img).all(0)
+    rad = int(np.asarray(base["radii"].cpu().numpy()).reshape(-1, 2)[bad].max())
+    ys, xs = np.nonzero(hit)
+    assert hit.sum() > 0 and ys.max() - ys.min() <= 2.3 * rad + 3 and xs.max() - xs.min() <= 2.3 * rad + 3, (int(hit.sum()), rad)  # (radii are 3 sigma; alpha >= 1/255 reaches 3.33 sigma)
+    blocks = hit[: H // 8 * 8, : W // 8 * 8].reshape(H // 8, 8, W // 8, 8).sum((1, 3))
+    assert ((blocks > 0) & (blocks < 64)).any(), "the poisoned pixels are whole 8 x 8 quadrants"
+    assert np.array_equal(img[:, ~hit], ref[:, ~hit]), "a pixel outside the footprint changed"
+    assert np.array_equal(out["n_touched"].cpu().numpy(), nt) and torch.equal(out["depth"], base["depth"])
+
+
 @pytest.mark.parametrize("post", [True, False], ids=["post_blend", "pre_blend"])
 def test_n_touched_gate_is_a_parameter(post):
     """n_touched counts a pixel while the transmittance after (MonoGS fork: `test_T > 0.5f`) or before the blend exceeds 0.5:
