@@ -3,10 +3,6 @@
 tag=${1:-r03}
 O=gpurun_out
 mkdir -p $O
-timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${tag}_bench.json 2> $O/${tag}_bench.err  # (the driver's arguments)
-timeout 400 python bench.py --batch 8 --no-cpu-baseline --no-render > $O/${tag}_bench_b8.json 2>> $O/${tag}_bench.err
-ROCPROF_HEAD=3 bash tools/rocprof_cmd.sh ${tag}_bench python bench.py --no-cpu-baseline > /dev/null
-tail -1 $O/${tag}_bench_out.txt > $O/${tag}_bench_under_rocprof.json
 # launches / device time per step and kernel: difference of a 25-step and a 5-step profile
 Bq="--no-second-mode --no-roofline --no-render --no-cpu-baseline --warmup 3"
 ROCPROF_HEAD=1 bash tools/rocprof_cmd.sh ${tag}_s5 python bench.py $Bq --steps 5 > /dev/null
@@ -39,6 +35,13 @@ for us, c, n in rows:
     print(f"{us:9.1f} us/step {c:7.1f} launches/step  {n[:170]}")
 PY
 bash tools/pmc_round.sh $tag > $O/${tag}_pmc_round.log 2>&1
+# The profiles bench.py READS (per-kernel averages of the eager and the replayed step, counter summaries) are installed into profiles/ of THIS
+# copy of the tree before the bench lines run: the line's `consistency` / `traffic` / `in_step` then refer to this call on this board
+for f in eager_step_kernels.txt step_kernels.txt pmc_summary.json mfma_busy.json; do [ -s $O/${tag}_$f ] && cp $O/${tag}_$f profiles/${tag}_$f; done
+timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${tag}_bench.json 2> $O/${tag}_bench.err  # (the driver's arguments)
+timeout 400 python bench.py --batch 8 --no-cpu-baseline --no-render > $O/${tag}_bench_b8.json 2>> $O/${tag}_bench.err
+ROCPROF_HEAD=3 bash tools/rocprof_cmd.sh ${tag}_bench python bench.py --no-cpu-baseline > /dev/null
+tail -1 $O/${tag}_bench_out.txt > $O/${tag}_bench_under_rocprof.json
 ROCPROF_HEAD=12 bash tools/rocprof_cmd.sh ${tag}_raster_stress python tools/mb_raster.py stress > $O/${tag}_raster_stress.log 2>&1
 ROCPROF_HEAD=12 bash tools/rocprof_cmd.sh ${tag}_raster_pair python tools/mb_raster.py pair 6 > $O/${tag}_raster_pair.log 2>&1
 timeout 600 python tools/config3.py > $O/${tag}_config3.json 2> $O/${tag}_config3.err
