@@ -364,7 +364,7 @@ def gemm_roofline(model, step, precision, B, H, W, passes=3):
         return pn, (sum(c * ns for c, ns in prow) / max(1e-9, sum(c for c, _ in prow)) / 1e3 if prow else None)
 
     prof_name, prof_avg_us = prof_avg("eager_step_kernels.txt")
-    same_regime = prof_name is not None and prof_name.endswith("eager_step_kernels.txt")
+    same_regime = prof_name is not None and prof_name.endswith("eager_step_kernels.txt") and B == 1 and (H, W) == (512, 512)  # (the committed profiles are one pair per step)
     step_name, step_avg_us = prof_avg("step_kernels.txt")
     check = {"dominant_ms_le_eager_step": bool(d["ms"] <= eager_step_ms), "gemm_ms_le_eager_step": bool(gemm_ms <= eager_step_ms),
              "eager_single_stream_step_ms": eager_step_ms, "profile": prof_name, "profile_is_same_regime": same_regime,
