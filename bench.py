@@ -370,6 +370,13 @@ def gemm_roofline(model, step, precision, B, H, W, passes=3):
              "eager_single_stream_step_ms": eager_step_ms, "profile": prof_name, "profile_is_same_regime": same_regime,
              "profile_avg_launch_us": prof_avg_us, "ratio_to_profile": (avg_us / prof_avg_us) if prof_avg_us else None,
              "agrees_with_profile_within_10pct": bool(abs(avg_us / prof_avg_us - 1.0) <= 0.10) if (prof_avg_us and same_regime) else None}
+    # (boards of the pool sustain clocks +-3.5 % apart on one tree -- DESIGN.md section 5, round 6 item 12 -- and the event pairs include
+    # the launch gap, +5-8 %: on a slower board than the committed profile's the ratio passes 1.10; the line says which board the profile is from)
+    try:
+        pb = open(os.path.join(ROOT, "profiles", os.path.basename(prof_name or "").split("_")[0] + "_profile_board.txt")).read().strip()  # (written by tools/evidence_round.sh)
+    except Exception:
+        pb = None
+    check["profile_board"], check["same_board_as_profile"] = pb, (pb == _board_id()) if pb else None
     in_step = None
     if step_avg_us and step_name.endswith("step_kernels.txt") and not step_name.endswith("eager_step_kernels.txt"):
         in_step = {"source": step_name + " (replayed multi-stream step under rocprofv3 --kernel-trace: the chains run beside each other)", "live": False,

@@ -38,6 +38,7 @@ bash tools/pmc_round.sh $tag > $O/${tag}_pmc_round.log 2>&1
 # The profiles bench.py READS (per-kernel averages of the eager and the replayed step, counter summaries) are installed into profiles/ of THIS
 # copy of the tree before the bench lines run: the line's `consistency` / `traffic` / `in_step` then refer to this call on this board
 for f in eager_step_kernels.txt step_kernels.txt pmc_summary.json mfma_busy.json; do [ -s $O/${tag}_$f ] && cp $O/${tag}_$f profiles/${tag}_$f; done
+python -c "import torch; print(torch.cuda.get_device_properties(0).uuid)" 2>/dev/null | tail -1 > $O/${tag}_profile_board.txt; cp $O/${tag}_profile_board.txt profiles/${tag}_profile_board.txt  # the board these profiles are from
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${tag}_bench.json 2> $O/${tag}_bench.err  # (the driver's arguments)
 timeout 400 python bench.py --batch 8 --no-cpu-baseline --no-render > $O/${tag}_bench_b8.json 2>> $O/${tag}_bench.err
 ROCPROF_HEAD=3 bash tools/rocprof_cmd.sh ${tag}_bench python bench.py --no-cpu-baseline > /dev/null
