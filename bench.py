@@ -326,6 +326,20 @@ def gemm_roofline(model, step, precision, B, H, W, passes=3):
         model._ctx.concurrent = conc
         ops.set_kernel_timer(None)
     eager_step_ms = statistics.median(r[1] for r in runs)
+    # what an event pair adds to a launch: pairs around a 64-float kernel, queued behind a sleep kernel like the passes above (the pair's own
+    # barrier packets and the kernel boundary; the trivial kernel itself is ~1.5 us of it).  Reported, NOT subtracted from anything.
+    pair_floor_us = None
+    try:
+        from siu3r_amd import raster as _r
+        x64 = torch.zeros(64, device="cuda")
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+        torch.cuda._sleep(int(2.0e7))
+        for a_, b_ in evs:
+            a_.record(); _r.scale_inplace_(x64, 1.0); b_.record()
+        torch.cuda.synchronize()
+        pair_floor_us = statistics.median(a_.elapsed_time(b_) for a_, b_ in evs) * 1e3
+    except Exception:
+        pass
     summ = {}
     for k in runs[0][0]:
         per = [r[0][k] for r in runs if k in r[0]]
@@ -393,6 +407,7 @@ def gemm_roofline(model, step, precision, B, H, W, passes=3):
         "mfma_busy_counter_frac": busy, "mfma_busy_live": False,
         "mfma_busy_source": "profiles/" + os.path.basename(BUSY_FILE) + " (SQ_VALU_MFMA_BUSY_CYCLES pass, all instantiations)" if busy is not None else None,
         "launches_per_step": d["launches"], "avg_launch_us": avg_us,
+        "event_pair_around_a_64_float_kernel_us": pair_floor_us,  # what the timing method adds to every launch (the profile's per-kernel durations do not carry it)
         "algorithmic_flops_per_launch_avg": d["flops"] / d["launches"],
         "share_of_gemm_time": d["ms"] / gemm_ms,
         "gemm_time_ms_per_step": gemm_ms,
