@@ -519,7 +519,11 @@ __global__ __launch_bounds__(256, 4) void msdeform_kernel(const void* value, int
 constexpr int GN_T = 1024;
 __global__ __launch_bounds__(GN_T) void gn_stats_kernel(const void* x, int x_dtype, float* stats, int HW, int C,
                                                         int groups, float eps) {
-  const int n = blockIdx.y, g = blockIdx.x;
+  // workgroups go to the XCDs round robin (linear id % 8) and every XCD has its own L2: neighbouring groups share 128-byte lines (a group
+  // of the network is 8 channels = 32 bytes of a pixel's 1 KB row), so the groups of one line are given to ONE XCD -- with consecutive
+  // groups on consecutive XCDs every L2 fetched every line for a quarter of it
+  const int n = blockIdx.y, bx = blockIdx.x;
+  const int g = groups % 8 == 0 ? (bx % 8) * (groups / 8) + bx / 8 : bx;
   const int cg = C / groups, cg4 = cg >> 2;
   const int64_t total = (int64_t)HW * cg4;
   double s = 0.0, ss = 0.0;
